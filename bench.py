@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbit/s of raw bitstream scanned (LAP_ANY, max_ac_errors = 2) on MI355X.
+
+Workload (BASELINE.json configs[1]): promiscuous LAP_ANY access-code scan of a 4 GiB
+single-channel packed bitstream resident in HBM (2^35 symbols; iid noise plus one ID-packet
+sync word with 0..3 bit errors every 4096 symbols, generated on the device by
+btbbx_synth_device).  One "step" = one pass of the scan kernel over the whole stream.
+With --gpus N every rank scans its own 4 GiB time shard of the same logical stream (weak
+scaling, no data-path collective); torch.distributed is used for the barrier and for the
+max-over-ranks of the timing only.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
+(nbits / 8 read + 16 B per reported hit written) / mean kernel time from HIP events on the
+launch stream, against the 8 TB/s HBM peak.  `cpu_baseline` = the UNMODIFIED reference
+(oracle/_ref/libbtbb_ref.so, all-matches loop around btbb_find_ac) -- or, if that file is
+missing, the oracle port -- timed on this box's host cores over a bounded slice of the same
+stream; its hit list is also compared with the GPU's (field "parity").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+SEED = 20260926
+STRIDE = 4096
+
+
+def cpu_baseline(words_host, first_word, gpu_hits, cores):
+    """Reference (or port) all-matches scan of `words_host` on `cores` host threads."""
+    import _libs
+    from libbtbb_amd import synth
+    ref = _libs.ref()
+    kind = "reference" if ref is not None else "port"
+    if ref is not None:
+        ref.btbb_init(2)
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    t0 = time.perf_counter()
+    sym = np.ascontiguousarray(synth.unpack_bits(words_host))      # one symbol per byte (reference layout)
+    unpack_s = time.perf_counter() - t0
+    n = len(sym) - 63
+    bounds = np.linspace(0, n, cores + 1).astype(np.int64)
+
+    def work(i):
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        if ref is not None:
+            # the caller loop of SURVEY.md 8(b): first-match API, resume one past each hit
+            out, off = [], lo
+            pkt = C.c_void_p(None)
+            base = sym.ctypes.data
+            while off < hi:
+                r = ref.btbb_find_ac(C.c_void_p(base + off), hi - off, 0xFFFFFFFF, 2, C.byref(pkt))
+                if r < 0:
+                    break
+                out.append((off + r, int(ref.btbb_packet_get_lap(pkt)), int(ref.btbb_packet_get_ac_errors(pkt))))
+                off += r + 1
+            if pkt.value:
+                ref.btbb_packet_unref(pkt)
+            return out
+        seg = sym[lo:hi + 63]
+        return [(o + lo, l, e) for (o, l, e) in _libs.orc_find_all(np.ascontiguousarray(seg), hi - lo, 0xFFFFFFFF, 2)]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        parts = list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    cpu_hits = [h for p in parts for h in p]
+    lo_bit = first_word * 64
+    sel = gpu_hits[(gpu_hits["offset"] >= lo_bit) & (gpu_hits["offset"] < lo_bit + n)]
+    sel = sel[np.argsort(sel["offset"], kind="stable")]
+    gpu_list = [(int(h["offset"]) - lo_bit, int(h["lap"]), int(h["ac_errors"])) for h in sel]
+    return {
+        "value": round(n / dt / 1e9, 4), "unit": "Gbit/s", "cores": cores, "kind": kind,
+        "sample": "first %d symbols of the same stream, %d threads x all-matches loop around btbb_find_ac "
+                  "(one symbol per byte; unpack %.2f s excluded)" % (n, cores, unpack_s),
+        "hits": len(cpu_hits),
+    }, cpu_hits == gpu_list
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gib", type=float, default=4.0, help="packed stream size per GPU in GiB")
+    ap.add_argument("--cpu-symbols", type=int, default=1 << 30, help="size of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus must match WORLD_SIZE"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import libbtbb_amd as bt
+    bt.init(2)
+    lib = bt.lib()
+
+    nwords = int(args.gib * (1 << 30)) // 8
+    nbits = nwords * 64 - 63
+    first_word = rank * nwords                     # time shard of the logical stream
+    stream = torch.empty(nwords, dtype=torch.int64, device=dev)
+    cap = nbits // STRIDE + (1 << 16)              # injections + chance matches + slack
+    hits_t = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    cnt_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    hs = C.c_void_p(cur.cuda_stream)
+
+    bt.check(lib.btbbx_synth_device(stream.data_ptr(), first_word, nwords, SEED, STRIDE, -1, 4, hs))
+    torch.cuda.synchronize()
+
+    def step():
+        cnt_t.zero_()
+        bt.check(lib.btbbx_scan_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2,
+                                       hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        cnt_t.zero_()
+        ev[k][0].record(cur)
+        bt.check(lib.btbbx_scan_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2,
+                                       hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
+        ev[k][1].record(cur)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    nhits = int(cnt_t.item())
+    assert nhits <= cap, "hit buffer overflow"
+    t_el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t_el[0]), float(t_el[1])
+
+    result = None
+    if rank == 0:
+        value = world * nbits * args.steps / elapsed / 1e9
+        alg_bytes = nbits / 8 + 16 * nhits
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Gbit/s raw bitstream scanned (LAP_ANY, err<=2)",
+            "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "promiscuous LAP_ANY scan, %.3g GiB packed single-channel synthetic "
+                                   "bitstream per GPU, max_ac_errors=2, sync word every %d symbols"
+                                   % (args.gib, STRIDE),
+                       "symbols_per_gpu": nbits, "hits_per_gpu": nhits,
+                       "parallelism": "time-sharded x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "scan_lap_any_kernel", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu:
+            ncpu_words = min(nwords, (args.cpu_symbols + 63) // 64)
+            words_host = stream[:ncpu_words].cpu().numpy().view(np.uint64)
+            raw = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:nhits]
+            cores = max(1, min(os.cpu_count() or 1, 64))
+            base, parity = cpu_baseline(words_host, 0, raw, cores)
+            result["cpu_baseline"] = base
+            result["parity"] = bool(parity)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,162 @@
+/*
+ * btbb.h -- drop-in public header of the MI355X-native Bluetooth baseband library.
+ *
+ * Source compatible with libbtbb's lib/src/btbb.h for the baseband hot path: the same
+ * names, argument meaning, return values and ownership rules, so Ubertooth /
+ * gr-bluetooth style callers compile and link unchanged (SONAME libbtbb.so.1).
+ * The computation behind every function that touches symbols runs in hand-written
+ * gfx950 HIP kernels; there is NO CPU fallback.  Without a usable GPU btbb_init()
+ * returns a negative value and the search/decode functions report "not found" /
+ * failure after printing a diagnostic to stderr.
+ *
+ * Each declaration cites the reference declaration it replaces
+ * (lib/src/btbb.h:<line> in /root/reference).
+ *
+ * Not provided (outside the hot path): hop reversal
+ * (btbb_init_hop_reversal / btbb_winnow), pcap/pcapng writers, BLE (lell_*).
+ */
+#ifndef INCLUDED_BTBB_H
+#define INCLUDED_BTBB_H
+
+#include <stdint.h>
+
+/* packet / piconet flag numbers -- btbb.h:27-42 */
+#define BTBB_WHITENED    0
+#define BTBB_NAP_VALID   1
+#define BTBB_UAP_VALID   2
+#define BTBB_LAP_VALID   3
+#define BTBB_CLK6_VALID  4
+#define BTBB_CLK27_VALID 5
+#define BTBB_CRC_CORRECT 6
+#define BTBB_HAS_PAYLOAD 7
+#define BTBB_IS_EDR      8
+
+#define BTBB_HOP_REVERSAL_INIT 9
+#define BTBB_GOT_FIRST_PACKET  10
+#define BTBB_IS_AFH            11
+#define BTBB_LOOKS_LIKE_AFH    12
+#define BTBB_IS_ALIASED        13
+#define BTBB_FOLLOWING         14
+
+/* payload modulation -- btbb.h:44-47 */
+#define BTBB_MOD_GFSK              0x00
+#define BTBB_MOD_PI_OVER_2_DQPSK   0x01
+#define BTBB_MOD_8DPSK             0x02
+
+/* transport types -- btbb.h:49-54 */
+#define BTBB_TRANSPORT_ANY     0x00
+#define BTBB_TRANSPORT_SCO     0x01
+#define BTBB_TRANSPORT_ESCO    0x02
+#define BTBB_TRANSPORT_ACL     0x03
+#define BTBB_TRANSPORT_CSB     0x04
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+typedef struct btbb_packet btbb_packet;      /* btbb.h:63 */
+typedef struct btbb_piconet btbb_piconet;    /* btbb.h:161 */
+
+/* btbb.h:73 -- build the syndrome tables (on the GPU) for up to max_ac_errors (0..5)
+ * corrected bit errors.  0 on success, negative on error.  As in the reference the
+ * first non-zero value sticks. */
+int btbb_init(int max_ac_errors);
+
+const char* btbb_get_release(void);          /* btbb.h:75 */
+const char* btbb_get_version(void);          /* btbb.h:76 */
+
+btbb_packet *btbb_packet_new(void);          /* btbb.h:78 */
+void btbb_packet_ref(btbb_packet *pkt);      /* btbb.h:79 */
+void btbb_packet_unref(btbb_packet *pkt);    /* btbb.h:80 */
+
+/* btbb.h:90-94 -- search `stream` (one 0/1 symbol per byte, air order, at least
+ * search_length + 72 symbols long) for an access code with the given LAP or LAP_ANY,
+ * tolerating max_ac_errors bit errors.  Returns the offset of the first match or a
+ * negative number; on a match *pkt is allocated if NULL and LAP / ac_errors / flags
+ * are (re)initialised. */
+int btbb_find_ac(char *stream,
+	       int search_length,
+	       uint32_t lap,
+	       int max_ac_errors,
+	       btbb_packet **pkt);
+#define LAP_ANY 0xffffffffUL                 /* btbb.h:95 */
+#define UAP_ANY 0xff                         /* btbb.h:96 */
+
+void btbb_packet_set_flag(btbb_packet *pkt, int flag, int val);      /* btbb.h:98 */
+int btbb_packet_get_flag(const btbb_packet *pkt, int flag);          /* btbb.h:99 */
+
+uint32_t btbb_packet_get_lap(const btbb_packet *pkt);                /* btbb.h:101 */
+void btbb_packet_set_uap(btbb_packet *pkt, uint8_t uap);             /* btbb.h:102 */
+uint8_t btbb_packet_get_uap(const btbb_packet *pkt);                 /* btbb.h:103 */
+uint16_t btbb_packet_get_nap(const btbb_packet *pkt);                /* btbb.h:104 */
+
+void btbb_packet_set_modulation(btbb_packet *pkt, uint8_t modulation);   /* btbb.h:106 */
+void btbb_packet_set_transport(btbb_packet *pkt, uint8_t transport);     /* btbb.h:107 */
+uint8_t btbb_packet_get_modulation(const btbb_packet *pkt);              /* btbb.h:108 */
+uint8_t btbb_packet_get_transport(const btbb_packet *pkt);               /* btbb.h:109 */
+
+uint8_t btbb_packet_get_channel(const btbb_packet *pkt);             /* btbb.h:111 */
+uint8_t btbb_packet_get_ac_errors(const btbb_packet *pkt);           /* btbb.h:112 */
+uint32_t btbb_packet_get_clkn(const btbb_packet *pkt);               /* btbb.h:113 */
+uint32_t btbb_packet_get_header_packed(const btbb_packet* pkt);      /* btbb.h:114 */
+
+/* btbb.h:116-120 -- copy up to 3125 symbols into the packet; clkn is CLK27-0 */
+void btbb_packet_set_data(btbb_packet *pkt,
+			  char *syms,
+			  int length,
+			  uint8_t channel,
+			  uint32_t clkn);
+
+const char *btbb_get_symbols(const btbb_packet* pkt);                /* btbb.h:123 */
+int btbb_packet_get_payload_length(const btbb_packet* pkt);          /* btbb.h:125 */
+const char *btbb_get_payload(const btbb_packet* pkt);                /* btbb.h:128 */
+int btbb_get_payload_packed(const btbb_packet* pkt, char *dst);      /* btbb.h:131 */
+
+uint8_t btbb_packet_get_type(const btbb_packet* pkt);                /* btbb.h:133 */
+uint8_t btbb_packet_get_lt_addr(const btbb_packet* pkt);             /* btbb.h:134 */
+uint8_t btbb_packet_get_header_flags(const btbb_packet* pkt);        /* btbb.h:135 */
+uint8_t btbb_packet_get_hec(const btbb_packet *pkt);                 /* btbb.h:136 */
+
+uint64_t btbb_gen_syncword(const int LAP);                           /* btbb.h:139 */
+
+int btbb_decode_header(btbb_packet* pkt);                            /* btbb.h:142 */
+int btbb_decode_payload(btbb_packet* pkt);                           /* btbb.h:145 */
+void btbb_print_packet(const btbb_packet* pkt);                      /* btbb.h:148 */
+int btbb_header_present(const btbb_packet* pkt);                     /* btbb.h:151 */
+
+btbb_piconet *btbb_piconet_new(void);                                /* btbb.h:163 */
+void btbb_piconet_ref(btbb_piconet *pn);                             /* btbb.h:164 */
+void btbb_piconet_unref(btbb_piconet *pn);                           /* btbb.h:165 */
+void btbb_init_piconet(btbb_piconet *pn, uint32_t lap);              /* btbb.h:168 */
+
+void btbb_piconet_set_uap(btbb_piconet *pn, uint8_t uap);            /* btbb.h:170 */
+uint8_t btbb_piconet_get_uap(const btbb_piconet *pn);                /* btbb.h:171 */
+uint32_t btbb_piconet_get_lap(const btbb_piconet *pn);               /* btbb.h:172 */
+uint16_t btbb_piconet_get_nap(const btbb_piconet *pn);               /* btbb.h:173 */
+uint64_t btbb_piconet_get_bdaddr(const btbb_piconet *pn);            /* btbb.h:174 */
+int btbb_piconet_get_clk_offset(const btbb_piconet *pn);             /* btbb.h:176 */
+void btbb_piconet_set_clk_offset(btbb_piconet *pn, int clk_offset);  /* btbb.h:177 */
+void btbb_piconet_set_flag(btbb_piconet *pn, int flag, int val);     /* btbb.h:179 */
+int btbb_piconet_get_flag(const btbb_piconet *pn, int flag);         /* btbb.h:180 */
+uint8_t btbb_piconet_set_channel_seen(btbb_piconet *pn, uint8_t channel);    /* btbb.h:182 */
+uint8_t btbb_piconet_clear_channel_seen(btbb_piconet *pn, uint8_t channel);  /* btbb.h:183 */
+uint8_t btbb_piconet_get_channel_seen(btbb_piconet *pn, uint8_t channel);    /* btbb.h:184 */
+uint8_t *btbb_piconet_get_afh_map(btbb_piconet *pn);                 /* btbb.h:186 */
+
+/* btbb.h:189 -- extract LAP/UAP/CLK information from a received packet */
+int btbb_process_packet(btbb_packet *pkt, btbb_piconet *pn);
+/* btbb.h:192 -- use packet headers to determine UAP (64 CLK1-6 candidates on the GPU) */
+int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn);
+void btbb_print_afh_map(btbb_piconet *pn);                           /* btbb.h:195 */
+/* btbb.h:198 -- decode a whole packet */
+int btbb_decode(btbb_packet* pkt);
+
+int btbb_init_survey(void);                                          /* btbb.h:208 */
+btbb_piconet *btbb_next_survey_result(void);                         /* btbb.h:210 */
+
+#ifdef __cplusplus
+} // __cplusplus defined.
+#endif
+
+#endif /* INCLUDED_BTBB_H */

@@ -1,0 +1,167 @@
+/*
+ * btbbx.h -- batch (GPU-resident) entry points of the MI355X baseband scanner.
+ *
+ * Additive to the drop-in API in btbb.h.  Plain C ABI: pointers and sizes only.
+ * Everything here runs on the GPU through hand-written gfx950 HIP kernels; there
+ * is no CPU fallback -- every entry point fails with BTBBX_E_NODEVICE when no HIP
+ * device is usable.
+ *
+ * Data layout ("packed stream"): LSB-first 64-bit words, stream bit i is bit
+ * (i % 64) of word (i / 64), so that the 64-symbol window starting at bit c has
+ * the value the reference obtains from air_to_host64(&stream[c], 64)
+ * (lib/src/bluetooth_packet.c:235-242).
+ *
+ * Reference interfaces replaced (relative to /root/reference):
+ *   btbbx_scan_*      <- the caller loop around btbb_find_ac, lib/src/btbb.h:82-94,
+ *                        lib/src/bluetooth_packet.c:368-464 (all matches, not first)
+ *   btbbx_pack_*      <- the one-symbol-per-byte convention of btbb.h:90,116
+ *   btbbx_trials_*    <- try_clock + crc_check over the 64 CLK1-6 candidates,
+ *                        lib/src/bluetooth_piconet.c:675-690,
+ *                        lib/src/bluetooth_packet.c:708-769, 1178-1195
+ *   btbbx_decode_*    <- btbb_header_present / btbb_decode_header / btbb_decode_payload,
+ *                        lib/src/bluetooth_packet.c:1198-1297, 1371-1408
+ */
+#ifndef INCLUDED_BTBBX_H
+#define INCLUDED_BTBBX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTBBX_OK            0
+#define BTBBX_E_NODEVICE   -2   /* no usable HIP device / runtime error (see btbbx_last_error) */
+#define BTBBX_E_ARG        -3   /* bad argument */
+#define BTBBX_E_NOTINIT    -4   /* btbbx_init / btbb_init not called */
+#define BTBBX_E_NOMEM      -5
+
+#define BTBBX_LAP_ANY 0xffffffffu
+#define BTBBX_MAX_SYMBOLS 3125            /* bluetooth_packet.h:27 */
+#define BTBBX_PKT_WORDS 50                /* 3200 bits >= 3125 symbols, one packed packet */
+
+/* one detected access code */
+typedef struct btbbx_hit {
+	uint64_t offset;      /* symbol index of the first sync-word bit inside its stream */
+	uint32_t lap;         /* LAP recovered (LAP_ANY) or searched for */
+	uint8_t  ac_errors;   /* as btbb_packet_get_ac_errors() would report */
+	uint8_t  reserved;
+	uint16_t stream;      /* stream (channel) index of the launch */
+} btbbx_hit;
+
+/* result of one (packet, clock) trial: what try_clock + crc_check leave behind */
+typedef struct btbbx_trial {
+	uint8_t uap;          /* try_clock() return value / pkt->UAP */
+	uint8_t type;         /* pkt->packet_type after try_clock */
+	int16_t rv;           /* crc_check() return value: 0, 1, 2, 10 or 1000 */
+} btbbx_trial;
+
+/* one packet to decode: where it is and what is known about it */
+typedef struct btbbx_pkt_in {
+	uint32_t length;      /* symbols captured, <= 3125 (btbb_packet_set_data clamps) */
+	uint32_t clkn;        /* CLK1-27 as stored by set_data (caller's clkn >> 1) */
+	uint32_t flags;       /* packet flags (BTBB_WHITENED etc., btbb.h:27-35) */
+	uint8_t  uap;         /* pkt->UAP on entry */
+	uint8_t  type;        /* pkt->packet_type on entry (state left by earlier calls) */
+	uint8_t  llid;        /* pkt->payload_llid on entry */
+	uint8_t  flow;        /* pkt->payload_flow on entry */
+} btbbx_pkt_in;
+
+/* everything btbb_decode_header + btbb_decode_payload write into a packet */
+typedef struct btbbx_pkt_out {
+	int32_t  header_rv;          /* btbb_decode_header() */
+	int32_t  payload_rv;         /* btbb_decode_payload() (0 if header failed) */
+	int32_t  payload_length;
+	int32_t  payload_header_length;
+	uint32_t flags;              /* packet flags afterwards */
+	uint32_t header_packed;      /* 18 unwhitened header bits */
+	uint8_t  header_present;     /* btbb_header_present() */
+	uint8_t  type, lt_addr, hdr_flags, hec;
+	uint8_t  llid, flow, uap;
+	uint64_t payload_header;     /* 16 payload-header bits, LSB first */
+	uint64_t payload[43];        /* 2744 payload bits, LSB first */
+} btbbx_pkt_out;
+
+/* ---- context ---------------------------------------------------------------- */
+/* Build the device tables for searches correcting up to max_ac_errors (0..5) bit
+ * errors on the CURRENT HIP device.  Like btbb_init() the first non-zero value wins
+ * (bluetooth_packet.c:288-289).  Returns 0 or a negative BTBBX_E_*. */
+int btbbx_init(int max_ac_errors);
+void btbbx_shutdown(void);
+const char *btbbx_last_error(void);
+int btbbx_device_count(void);
+int btbbx_table_errors(void);          /* the max_ac_errors the tables were built with */
+
+/* ---- device memory helpers (so C callers need not link HIP themselves) -------- */
+void *btbbx_malloc(size_t bytes);
+void btbbx_free(void *dptr);
+int btbbx_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int btbbx_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int btbbx_memset(void *dptr, int value, size_t bytes);
+int btbbx_sync(void *hip_stream);
+
+/* ---- access-code scan -------------------------------------------------------- */
+/* All pointers are DEVICE pointers.  n_streams packed streams of n_words words each
+ * lie pitch_words apart; offsets [0, search_bits) of every stream are tested, which
+ * needs search_bits + 63 <= 64 * n_words.  Hits are appended (unordered) to d_hits,
+ * *d_hit_count counts ALL hits even beyond hit_cap.  The caller zeroes *d_hit_count.
+ * Asynchronous on hip_stream (NULL = the null stream). */
+int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+		      uint32_t n_streams, uint64_t search_bits,
+		      uint32_t lap, int max_ac_errors,
+		      btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
+		      void *hip_stream);
+
+/* First match only (btbb_find_ac semantics) of ONE stream: *d_first receives
+ * (offset << 32 | lap << 8 | ac_errors) of the smallest matching offset, or
+ * UINT64_MAX.  search_bits < 2^32.  The caller presets *d_first to UINT64_MAX. */
+int btbbx_scan_first_device(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits,
+			    uint32_t lap, int max_ac_errors, uint64_t *d_first,
+			    void *hip_stream);
+
+/* Host convenience wrappers (copy in, scan on the GPU, copy out, sort by
+ * (stream, offset)).  Return the number of hits found (may exceed cap; only cap are
+ * written) or a negative BTBBX_E_*. */
+int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search_bits,
+			uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
+int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
+			   uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
+void btbbx_sort_hits(btbbx_hit *hits, size_t n);
+
+/* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
+ * ceil(n_symbols / 64), the tail of the last word is zero */
+int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, uint64_t *d_words,
+		      void *hip_stream);
+int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_symbols,
+			void *hip_stream);
+
+/* ---- synthetic traffic (same generator as libbtbb_amd/synth.py) --------------- */
+/* words [first_word, first_word + n_words) of the infinite stream `seed`:
+ * iid noise plus one sync word per `stride` symbols (stride >= 512), LAP random or
+ * fixed_lap (>= 0), k % err_cycle bit errors in sync-word bits 0..56. */
+int btbbx_synth_device(uint64_t *d_words, uint64_t first_word, uint64_t n_words,
+		       uint64_t seed, uint32_t stride, int64_t fixed_lap, uint32_t err_cycle,
+		       void *hip_stream);
+
+/* ---- packet chain ------------------------------------------------------------ */
+/* Cut packets out of packed streams: packet i = bits [offset, offset + length) of
+ * stream hits[i].stream, zero padded to BTBBX_PKT_WORDS words. */
+int btbbx_gather_packets_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+				const btbbx_hit *d_hits, uint32_t n_packets, uint32_t max_length,
+				uint64_t *d_packets, uint32_t *d_lengths, void *hip_stream);
+
+/* 64 clock trials per packet: d_trials[i * 64 + c] = state after try_clock(c) and
+ * crc_check(c) run in clock order c = 0..63 on packet i (bluetooth_piconet.c:675-690
+ * with GOT_FIRST_PACKET clear).  d_in[i] gives each packet's entry state. */
+int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+			btbbx_trial *d_trials, void *hip_stream);
+
+/* header_present + decode_header + decode_payload with the clock / UAP in d_in */
+int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+			btbbx_pkt_out *d_out, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDED_BTBBX_H */

@@ -1,0 +1,296 @@
+"""libbtbb_amd -- host-side Python view of the MI355X-native Bluetooth baseband scanner.
+
+The product is the C-ABI shared library ``libbtbb_amd/libbtbb_amd.so`` (SONAME
+``libbtbb.so.1``; sources in ``libbtbb_amd/csrc``, headers in ``include/``): a drop-in for the
+baseband hot path of libbtbb whose computation runs in hand-written gfx950 HIP kernels.
+This package only *binds* it with ctypes for the tests and the benchmark -- there is no
+Python or CPU implementation of the path here, and loading fails loudly if the library has
+not been built (``python -c "import __graft_entry__ as g; g.build()"``).
+
+PyTorch (when present) is imported *before* the library so that both share one HIP runtime
+(torch bundles its own libamdhip64.so); torch tensors' ``data_ptr()`` can then be handed to
+the ``btbbx_*_device`` entry points.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # share torch's HIP runtime when torch is around (plumbing only)
+    import torch as _torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the C library
+    _torch = None
+
+from . import synth  # noqa: F401  (host-side synthetic traffic, numpy)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbtbb_amd.so")
+
+LAP_ANY = 0xFFFFFFFF
+PKT_WORDS = 50
+MAX_SYMBOLS = 3125
+
+# flag numbers (include/btbb.h)
+BTBB_WHITENED, BTBB_NAP_VALID, BTBB_UAP_VALID, BTBB_LAP_VALID = 0, 1, 2, 3
+BTBB_CLK6_VALID, BTBB_CLK27_VALID, BTBB_CRC_CORRECT, BTBB_HAS_PAYLOAD = 4, 5, 6, 7
+BTBB_GOT_FIRST_PACKET, BTBB_FOLLOWING = 10, 14
+
+
+class Hit(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("lap", C.c_uint32), ("ac_errors", C.c_uint8),
+                ("reserved", C.c_uint8), ("stream", C.c_uint16)]
+
+
+class Trial(C.Structure):
+    _fields_ = [("uap", C.c_uint8), ("type", C.c_uint8), ("rv", C.c_int16)]
+
+
+class PktIn(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("clkn", C.c_uint32), ("flags", C.c_uint32),
+                ("uap", C.c_uint8), ("type", C.c_uint8), ("llid", C.c_uint8), ("flow", C.c_uint8)]
+
+
+class PktOut(C.Structure):
+    _fields_ = [("header_rv", C.c_int32), ("payload_rv", C.c_int32), ("payload_length", C.c_int32),
+                ("payload_header_length", C.c_int32), ("flags", C.c_uint32), ("header_packed", C.c_uint32),
+                ("header_present", C.c_uint8), ("type", C.c_uint8), ("lt_addr", C.c_uint8),
+                ("hdr_flags", C.c_uint8), ("hec", C.c_uint8), ("llid", C.c_uint8), ("flow", C.c_uint8),
+                ("uap", C.c_uint8), ("payload_header", C.c_uint64), ("payload", C.c_uint64 * 43)]
+
+
+HIT_DTYPE = np.dtype([("offset", "<u8"), ("lap", "<u4"), ("ac_errors", "u1"), ("reserved", "u1"), ("stream", "<u2")])
+TRIAL_DTYPE = np.dtype([("uap", "u1"), ("type", "u1"), ("rv", "<i2")])
+PKTIN_DTYPE = np.dtype([("length", "<u4"), ("clkn", "<u4"), ("flags", "<u4"), ("uap", "u1"), ("type", "u1"),
+                        ("llid", "u1"), ("flow", "u1")])
+PKTOUT_DTYPE = np.dtype([("header_rv", "<i4"), ("payload_rv", "<i4"), ("payload_length", "<i4"),
+                         ("payload_header_length", "<i4"), ("flags", "<u4"), ("header_packed", "<u4"),
+                         ("header_present", "u1"), ("type", "u1"), ("lt_addr", "u1"), ("hdr_flags", "u1"),
+                         ("hec", "u1"), ("llid", "u1"), ("flow", "u1"), ("uap", "u1"),
+                         ("payload_header", "<u8"), ("payload", "<u8", (43,))])
+assert HIT_DTYPE.itemsize == C.sizeof(Hit) == 16
+assert TRIAL_DTYPE.itemsize == C.sizeof(Trial) == 4
+assert PKTIN_DTYPE.itemsize == C.sizeof(PktIn) == 16
+assert PKTOUT_DTYPE.itemsize == C.sizeof(PktOut)
+
+_vp, _u64, _u32 = C.c_void_p, C.c_uint64, C.c_uint32
+
+# every symbol include/btbbx.h and include/btbb.h declare: (restype, argtypes)
+SIGNATURES = {
+    # ---- btbbx.h
+    "btbbx_init": (C.c_int, [C.c_int]),
+    "btbbx_shutdown": (None, []),
+    "btbbx_last_error": (C.c_char_p, []),
+    "btbbx_device_count": (C.c_int, []),
+    "btbbx_table_errors": (C.c_int, []),
+    "btbbx_malloc": (_vp, [C.c_size_t]),
+    "btbbx_free": (None, [_vp]),
+    "btbbx_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "btbbx_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "btbbx_memset": (C.c_int, [_vp, C.c_int, C.c_size_t]),
+    "btbbx_sync": (C.c_int, [_vp]),
+    "btbbx_scan_device": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, _vp, _u32, _vp, _vp]),
+    "btbbx_scan_first_device": (C.c_int, [_vp, _u64, _u64, _u32, C.c_int, _vp, _vp]),
+    "btbbx_scan_host": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
+    "btbbx_scan_symbols": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
+    "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
+    "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "btbbx_unpack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "btbbx_synth_device": (C.c_int, [_vp, _u64, _u64, _u64, _u32, C.c_int64, _u32, _vp]),
+    "btbbx_gather_packets_device": (C.c_int, [_vp, _u64, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "btbbx_trials_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    # ---- btbb.h
+    "btbb_init": (C.c_int, [C.c_int]),
+    "btbb_get_release": (C.c_char_p, []),
+    "btbb_get_version": (C.c_char_p, []),
+    "btbb_packet_new": (_vp, []),
+    "btbb_packet_ref": (None, [_vp]),
+    "btbb_packet_unref": (None, [_vp]),
+    "btbb_find_ac": (C.c_int, [_vp, C.c_int, _u32, C.c_int, C.POINTER(_vp)]),
+    "btbb_packet_set_flag": (None, [_vp, C.c_int, C.c_int]),
+    "btbb_packet_get_flag": (C.c_int, [_vp, C.c_int]),
+    "btbb_packet_get_lap": (_u32, [_vp]),
+    "btbb_packet_set_uap": (None, [_vp, C.c_uint8]),
+    "btbb_packet_get_uap": (C.c_uint8, [_vp]),
+    "btbb_packet_get_nap": (C.c_uint16, [_vp]),
+    "btbb_packet_set_modulation": (None, [_vp, C.c_uint8]),
+    "btbb_packet_set_transport": (None, [_vp, C.c_uint8]),
+    "btbb_packet_get_modulation": (C.c_uint8, [_vp]),
+    "btbb_packet_get_transport": (C.c_uint8, [_vp]),
+    "btbb_packet_get_channel": (C.c_uint8, [_vp]),
+    "btbb_packet_get_ac_errors": (C.c_uint8, [_vp]),
+    "btbb_packet_get_clkn": (_u32, [_vp]),
+    "btbb_packet_get_header_packed": (_u32, [_vp]),
+    "btbb_packet_set_data": (None, [_vp, _vp, C.c_int, C.c_uint8, _u32]),
+    "btbb_get_symbols": (_vp, [_vp]),
+    "btbb_packet_get_payload_length": (C.c_int, [_vp]),
+    "btbb_get_payload": (_vp, [_vp]),
+    "btbb_get_payload_packed": (C.c_int, [_vp, _vp]),
+    "btbb_packet_get_type": (C.c_uint8, [_vp]),
+    "btbb_packet_get_lt_addr": (C.c_uint8, [_vp]),
+    "btbb_packet_get_header_flags": (C.c_uint8, [_vp]),
+    "btbb_packet_get_hec": (C.c_uint8, [_vp]),
+    "btbb_gen_syncword": (_u64, [C.c_int]),
+    "btbb_decode_header": (C.c_int, [_vp]),
+    "btbb_decode_payload": (C.c_int, [_vp]),
+    "btbb_print_packet": (None, [_vp]),
+    "btbb_header_present": (C.c_int, [_vp]),
+    "btbb_piconet_new": (_vp, []),
+    "btbb_piconet_ref": (None, [_vp]),
+    "btbb_piconet_unref": (None, [_vp]),
+    "btbb_init_piconet": (None, [_vp, _u32]),
+    "btbb_piconet_set_uap": (None, [_vp, C.c_uint8]),
+    "btbb_piconet_get_uap": (C.c_uint8, [_vp]),
+    "btbb_piconet_get_lap": (_u32, [_vp]),
+    "btbb_piconet_get_nap": (C.c_uint16, [_vp]),
+    "btbb_piconet_get_bdaddr": (_u64, [_vp]),
+    "btbb_piconet_get_clk_offset": (C.c_int, [_vp]),
+    "btbb_piconet_set_clk_offset": (None, [_vp, C.c_int]),
+    "btbb_piconet_set_flag": (None, [_vp, C.c_int, C.c_int]),
+    "btbb_piconet_get_flag": (C.c_int, [_vp, C.c_int]),
+    "btbb_piconet_set_channel_seen": (C.c_uint8, [_vp, C.c_uint8]),
+    "btbb_piconet_clear_channel_seen": (C.c_uint8, [_vp, C.c_uint8]),
+    "btbb_piconet_get_channel_seen": (C.c_uint8, [_vp, C.c_uint8]),
+    "btbb_piconet_get_afh_map": (_vp, [_vp]),
+    "btbb_process_packet": (C.c_int, [_vp, _vp]),
+    "btbb_uap_from_header": (C.c_int, [_vp, _vp]),
+    "btbb_print_afh_map": (None, [_vp]),
+    "btbb_decode": (C.c_int, [_vp]),
+    "btbb_init_survey": (C.c_int, []),
+    "btbb_next_survey_result": (_vp, []),
+}
+
+_lib = None
+
+
+class BtbbError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library (raises if it has not been built -- no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BtbbError(
+                "%s is missing: build it with `make -C libbtbb_amd/csrc` "
+                "(or __graft_entry__.build()); there is no Python/CPU fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError = missing export
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what="btbbx call"):
+    if rc < 0:
+        raise BtbbError("%s failed (%d): %s" % (what, rc, lib().btbbx_last_error().decode()))
+    return rc
+
+
+def init(max_ac_errors=2):
+    """btbb_init() on the current HIP device."""
+    check(lib().btbbx_init(max_ac_errors), "btbbx_init")
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------------------------
+# thin host-buffer helpers (tests, small jobs); the benchmark uses the *_device entries
+# ------------------------------------------------------------------------------------
+def scan_words(words, search_bits, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20):
+    """All access codes in a packed stream held in host memory (numpy uint64)."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    hits = np.zeros(cap, dtype=HIT_DTYPE)
+    n = check(lib().btbbx_scan_host(_ptr(words), len(words), search_bits, lap, max_ac_errors, _ptr(hits), cap),
+              "btbbx_scan_host")
+    if n > cap:
+        raise BtbbError("hit buffer too small: %d > %d" % (n, cap))
+    return hits[:n]
+
+
+def scan_symbols(symbols, search_length, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20):
+    symbols = np.ascontiguousarray(symbols, dtype=np.uint8)
+    hits = np.zeros(cap, dtype=HIT_DTYPE)
+    n = check(lib().btbbx_scan_symbols(_ptr(symbols), len(symbols), search_length, lap, max_ac_errors,
+                                       _ptr(hits), cap), "btbbx_scan_symbols")
+    if n > cap:
+        raise BtbbError("hit buffer too small: %d > %d" % (n, cap))
+    return hits[:n]
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through the library (no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().btbbx_malloc(max(self.nbytes, 8))
+        if not self.ptr:
+            raise BtbbError("btbbx_malloc(%d): %s" % (nbytes, lib().btbbx_last_error().decode()))
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(lib().btbbx_memcpy_h2d(self.ptr, _ptr(a), a.nbytes), "h2d")
+        return self
+
+    def download(self, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().btbbx_memcpy_d2h(_ptr(out), self.ptr, out.nbytes), "d2h")
+        return out
+
+    def zero(self):
+        check(lib().btbbx_memset(self.ptr, 0, self.nbytes), "memset")
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().btbbx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def packets_to_words(symbol_arrays):
+    """List of 0/1 symbol arrays -> (n, 50) packed packet words + lengths (host side packing
+    of TEST INPUT only; captured streams are packed on the GPU by btbbx_pack_device)."""
+    n = len(symbol_arrays)
+    words = np.zeros((n, PKT_WORDS), dtype=np.uint64)
+    lengths = np.zeros(n, dtype=np.uint32)
+    for i, s in enumerate(symbol_arrays):
+        s = np.asarray(s, dtype=np.uint8)[:MAX_SYMBOLS]
+        lengths[i] = len(s)
+        w = synth.pack_bits(s)
+        words[i, :len(w)] = w
+    return words, lengths
+
+
+def run_trials(packet_words, pkt_in):
+    """64 clock trials per packet on the GPU -> (n, 64) TRIAL_DTYPE."""
+    n = len(packet_words)
+    d_pk = DeviceBuffer(packet_words.nbytes).upload(packet_words)
+    d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
+    d_tr = DeviceBuffer(n * 64 * 4)
+    check(lib().btbbx_trials_device(d_pk.ptr, d_in.ptr, n, d_tr.ptr, None), "btbbx_trials_device")
+    check(lib().btbbx_sync(None))
+    return d_tr.download(TRIAL_DTYPE, n * 64).reshape(n, 64)
+
+
+def run_decode(packet_words, pkt_in):
+    """decode_header + decode_payload per packet on the GPU -> PKTOUT_DTYPE array."""
+    n = len(packet_words)
+    d_pk = DeviceBuffer(packet_words.nbytes).upload(packet_words)
+    d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
+    d_out = DeviceBuffer(n * PKTOUT_DTYPE.itemsize).zero()
+    check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
+    check(lib().btbbx_sync(None))
+    return d_out.download(PKTOUT_DTYPE, n)

@@ -1,0 +1,405 @@
+// btbb_api.cpp -- the drop-in C ABI of include/btbb.h (packet half).
+//
+// Same names, arguments, return values and ownership as libbtbb's public packet API
+// (lib/src/btbb.h:63-151, 198; implementation lib/src/bluetooth_packet.c:201-208,
+// 268-366, 444-542, 1198-1338, 1371-1408).  Host code here only keeps the packet object
+// and moves bytes; every function that looks at symbols launches the HIP kernels of
+// scan.hip / packet.hip.  There is no CPU fallback: without a GPU these functions print a
+// diagnostic and report failure.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+#include "packet_obj.h"
+#include "../../include/btbb.h"
+
+int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+		  btbbx_pkt_out *d_out, uint32_t mode, const TrialPlan *plan, hipStream_t stream);
+
+#ifndef BTBB_RELEASE
+#define BTBB_RELEASE "mi355x-r1"
+#endif
+#ifndef BTBB_VERSION
+#define BTBB_VERSION "1.0"
+#endif
+
+static const char *const type_names[16] = {
+	"NULL", "POLL", "FHS", "DM1", "DH1/2-DH1", "HV1", "HV2/2-EV3", "HV3/EV3/3-EV3",
+	"DV/3-DH1", "AUX1", "DM3/2-DH3", "DH3/3-DH3", "EV4/2-EV5", "EV5/3-EV5", "DM5/2-DH5", "DH5/3-DH5"
+};
+
+static int gpu_ready(const char *who)
+{
+	if (ctx().ready)
+		return 1;
+	// like the reference without btbb_init(): an empty syndrome map
+	int rc = btbbx_init(0);
+	if (rc) {
+		fprintf(stderr, "%s: GPU path unavailable: %s\n", who, btbbx_last_error());
+		return 0;
+	}
+	return 1;
+}
+
+extern "C" {
+
+const char *btbb_get_release(void) { return BTBB_RELEASE; }   /* bluetooth_packet.c:268 */
+const char *btbb_get_version(void) { return BTBB_VERSION; }   /* :275 */
+
+/* bluetooth_packet.c:279-292 */
+int btbb_init(int max_ac_errors)
+{
+	if (max_ac_errors < 0 || max_ac_errors > 5) {
+		fprintf(stderr, "%s: max_ac_errors out of range\n", __FUNCTION__);
+		return -1;
+	}
+	int rc = btbbx_init(max_ac_errors);
+	if (rc) {
+		fprintf(stderr, "%s: %s\n", __FUNCTION__, btbbx_last_error());
+		return rc;
+	}
+	return 0;
+}
+
+/* :294-317 */
+btbb_packet *btbb_packet_new(void)
+{
+	btbb_packet *pkt = (btbb_packet *)calloc(1, sizeof(btbb_packet));
+	if (pkt)
+		pkt->refcount = 1;
+	else
+		fprintf(stderr, "Unable to allocate packet");
+	return pkt;
+}
+
+void btbb_packet_ref(btbb_packet *pkt) { pkt->refcount++; }
+
+void btbb_packet_unref(btbb_packet *pkt)
+{
+	pkt->refcount--;
+	if (pkt->refcount == 0)
+		free(pkt);
+}
+
+/* :482-494 */
+void btbb_packet_set_flag(btbb_packet *pkt, int flag, int val)
+{
+	uint32_t mask = 1u << flag;
+	pkt->flags &= ~mask;
+	if (val)
+		pkt->flags |= mask;
+}
+
+int btbb_packet_get_flag(const btbb_packet *pkt, int flag) { return (pkt->flags & (1u << flag)) != 0; }
+
+/* :319-366 */
+uint32_t btbb_packet_get_lap(const btbb_packet *pkt) { return pkt->LAP; }
+void btbb_packet_set_uap(btbb_packet *pkt, uint8_t uap)
+{
+	pkt->UAP = uap;
+	btbb_packet_set_flag(pkt, BTBB_UAP_VALID, 1);
+}
+uint8_t btbb_packet_get_uap(const btbb_packet *pkt) { return pkt->UAP; }
+uint16_t btbb_packet_get_nap(const btbb_packet *pkt) { return pkt->NAP; }
+uint32_t btbb_packet_get_clkn(const btbb_packet *pkt) { return pkt->clkn; }
+uint8_t btbb_packet_get_channel(const btbb_packet *pkt) { return pkt->channel; }
+void btbb_packet_set_modulation(btbb_packet *pkt, uint8_t m) { pkt->modulation = m; }
+uint8_t btbb_packet_get_modulation(const btbb_packet *pkt) { return pkt->modulation; }
+void btbb_packet_set_transport(btbb_packet *pkt, uint8_t t) { pkt->transport = t; }
+uint8_t btbb_packet_get_transport(const btbb_packet *pkt) { return pkt->transport; }
+uint8_t btbb_packet_get_ac_errors(const btbb_packet *pkt) { return pkt->ac_errors; }
+
+/* :188-199 -- once per search, host side (24 XORs); the kernels get the result */
+uint64_t btbb_gen_syncword(const int LAP) { return host_gen_syncword((uint32_t)LAP); }
+
+/* :444-464 -- first match through the GPU scan */
+int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_errors, btbb_packet **pkt_ptr)
+{
+	if (search_length <= 0)
+		return -1;
+	if (!gpu_ready("btbb_find_ac"))
+		return -1;
+	const uint64_t n_sym = (uint64_t)search_length + 63;     // last symbol the reference reads
+	const uint64_t n_words = (n_sym + 63) / 64;
+	const size_t sym_bytes = (n_sym + 15) & ~15ULL;
+	char *block = (char *)ctx_scratch(sym_bytes + (n_words + 2) * 8 + 16);
+	if (!block) {
+		fprintf(stderr, "btbb_find_ac: %s\n", btbbx_last_error());
+		return -1;
+	}
+	uint8_t *d_sym = (uint8_t *)block;
+	uint64_t *d_words = (uint64_t *)(block + sym_bytes);
+	uint64_t *d_first = d_words + n_words + 1;
+	uint64_t first = ~0ULL;
+	int rc = BTBBX_OK;
+	if (hipMemcpy(d_sym, stream, n_sym, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(d_first, &first, 8, hipMemcpyHostToDevice) != hipSuccess)
+		rc = BTBBX_E_NODEVICE;
+	if (!rc)
+		rc = btbbx_pack_device(d_sym, n_sym, d_words, nullptr);
+	if (!rc)
+		rc = btbbx_scan_first_device(d_words, n_words, (uint64_t)search_length,
+					     lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, d_first, nullptr);
+	if (!rc && hipMemcpy(&first, d_first, 8, hipMemcpyDeviceToHost) != hipSuccess)
+		rc = BTBBX_E_NODEVICE;
+	if (rc) {
+		fprintf(stderr, "btbb_find_ac: GPU scan failed: %s\n", btbbx_last_error());
+		return -1;
+	}
+	if (first == ~0ULL)
+		return -1;
+	int offset = (int)(first >> 32);
+	uint32_t found_lap = (uint32_t)(first >> 8) & 0xffffff;
+	uint8_t ac_errors = (uint8_t)(first & 0xff);
+	if (*pkt_ptr == NULL)
+		*pkt_ptr = btbb_packet_new();
+	/* init_packet, :201-208.  Known-LAP searches store the caller's 32-bit value. */
+	(*pkt_ptr)->LAP = lap == LAP_ANY ? found_lap : lap;
+	(*pkt_ptr)->ac_errors = ac_errors;
+	(*pkt_ptr)->flags = 0;
+	btbb_packet_set_flag(*pkt_ptr, BTBB_WHITENED, 1);
+	return offset;
+}
+
+/* :467-480 */
+void btbb_packet_set_data(btbb_packet *pkt, char *data, int length, uint8_t channel, uint32_t clkn)
+{
+	if (length > PKT_MAX_SYMBOLS)
+		length = PKT_MAX_SYMBOLS;
+	if (length > 0)
+		memcpy(pkt->symbols, data, (size_t)length);
+	pkt->length = (uint16_t)length;
+	pkt->channel = channel;
+	pkt->clkn = clkn >> 1;
+}
+
+const char *btbb_get_symbols(const btbb_packet *pkt) { return pkt->symbols; }
+int btbb_packet_get_payload_length(const btbb_packet *pkt) { return pkt->payload_length; }
+const char *btbb_get_payload(const btbb_packet *pkt) { return pkt->payload; }
+
+static uint32_t bits_of(const char *air, int n)
+{
+	uint32_t v = 0;
+	for (int i = 0; i < n; i++)
+		v |= (uint32_t)(uint8_t)air[i] << i;
+	return v;
+}
+
+/* :511-517 -- format conversion of already decoded bits (no symbol processing) */
+int btbb_get_payload_packed(const btbb_packet *pkt, char *dst)
+{
+	for (int i = 0; i < pkt->payload_length; i++)
+		dst[i] = (char)(uint8_t)bits_of(pkt->payload + 8 * i, 8);
+	return pkt->payload_length;
+}
+
+uint8_t btbb_packet_get_type(const btbb_packet *pkt) { return pkt->packet_type; }
+uint8_t btbb_packet_get_lt_addr(const btbb_packet *pkt) { return pkt->packet_lt_addr; }
+uint8_t btbb_packet_get_header_flags(const btbb_packet *pkt) { return pkt->packet_flags; }
+uint8_t btbb_packet_get_hec(const btbb_packet *pkt) { return pkt->packet_hec; }
+uint32_t btbb_packet_get_header_packed(const btbb_packet *pkt) { return bits_of(pkt->packet_header, 18); }
+
+/* :1371-1408 */
+int btbb_header_present(const btbb_packet *pkt)
+{
+	int present = 0;
+	if (packet_gpu_decode(const_cast<btbb_packet *>(pkt), 0, nullptr, &present, nullptr, nullptr))
+		return 0;
+	return present;
+}
+
+/* :1198-1221 */
+int btbb_decode_header(btbb_packet *pkt)
+{
+	int rv = 0;
+	if (packet_gpu_decode(pkt, DEC_HEADER, nullptr, nullptr, &rv, nullptr))
+		return 0;
+	return rv;
+}
+
+/* :1223-1297 */
+int btbb_decode_payload(btbb_packet *pkt)
+{
+	int rv = 0;
+	if (packet_gpu_decode(pkt, DEC_PAYLOAD, nullptr, nullptr, nullptr, &rv))
+		return 0;
+	return rv;
+}
+
+/* :1320-1338 */
+void btbb_print_packet(const btbb_packet *pkt)
+{
+	if (btbb_packet_get_flag(pkt, BTBB_HAS_PAYLOAD)) {
+		printf("  Type: %s\n", type_names[pkt->packet_type & 15]);
+		if (pkt->payload_header_length > 0) {
+			printf("  LT_ADDR: %d\n", pkt->packet_lt_addr);
+			printf("  LLID: %d\n", pkt->payload_llid);
+			printf("  flow: %d\n", pkt->payload_flow);
+			printf("  payload length: %d\n", pkt->payload_length);
+		}
+		if (pkt->payload_length) {
+			printf("  Data: ");
+			for (int i = 0; i < pkt->payload_length; i++)
+				printf(" %02x", bits_of(pkt->payload + 8 * i, 8));
+			printf("\n");
+		}
+	}
+}
+
+/* :1300-1317 */
+int btbb_decode(btbb_packet *pkt)
+{
+	int hdr = 0, rv = 0;
+	btbb_packet_set_flag(pkt, BTBB_HAS_PAYLOAD, 0);
+	if (packet_gpu_decode(pkt, DEC_HEADER | DEC_PAYLOAD, nullptr, nullptr, &hdr, &rv))
+		return 0;
+	if (!hdr)
+		rv = 0;
+	if (rv > 0) {
+		printf("Packet decoded with clock 0x%02x (rv=%d)\n", pkt->clkn & 0x3f, rv);
+		btbb_print_packet(pkt);
+	}
+	return rv;
+}
+
+} // extern "C"
+
+// ---- GPU round trips for one packet object ---------------------------------------------------
+
+struct DevPacketBufs {
+	uint8_t *d_sym;        // 3200 bytes
+	uint8_t *d_pay;        // 2752 bytes
+	uint64_t *d_pkt;       // 50 words
+	btbbx_pkt_in *d_in;
+	btbbx_pkt_out *d_out;
+	btbbx_trial *d_trials; // 64
+};
+
+static int dev_bufs(DevPacketBufs &b)
+{
+	static void *block = nullptr;
+	if (!block) {
+		hipError_t e = hipMalloc(&block, 16384);
+		if (e != hipSuccess)
+			return hip_fail(e, "hipMalloc(packet buffers)");
+	}
+	char *p = (char *)block;
+	b.d_sym = (uint8_t *)p;                 p += 3200;
+	b.d_pay = (uint8_t *)p;                 p += 2752;
+	b.d_pkt = (uint64_t *)p;                p += 8 * BTBBX_PKT_WORDS;
+	b.d_in = (btbbx_pkt_in *)p;             p += 64;
+	b.d_out = (btbbx_pkt_out *)p;           p += (sizeof(btbbx_pkt_out) + 63) & ~63u;
+	b.d_trials = (btbbx_trial *)p;
+	return BTBBX_OK;
+}
+
+static void fill_in(const btbb_packet *pkt, btbbx_pkt_in &in)
+{
+	memset(&in, 0, sizeof(in));
+	in.length = pkt->length;
+	in.clkn = pkt->clkn;
+	in.flags = pkt->flags;
+	in.uap = pkt->UAP;
+	in.type = pkt->packet_type;
+	in.llid = pkt->payload_llid;
+	in.flow = pkt->payload_flow;
+}
+
+static int upload_symbols(const btbb_packet *pkt, DevPacketBufs &b)
+{
+	// the whole symbol array travels: FEC 2/3 may read past pkt->length (stale tail)
+	static uint8_t staging[3200];
+	memcpy(staging, pkt->symbols, PKT_MAX_SYMBOLS);
+	memset(staging + PKT_MAX_SYMBOLS, 0, sizeof(staging) - PKT_MAX_SYMBOLS);
+	HIP_TRY(hipMemcpy(b.d_sym, staging, sizeof(staging), hipMemcpyHostToDevice));
+	return btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+}
+
+int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
+{
+	if (!gpu_ready("btbb_uap_from_header"))
+		return BTBBX_E_NODEVICE;
+	DevPacketBufs b;
+	int rc = dev_bufs(b);
+	if (rc) return rc;
+	rc = upload_symbols(pkt, b);
+	if (rc) return rc;
+	btbbx_pkt_in in;
+	fill_in(pkt, in);
+	HIP_TRY(hipMemcpy(b.d_in, &in, sizeof(in), hipMemcpyHostToDevice));
+	rc = btbbx_trials_device(b.d_pkt, b.d_in, 1, b.d_trials, nullptr);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpy(trials64, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost));
+	return BTBBX_OK;
+}
+
+int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, int *header_present,
+		      int *header_rv, int *payload_rv)
+{
+	if (!gpu_ready("btbb_decode"))
+		return BTBBX_E_NODEVICE;
+	DevPacketBufs b;
+	int rc = dev_bufs(b);
+	if (rc) return rc;
+	rc = upload_symbols(pkt, b);
+	if (rc) return rc;
+
+	btbbx_pkt_in in;
+	fill_in(pkt, in);
+	btbbx_pkt_out out;
+	memset(&out, 0, sizeof(out));
+	out.payload_length = pkt->payload_length;
+	out.payload_header_length = pkt->payload_header_length;
+	out.header_packed = bits_of(pkt->packet_header, 18);
+	out.type = pkt->packet_type;
+	out.lt_addr = pkt->packet_lt_addr;
+	out.hdr_flags = pkt->packet_flags;
+	out.hec = pkt->packet_hec;
+	out.payload_header = bits_of(pkt->payload_header, 16);
+	HIP_TRY(hipMemcpy(b.d_in, &in, sizeof(in), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(b.d_out, &out, sizeof(out), hipMemcpyHostToDevice));
+	const bool touches_payload = mode & (DEC_PAYLOAD | DEC_TRIALS);
+	if (touches_payload) {
+		// current payload bits travel too: a decoder only overwrites a prefix
+		static uint8_t staging[2752];
+		memcpy(staging, pkt->payload, PKT_MAX_PAYLOAD_BITS);
+		memset(staging + PKT_MAX_PAYLOAD_BITS, 0, sizeof(staging) - PKT_MAX_PAYLOAD_BITS);
+		HIP_TRY(hipMemcpy(b.d_pay, staging, sizeof(staging), hipMemcpyHostToDevice));
+		rc = btbbx_pack_device(b.d_pay, 2752, (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), nullptr);
+		if (rc) return rc;
+	}
+	rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, nullptr);
+	if (rc) return rc;
+	if (touches_payload) {
+		rc = btbbx_unpack_device((const uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)),
+					 2752, b.d_pay, nullptr);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipMemcpy(&out, b.d_out, sizeof(out), hipMemcpyDeviceToHost));
+	if (header_present) *header_present = out.header_present;
+	if (header_rv) *header_rv = out.header_rv;
+	if (payload_rv) *payload_rv = out.payload_rv;
+	if (mode == 0)
+		return BTBBX_OK;           // btbb_header_present: const, nothing written back
+
+	if (touches_payload) {
+		static uint8_t staging[2752];
+		HIP_TRY(hipMemcpy(staging, b.d_pay, sizeof(staging), hipMemcpyDeviceToHost));
+		memcpy(pkt->payload, staging, PKT_MAX_PAYLOAD_BITS);
+	}
+	pkt->flags = out.flags;
+	pkt->UAP = out.uap;
+	pkt->packet_type = out.type;
+	pkt->packet_lt_addr = out.lt_addr;
+	pkt->packet_flags = out.hdr_flags;
+	pkt->packet_hec = out.hec;
+	for (int i = 0; i < 18; i++)
+		pkt->packet_header[i] = (char)((out.header_packed >> i) & 1);
+	pkt->payload_header_length = out.payload_header_length;
+	for (int i = 0; i < 16; i++)
+		pkt->payload_header[i] = (char)((out.payload_header >> i) & 1);
+	pkt->payload_llid = out.llid;
+	pkt->payload_flow = out.flow;
+	pkt->payload_length = out.payload_length;
+	return BTBBX_OK;
+}

@@ -1,0 +1,98 @@
+// common.h -- shared declarations of the MI355X baseband scanner (host + device).
+//
+// Everything is derived from the Bluetooth baseband spec polynomials at start-up
+// (tables.cpp); nothing is transcribed from the reference's tables.  Reference
+// citations are relative to /root/reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/btbbx.h"
+
+// ---- spec constants ---------------------------------------------------------------
+#define SW_POLY   0260534236651ULL         // (64,30) block code generator, degree 34
+#define SW_PN     0x83848D96BBCC54FCULL    // PN overlay (bluetooth_packet.c:115)
+#define BARKER1   0x27u                    // 7-bit window when LAP bit 23 = 1 (host order)
+#define BARKER0   0x58u                    // 7-bit window when LAP bit 23 = 0
+#define LOW57     0x01ffffffffffffffULL
+
+// ---- scan kernel geometry ---------------------------------------------------------
+#define SCAN_THREADS   1024                // one workgroup per CU, 16 wave64
+#define SCAN_WAVES     (SCAN_THREADS / 64)
+#define TABA_BITS      13                  // window bits 32..44
+#define TABB_BITS      12                  // window bits 45..56 (+1 class bit)
+#define BITMAP_BITS    18                  // projection width of the candidate bitmap
+#define QRING          256                 // per-wave candidate ring (entries)
+
+#define LDS_TABA_WORDS   (1u << TABA_BITS)            // 8192 u32
+#define LDS_TABB_WORDS   (2u << TABB_BITS)            // 8192 u32
+#define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 8192 u32
+#define LDS_QUEUE_WORDS  (SCAN_WAVES * QRING)         // 4096 u32
+#define SCAN_LDS_BYTES   (4u * (LDS_TABA_WORDS + LDS_TABB_WORDS + LDS_BITMAP_WORDS + LDS_QUEUE_WORDS))
+
+// ---- device-side table bundle -----------------------------------------------------
+struct ScanTables {
+	const uint32_t *tabA;      // [8192]   low-32 syndrome of window bits 32..44
+	const uint32_t *tabB;      // [2][4096] low-32 syndrome of bits 45..56 ^ class constant
+	const uint32_t *bitmap;    // [8192]   2^18-bit set: projection of acceptable syndromes
+	const uint64_t *bytetab;   // [8][256] full 34-bit syndrome per window byte
+	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)
+	uint64_t hmask;            // slots - 1
+	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1
+};
+
+// packed hash slot: bits 0..33 syndrome, then five 6-bit error positions (63 = unused),
+// ascending.  Empty slot = all ones.
+#define HSLOT_EMPTY 0xffffffffffffffffULL
+
+struct HostTables {
+	uint64_t col[64];          // x^j mod g: syndrome of single bit j
+	uint64_t bytetab[8][256];
+	uint64_t gen_rows[24];     // generator rows per LAP bit, MSB first
+	uint64_t sw_default;       // sync word of LAP 0
+	uint8_t  whiten[127];
+	uint8_t  whiten_idx[64];
+	uint8_t  fec23_par[10];    // parity column of data bit i
+	int8_t   fec23_fix[32];    // 5-bit syndrome -> data bit, -1 = none/parity, -2 = fail
+};
+
+const HostTables &host_tables();
+uint64_t host_gen_syncword(uint32_t lap);
+uint64_t host_syndrome(uint64_t cw);
+
+// ---- context ------------------------------------------------------------------------
+struct Ctx {
+	bool ready = false;
+	int device = -1;
+	int table_errors = 0;       // max_ac_errors the tables were built for
+	int num_cus = 256;
+	ScanTables scan{};          // device pointers
+	void *d_tab_block = nullptr;
+	void *d_hslots = nullptr;
+	// packet-chain tables
+	void *d_chain = nullptr;
+	// scratch for the host convenience wrappers and the drop-in API
+	void *d_scratch = nullptr;
+	size_t scratch_bytes = 0;
+	void *h_pinned = nullptr;
+	size_t pinned_bytes = 0;
+};
+
+Ctx &ctx();
+int ctx_require();                       // BTBBX_OK or error (sets last error)
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+void *ctx_scratch(size_t bytes);         // grow-only device scratch
+void *ctx_pinned(size_t bytes);          // grow-only pinned host staging
+
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_fail(_e, #expr); } while (0)
+
+// device constants for the packet chain (whitening etc.), defined in packet.hip
+struct ChainTables {
+	uint64_t whiten2[4];       // two periods of the 127-bit whitening sequence, packed (254 bits)
+	uint8_t  whiten_idx[64];
+	uint8_t  fec23_par[10];
+	int8_t   fec23_fix[32];
+};
+int chain_upload(const HostTables &t);

@@ -1,0 +1,787 @@
+// packet.hip -- the bit chain behind an access code, on packed symbols, for gfx950.
+//
+// Restates, one lane per (packet, clock) trial or per packet, the reference's
+//   unfec13 (lib/src/bluetooth_packet.c:552)    unfec23 / fec23 (:571-649)
+//   unwhiten (:653)   crcgen / payload_crc (:671, :772)   uap_from_hec (:693)
+//   try_clock (:1178) crc_check (:708) fhs/DM/DH/EV3/EV4/EV5/HV (:783-1174)
+//   btbb_header_present (:1371) btbb_decode_header (:1198) btbb_decode_payload (:1223)
+// Symbols are bits of 64-bit words (bit i of the packet = symbol i), so FEC 1/3 is three
+// masked ANDs, whitening is an XOR with a slice of the 127-bit sequence, and the CRC runs
+// a byte at a time.  Identities used (all exact):
+//   * crcgen over n bytes followed by its own 16 check bits leaves the register at 0, so
+//     payload_crc() == (CRC over all payload_length bytes == 0) for payload_length >= 2;
+//   * with payload_length == 1 payload_crc() can never succeed (the check word read from
+//     in front of payload[] has bit 4 set by payload_length itself, the seed's low byte
+//     is 0), which removes the llid/flow dependency of EV4;
+//   * crc_check() maps every EV3/EV5 result to 1 (:760-766).
+// Reference quirks kept: FEC-2/3 reads past pkt->length (DM), EV3/EV5 re-use the first
+// payload byte (:1036, :1122), DV whitening restarts at 18 (:913-937), a failed FEC 1/3
+// leaves UAP/type from the previous trial (:1186-1187).
+#include <string.h>
+#include "common.h"
+#include "packet_obj.h"
+
+__constant__ ChainTables g_chain;
+
+int chain_upload(const HostTables &t)
+{
+	ChainTables c;
+	memset(&c, 0, sizeof(c));
+	for (int j = 0; j < 256; j++)
+		if (t.whiten[j % 127])
+			c.whiten2[j >> 6] |= 1ULL << (j & 63);
+	memcpy(c.whiten_idx, t.whiten_idx, 64);
+	memcpy(c.fec23_par, t.fec23_par, 10);
+	memcpy(c.fec23_fix, t.fec23_fix, 32);
+	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_chain), &c, sizeof(c)));
+	return BTBBX_OK;
+}
+
+#define F_WHITENED    (1u << 0)
+#define F_CLK6_VALID  (1u << 4)
+#define F_HAS_PAYLOAD (1u << 7)
+
+// ---- bit helpers ----------------------------------------------------------------------------
+
+// n (1..64) bits of the packet starting at symbol pos; pos + n <= 3200
+__device__ __forceinline__ uint64_t pk_bits(const uint64_t *w, uint32_t pos, uint32_t n)
+{
+	uint32_t i = pos >> 6, s = pos & 63;
+	uint64_t v = w[i] >> s;
+	if (s + n > 64)
+		v |= w[i + 1] << (64 - s);
+	return n == 64 ? v : v & ((1ULL << n) - 1);
+}
+
+// n (1..64) whitening bits starting at phase idx (0..126)
+__device__ __forceinline__ uint64_t wh_bits(uint32_t idx, uint32_t n)
+{
+	uint32_t i = idx >> 6, s = idx & 63;
+	uint64_t v = g_chain.whiten2[i] >> s;
+	if (s + n > 64)
+		v |= g_chain.whiten2[i + 1] << (64 - s);
+	return n == 64 ? v : v & ((1ULL << n) - 1);
+}
+
+__device__ __forceinline__ uint32_t wh_start(uint32_t clock, uint32_t skip)
+{
+	return (g_chain.whiten_idx[clock & 63] + skip) % 127u;
+}
+
+__device__ __forceinline__ uint32_t rev8(uint32_t b) { return __brev(b) >> 24; }
+
+// one byte through the reflected CRC-CCITT register of crcgen (:681-687)
+__device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t byte)
+{
+	uint32_t x = (crc ^ byte) & 0xff;
+	x ^= (x << 4) & 0xff;
+	return ((crc >> 8) ^ (x << 8) ^ (x << 3) ^ (x >> 4)) & 0xffff;
+}
+
+__device__ __forceinline__ uint32_t crc_seed(uint32_t uap) { return rev8(uap & 0xff) << 8; }
+
+// uap_from_hec (:693-705)
+__device__ __forceinline__ uint32_t uap_from_hec(uint32_t data, uint32_t hec)
+{
+#pragma unroll
+	for (int i = 9; i >= 0; i--) {
+		if (hec & 0x80)
+			hec ^= 0x65;
+		hec = ((hec << 1) | (((hec >> 7) ^ (data >> i)) & 1)) & 0xff;
+	}
+	return rev8(hec);
+}
+
+// FEC 1/3 of n <= 21 triples held in the low 3n bits of v: majority bits (compacted) and
+// the number of triples that disagree (:552-568)
+__device__ __forceinline__ uint32_t fec13(uint64_t v, uint32_t n, uint32_t &disagree)
+{
+	const uint64_t M = 0x9249249249249249ULL;          // every third bit
+	uint64_t a = v & M, b = (v >> 1) & M, c = (v >> 2) & M;
+	uint64_t maj = (a & b) | (b & c) | (c & a);
+	uint64_t dis = (a ^ b) | (b ^ c) | (c ^ a);
+	if (n < 21) {
+		uint64_t keep = (1ULL << (3 * n)) - 1;
+		maj &= keep;
+		dis &= keep;
+	}
+	disagree = __popcll(dis);
+	uint32_t out = 0;
+	for (uint32_t i = 0; i < n; i++)
+		out |= (uint32_t)((maj >> (3 * i)) & 1) << i;
+	return out;
+}
+
+// one (15,10) block: 15 symbols in -> 10 corrected data bits, false if uncorrectable (:602-646)
+__device__ __forceinline__ bool fec23_block(uint32_t blk, uint32_t &data)
+{
+	data = blk & 0x3ff;
+	uint32_t par = 0;
+#pragma unroll
+	for (int i = 0; i < 10; i++)
+		if ((data >> i) & 1)
+			par ^= g_chain.fec23_par[i];
+	uint32_t diff = (blk >> 10) ^ par;
+	int fix = g_chain.fec23_fix[diff & 31];
+	if (fix == -2)
+		return false;
+	if (fix >= 0)
+		data ^= 1u << fix;
+	return true;
+}
+
+// ---- packet state -----------------------------------------------------------------------------
+
+struct PState {
+	const uint64_t *w;       // 50 packed words
+	int length;              // pkt->length
+	uint32_t flags;
+	uint32_t uap, type;
+	uint32_t lt_addr, hdr_flags, hec, header18;
+	int plen;                // payload_length
+	int phl;                 // payload_header_length
+	uint32_t ph16;           // payload_header bits
+	uint32_t ph_written;     // how many payload_header chars were written
+	uint32_t llid, flow;
+	// payload writer
+	uint64_t *out;           // 43 words or nullptr
+	uint32_t written;        // payload bits written (prefix)
+};
+
+// streams payload bits into the CRC (whole bytes) and, when WRITE, into the output words
+template <bool WRITE>
+struct Sink {
+	uint64_t acc = 0;
+	uint32_t nacc = 0;
+	uint32_t crc;
+	uint64_t oacc = 0;
+	uint32_t onacc = 0, oword = 0;
+	uint64_t *out;
+	__device__ Sink(uint32_t seed, uint64_t *o) : crc(seed), out(o) {}
+	__device__ __forceinline__ void push(uint64_t bits, uint32_t n)   // n <= 32
+	{
+		acc |= bits << nacc;
+		nacc += n;
+		while (nacc >= 8) {
+			crc = crc_byte(crc, (uint32_t)acc & 0xff);
+			acc >>= 8;
+			nacc -= 8;
+		}
+		if (WRITE) {
+			oacc |= bits << onacc;
+			onacc += n;
+			if (onacc >= 64) {
+				out[oword++] = oacc;
+				onacc -= 64;
+				oacc = onacc ? bits >> (n - onacc) : 0;
+			}
+		}
+	}
+	// merge the unfinished word with what the output already holds
+	__device__ __forceinline__ void flush()
+	{
+		if (WRITE && onacc) {
+			uint64_t keep = ~0ULL << onacc;
+			out[oword] = (out[oword] & keep) | oacc;
+		}
+	}
+};
+
+__device__ __forceinline__ bool whitened(const PState &s) { return s.flags & F_WHITENED; }
+
+__device__ __forceinline__ uint64_t wh(const PState &s, uint32_t idx, uint32_t n)
+{
+	return whitened(s) ? wh_bits(idx, n) : 0ULL;
+}
+
+// all FEC-2/3 blocks of `nblocks` decodable?
+__device__ __forceinline__ bool fec23_ok(const uint64_t *w, uint32_t pos, uint32_t nblocks)
+{
+	for (uint32_t k = 0; k < nblocks; k++) {
+		uint32_t d;
+		if (!fec23_block((uint32_t)pk_bits(w, pos + 15 * k, 15), d))
+			return false;
+	}
+	return true;
+}
+
+// fhs (:783-818)
+template <bool WRITE>
+__device__ int do_fhs(PState &s, uint32_t clock)
+{
+	int size = s.length - 122;
+	s.plen = 20;
+	if (size < 240)
+		return 1;
+	uint64_t corr[3] = {0, 0, 0};
+	for (uint32_t k = 0; k < 16; k++) {
+		uint32_t d;
+		if (!fec23_block((uint32_t)pk_bits(s.w, 122 + 15 * k, 15), d))
+			return 0;
+		uint32_t bit = 10 * k;
+		corr[bit >> 6] |= (uint64_t)d << (bit & 63);
+		if ((bit & 63) > 54)
+			corr[(bit >> 6) + 1] |= (uint64_t)d >> (64 - (bit & 63));
+	}
+	int rv = 0;
+	uint32_t c = clock;
+	for (int attempt = 0; attempt < 33; attempt++) {
+		if (attempt)
+			c = 31 + attempt;
+		uint32_t idx = wh_start(c, 18);
+		uint32_t crc = crc_seed(s.uap);
+		uint64_t pl[3];
+		for (int i = 0; i < 3; i++) {
+			uint32_t n = i < 2 ? 64 : 32;
+			pl[i] = corr[i] ^ wh(s, idx, n);
+			idx = (idx + n) % 127u;
+			for (uint32_t b = 0; b < n; b += 8)
+				crc = crc_byte(crc, (uint32_t)(pl[i] >> b) & 0xff);
+		}
+		if (WRITE) {
+			s.out[0] = pl[0];
+			s.out[1] = pl[1];
+			s.out[2] = (s.out[2] & ~0xffffffffULL) | pl[2];
+			if (s.written < 160) s.written = 160;
+		}
+		if (crc == 0) {
+			rv = 1000;
+			break;
+		}
+	}
+	return rv;
+}
+
+// decode_payload_header (:821-895)
+template <bool WRITE>
+__device__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int header_bytes, int size, bool fec)
+{
+	uint32_t hbits = header_bytes == 2 ? 16 : 8;
+	if (size < (int)hbits)
+		return false;
+	uint32_t raw;
+	if (fec) {
+		if (size < (header_bytes == 2 ? 30 : 15))
+			return false;
+		uint32_t d0, d1 = 0;
+		if (!fec23_block((uint32_t)pk_bits(s.w, pos, 15), d0))
+			return false;
+		if (header_bytes == 2 && !fec23_block((uint32_t)pk_bits(s.w, pos + 15, 15), d1))
+			return false;
+		raw = (d0 | (d1 << 10)) & ((1u << hbits) - 1);
+	} else {
+		raw = (uint32_t)pk_bits(s.w, pos, hbits);
+	}
+	uint32_t ph = raw ^ (uint32_t)wh(s, wh_start(clock, 18), hbits);
+	s.ph16 = (s.ph16 & ~((1u << hbits) - 1)) | ph;
+	if (s.ph_written < hbits) s.ph_written = hbits;
+	int plen = header_bytes == 2 ? (int)((s.ph16 >> 3) & 0x3ff) + 4 : (int)((s.ph16 >> 3) & 0x1f) + 3;
+	int cap;
+	switch (s.type) {
+	case 3:  cap = 20;  break;
+	case 4:  cap = 30;  break;
+	case 8:  cap = 12;  break;
+	case 10: cap = 125; break;
+	case 11: cap = 187; break;
+	case 14: cap = 228; break;
+	case 15: cap = 343; break;
+	default: cap = 0;   break;
+	}
+	s.plen = plen < cap ? plen : cap;
+	s.llid = s.ph16 & 3;
+	s.flow = (s.ph16 >> 2) & 1;
+	s.phl = header_bytes;
+	return true;
+}
+
+// DM (:898-958)
+template <bool WRITE>
+__device__ int do_DM(PState &s, uint32_t clock)
+{
+	uint32_t pos = 122;
+	int size = s.length - 122;
+	int header_bytes = 2, max_length;
+	switch (s.type) {
+	case 8:  pos += 80; size -= 80; header_bytes = 1; max_length = 12; break;
+	case 3:  header_bytes = 1; max_length = 20; break;
+	case 10: max_length = 125; break;
+	case 14: max_length = 228; break;
+	default: return 0;
+	}
+	if (!do_payload_header<WRITE>(s, pos, clock, header_bytes, size, true))
+		return 0;
+	if (s.plen > max_length)
+		return 1;
+	int nbits = s.plen * 8;
+	if (nbits > size)
+		return 1;
+	uint32_t nblocks = (nbits + 9) / 10;
+	if (WRITE && !fec23_ok(s.w, pos, nblocks))      // the reference writes nothing on failure
+		return 0;
+	Sink<WRITE> sink(crc_seed(s.uap), s.out);
+	uint32_t idx = wh_start(clock, 18);
+	int left = nbits;
+	for (uint32_t k = 0; k < nblocks; k++) {
+		uint32_t d;
+		if (!fec23_block((uint32_t)pk_bits(s.w, pos + 15 * k, 15), d))
+			return 0;
+		uint32_t n = left < 10 ? left : 10;
+		sink.push((d ^ (uint32_t)wh(s, idx, 10)) & ((1u << n) - 1), n);
+		idx = (idx + 10) % 127u;
+		left -= n;
+	}
+	sink.flush();
+	if (WRITE && s.written < (uint32_t)nbits) s.written = nbits;
+	return sink.crc == 0 ? 10 : 2;
+}
+
+// DH (:962-1011)
+template <bool WRITE>
+__device__ int do_DH(PState &s, uint32_t clock)
+{
+	const uint32_t pos = 122;
+	int size = s.length - 122;
+	int header_bytes = 2, max_length;
+	switch (s.type) {
+	case 9:
+	case 4:  header_bytes = 1; max_length = 30; break;
+	case 11: max_length = 187; break;
+	case 15: max_length = 343; break;
+	default: return 0;
+	}
+	if (!do_payload_header<WRITE>(s, pos, clock, header_bytes, size, false))
+		return 0;
+	if (s.plen > max_length)
+		return 1;
+	int nbits = s.plen * 8;
+	if (nbits > size)
+		return 1;
+	Sink<WRITE> sink(crc_seed(s.uap), s.out);
+	uint32_t idx = wh_start(clock, 18);
+	for (int done = 0; done < nbits; done += 32) {
+		uint32_t n = nbits - done < 32 ? nbits - done : 32;
+		sink.push(pk_bits(s.w, pos + done, n) ^ wh(s, idx, n), n);
+		idx = (idx + n) % 127u;
+	}
+	sink.flush();
+	if (WRITE && s.written < (uint32_t)nbits) s.written = nbits;
+	if (s.type == 9)
+		return 2;
+	return sink.crc == 0 ? 10 : 2;
+}
+
+// EV3 (:1013-1042) / EV5 (:1099-1128)
+template <bool WRITE>
+__device__ int do_EV35(PState &s, uint32_t clock, int maxlength)
+{
+	int size = s.length - 122;
+	uint32_t first8 = (uint32_t)pk_bits(s.w, 122, 8);
+	Sink<WRITE> sink(crc_seed(s.uap), s.out);
+	uint32_t idx = wh_start(clock, 18);
+	int rv = 2;
+	int L;
+	for (L = 0; L < maxlength; L++) {
+		if (8 * L + 8 > size) {
+			rv = 1;
+			break;
+		}
+		// the reference writes byte L, then tests the CRC over bytes 0..L-1
+		uint32_t byte = first8 ^ (uint32_t)wh(s, idx, 8);
+		idx = (idx + 8) % 127u;
+		bool match = L > 2 && sink.crc == 0;     // CRC over bytes 0..L-1 == 0
+		sink.push(byte, 8);
+		if (WRITE && s.written < (uint32_t)(8 * L + 8)) s.written = 8 * L + 8;
+		if (match) {
+			rv = 10;
+			break;
+		}
+	}
+	sink.flush();
+	s.plen = L;
+	return rv;
+}
+
+// EV4 (:1044-1097)
+template <bool WRITE>
+__device__ int do_EV4(PState &s, uint32_t clock)
+{
+	int size = s.length - 122;
+	uint32_t crc = crc_seed(s.uap);
+	uint64_t acc = 0;           // payload bits produced but not yet consumed by the CRC
+	uint32_t nacc = 0;
+	uint64_t oacc = 0;
+	uint32_t onacc = 0, oword = 0;
+	int L = 1;
+	int rv = 2;
+	for (int b = 0; b < 98; b++) {
+		int syms = 15 * b, bits = 10 * b;
+		if (syms + 15 > size) { rv = 1; break; }
+		uint32_t d;
+		if (!fec23_block((uint32_t)pk_bits(s.w, 122 + syms, 15), d)) { rv = syms < 45 ? 0 : 1; break; }
+		uint64_t ten = d ^ (uint32_t)wh(s, wh_start(clock, 18 + bits), 10);
+		acc |= ten << nacc;
+		nacc += 10;
+		if (WRITE) {
+			oacc |= ten << onacc;
+			onacc += 10;
+			if (onacc >= 64) {
+				s.out[oword++] = oacc;
+				onacc -= 64;
+				oacc = onacc ? ten >> (10 - onacc) : 0;
+			}
+			if (s.written < (uint32_t)(bits + 10)) s.written = bits + 10;
+		}
+		bool hit = false;
+		while (L * 8 <= bits) {
+			crc = crc_byte(crc, (uint32_t)acc & 0xff);      // byte L-1
+			acc >>= 8;
+			nacc -= 8;
+			if (L >= 2 && crc == 0) { hit = true; break; }
+			L++;
+		}
+		if (hit) { rv = 10; break; }
+	}
+	if (WRITE && onacc) {
+		uint64_t keep = ~0ULL << onacc;
+		s.out[oword] = (s.out[oword] & keep) | oacc;
+	}
+	s.plen = L;
+	return rv;
+}
+
+// HV (:1131-1174)
+template <bool WRITE>
+__device__ int do_HV(PState &s, uint32_t clock)
+{
+	int size = s.length - 122;
+	s.phl = 0;
+	if (size < 240) {
+		s.plen = 0;
+		return 1;
+	}
+	uint32_t idx = wh_start(clock, 18);
+	if (s.type == 5) {
+		uint32_t data[4], total = 0;
+		for (int i = 0; i < 4; i++) {       // 80 triples = 4 x 20
+			uint32_t dis;
+			data[i] = fec13(pk_bits(s.w, 122 + 60 * i, 60), 20, dis);
+			total += dis;
+		}
+		if (!(total < 20))
+			return 0;
+		s.plen = 10;
+		s.flags |= F_HAS_PAYLOAD;
+		if (WRITE) {
+			Sink<true> sink(0, s.out);
+			for (int i = 0; i < 4; i++) {
+				sink.push(data[i] ^ (uint32_t)wh(s, idx, 20), 20);
+				idx = (idx + 20) % 127u;
+			}
+			sink.flush();
+			if (s.written < 80) s.written = 80;
+		}
+	} else if (s.type == 6) {
+		if (!fec23_ok(s.w, 122, 16))
+			return 0;
+		s.plen = 20;
+		s.flags |= F_HAS_PAYLOAD;
+		if (WRITE) {
+			Sink<true> sink(0, s.out);
+			for (uint32_t k = 0; k < 16; k++) {
+				uint32_t d;
+				fec23_block((uint32_t)pk_bits(s.w, 122 + 15 * k, 15), d);
+				sink.push(d ^ (uint32_t)wh(s, idx, 10), 10);
+				idx = (idx + 10) % 127u;
+			}
+			sink.flush();
+			if (s.written < 160) s.written = 160;
+		}
+	} else if (s.type == 7) {
+		s.plen = 30;
+		s.flags |= F_HAS_PAYLOAD;
+		if (WRITE) {
+			Sink<true> sink(0, s.out);
+			for (int done = 0; done < 240; done += 30) {
+				sink.push(pk_bits(s.w, 122 + done, 30) ^ wh(s, idx, 30), 30);
+				idx = (idx + 30) % 127u;
+			}
+			sink.flush();
+			if (s.written < 240) s.written = 240;
+		}
+	}
+	return 2;
+}
+
+// crc_check (:708-769)
+template <bool WRITE>
+__device__ int do_crc_check(PState &s, uint32_t clock)
+{
+	int rv = 1;
+	switch (s.type) {
+	case 2:  rv = do_fhs<WRITE>(s, clock); break;
+	case 8: case 3: case 10: case 14: rv = do_DM<WRITE>(s, clock); break;
+	case 4: case 11: case 15: rv = do_DH<WRITE>(s, clock); break;
+	case 7:  rv = WRITE ? do_EV35<WRITE>(s, clock, 32) : 1; break;     // always mapped to 1 below
+	case 12: rv = do_EV4<WRITE>(s, clock); break;
+	case 13: rv = WRITE ? do_EV35<WRITE>(s, clock, 182) : 1; break;
+	case 5:  rv = do_HV<WRITE>(s, clock); break;
+	default: break;
+	}
+	if (rv == 0 && s.type != 2 && s.type != 3 && s.type != 5)
+		return 1;
+	if (rv > 1 && (s.type == 7 || s.type == 13))
+		return 1;
+	return rv;
+}
+
+// FEC-1/3 decoded header bits and the number of disagreeing triples
+__device__ __forceinline__ uint32_t header_fec13(const uint64_t *w, uint32_t &disagree)
+{
+	return fec13(pk_bits(w, 68, 54), 18, disagree);
+}
+
+// try_clock (:1178-1195); returns the reference's return value
+__device__ __forceinline__ uint32_t do_try_clock(PState &s, uint32_t clock, uint32_t hdr, uint32_t disagree)
+{
+	if (!(disagree < 4))
+		return 0;
+	uint32_t clear = hdr ^ (uint32_t)wh(s, wh_start(clock, 0), 18);
+	s.uap = uap_from_hec(clear & 0x3ff, clear >> 10);
+	s.type = (clear >> 3) & 0xf;
+	return s.uap;
+}
+
+// btbb_header_present (:1371-1408)
+__device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
+{
+	if (length < 122)
+		return 0;
+	uint32_t msb = (uint32_t)pk_bits(w, 63, 1);
+	uint32_t tr = (uint32_t)pk_bits(w, 64, 4);
+	uint32_t want = msb ? 0xAu : 0x5u;          // !m, m, !m, m  (LSB first)
+	uint32_t errs = __popc(tr ^ want), dis;
+	(void)fec13(pk_bits(w, 68, 54), 18, dis);
+	return (errs + dis) < 5;
+}
+
+// ---- kernels --------------------------------------------------------------------------------
+
+// one wave per packet, one lane per CLK1-6 candidate
+__global__ __launch_bounds__(64) void trials_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+						     uint32_t n_packets, btbbx_trial *trials)
+{
+	uint32_t pkt = blockIdx.x;
+	uint32_t clock = threadIdx.x;
+	if (pkt >= n_packets)
+		return;
+	const btbbx_pkt_in pi = in[pkt];
+	PState s;
+	s.w = packets + (uint64_t)pkt * BTBBX_PKT_WORDS;
+	s.length = (int)pi.length;
+	s.flags = pi.flags;
+	s.uap = pi.uap;
+	s.type = pi.type;
+	s.llid = pi.llid;
+	s.flow = pi.flow;
+	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0;
+	s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
+	s.out = nullptr;
+	s.written = 0;
+	uint32_t dis;
+	uint32_t hdr = header_fec13(s.w, dis);
+	uint32_t uap = do_try_clock(s, clock, hdr, dis);
+	int rv = do_crc_check<false>(s, clock);
+	btbbx_trial t;
+	t.uap = (uint8_t)uap;
+	t.type = (uint8_t)s.type;
+	t.rv = (int16_t)rv;
+	trials[(uint64_t)pkt * 64 + clock] = t;
+}
+
+// mode bits of decode_kernel (packet_obj.h):
+//   DEC_HEADER   btbb_decode_header
+//   DEC_PAYLOAD  btbb_decode_payload (after a successful header when DEC_HEADER is set)
+//   DEC_TRIALS   replay, in candidate order and with all state written, the try_clock /
+//                crc_check calls btbb_uap_from_header made (plan says which ones)
+
+__global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode,
+						     TrialPlan plan)
+{
+	uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pkt >= n_packets)
+		return;
+	const btbbx_pkt_in pi = in[pkt];
+	btbbx_pkt_out *o = outs + pkt;
+	PState s;
+	s.w = packets + (uint64_t)pkt * BTBBX_PKT_WORDS;
+	s.length = (int)pi.length;
+	s.flags = pi.flags;
+	s.uap = pi.uap;
+	s.type = pi.type;
+	s.llid = pi.llid;
+	s.flow = pi.flow;
+	s.plen = o->payload_length;
+	s.phl = o->payload_header_length;
+	s.ph16 = (uint32_t)o->payload_header;
+	s.ph_written = 0;
+	s.lt_addr = o->lt_addr; s.hdr_flags = o->hdr_flags; s.hec = o->hec; s.header18 = o->header_packed;
+	s.out = o->payload;
+	s.written = 0;
+
+	int header_rv = 0, payload_rv = 0;
+	o->header_present = (uint8_t)do_header_present(s.w, s.length);
+
+	if (mode & DEC_TRIALS) {
+		uint32_t dis;
+		uint32_t hdr = header_fec13(s.w, dis);
+		for (uint32_t count = 0; count < 64; count++) {
+			uint32_t clock = (count + plan.clock_offset) & 63;
+			if ((plan.try_mask >> count) & 1)
+				header_rv = (int)do_try_clock(s, clock, hdr, dis);
+			if ((plan.crc_mask >> count) & 1)
+				payload_rv = do_crc_check<true>(s, clock);
+		}
+	} else {
+		bool go = true;
+		if (mode & DEC_HEADER) {
+			// btbb_decode_header (:1198-1221)
+			uint32_t dis;
+			uint32_t hdr = header_fec13(s.w, dis);
+			go = false;
+			if ((s.flags & F_CLK6_VALID) && dis < 4) {
+				uint32_t clear = hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18);
+				s.header18 = clear;
+				uint32_t hec = clear >> 10;
+				if (uap_from_hec(clear & 0x3ff, hec) == s.uap) {
+					s.lt_addr = clear & 7;
+					s.type = (clear >> 3) & 0xf;
+					s.hdr_flags = (clear >> 7) & 7;
+					s.hec = hec;
+					header_rv = 1;
+					go = true;
+				}
+			}
+		}
+		if ((mode & DEC_PAYLOAD) && go) {
+			// btbb_decode_payload (:1223-1297)
+			uint32_t clock = pi.clkn;
+			s.phl = 0;
+			switch (s.type) {
+			case 0: case 1: s.plen = 0; payload_rv = 1; break;
+			case 2:  payload_rv = do_fhs<true>(s, clock); break;
+			case 3: case 8: case 10: case 14: payload_rv = do_DM<true>(s, clock); break;
+			case 4: case 9: case 11: case 15: payload_rv = do_DH<true>(s, clock); break;
+			case 5: case 6: payload_rv = do_HV<true>(s, clock); break;
+			case 7:
+				payload_rv = do_EV35<true>(s, clock, 32);
+				if (payload_rv <= 1)
+					payload_rv = do_HV<true>(s, clock);
+				break;
+			case 12: payload_rv = do_EV4<true>(s, clock); break;
+			case 13: payload_rv = do_EV35<true>(s, clock, 182); break;
+			}
+			s.flags |= F_HAS_PAYLOAD;
+		}
+	}
+	o->header_rv = header_rv;
+	o->payload_rv = payload_rv;
+	o->payload_length = s.plen;
+	o->payload_header_length = s.phl;
+	o->flags = s.flags;
+	o->header_packed = s.header18;
+	o->type = (uint8_t)s.type;
+	o->lt_addr = (uint8_t)s.lt_addr;
+	o->hdr_flags = (uint8_t)s.hdr_flags;
+	o->hec = (uint8_t)s.hec;
+	o->llid = (uint8_t)s.llid;
+	o->flow = (uint8_t)s.flow;
+	o->uap = (uint8_t)s.uap;
+	o->payload_header = s.ph16;
+}
+
+// cut packets out of the packed streams
+__global__ __launch_bounds__(64) void gather_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
+						     const btbbx_hit *hits, uint32_t n_packets, uint32_t max_length,
+						     uint64_t *packets, uint32_t *lengths)
+{
+	uint32_t pkt = blockIdx.x;
+	uint32_t i = threadIdx.x;           // output word
+	if (pkt >= n_packets || i >= BTBBX_PKT_WORDS)
+		return;
+	const btbbx_hit h = hits[pkt];
+	const uint64_t *base = words + (uint64_t)h.stream * pitch_words;
+	uint64_t total_bits = n_words * 64;
+	uint64_t avail = h.offset < total_bits ? total_bits - h.offset : 0;
+	uint32_t len = avail < max_length ? (uint32_t)avail : max_length;
+	if (len > BTBBX_MAX_SYMBOLS)
+		len = BTBBX_MAX_SYMBOLS;
+	uint64_t bit = h.offset + 64ULL * i;
+	uint64_t j = bit >> 6;
+	uint32_t sh = (uint32_t)(bit & 63);
+	uint64_t lo = j < n_words ? base[j] : 0, hi = (j + 1) < n_words ? base[j + 1] : 0;
+	uint64_t v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+	// zero everything at and beyond `len`
+	uint32_t first = 64 * i;
+	if (first >= len)
+		v = 0;
+	else if (len - first < 64)
+		v &= (1ULL << (len - first)) - 1;
+	packets[(uint64_t)pkt * BTBBX_PKT_WORDS + i] = v;
+	if (i == 0)
+		lengths[pkt] = len;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+
+extern "C" int btbbx_gather_packets_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+					   const btbbx_hit *d_hits, uint32_t n_packets, uint32_t max_length,
+					   uint64_t *d_packets, uint32_t *d_lengths, void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!n_packets)
+		return BTBBX_OK;
+	hipLaunchKernelGGL(gather_kernel, dim3(n_packets), dim3(64), 0, (hipStream_t)hip_stream,
+			   d_words, n_words, pitch_words, d_hits, n_packets, max_length, d_packets, d_lengths);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+				   btbbx_trial *d_trials, void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!n_packets)
+		return BTBBX_OK;
+	hipLaunchKernelGGL(trials_kernel, dim3(n_packets), dim3(64), 0, (hipStream_t)hip_stream,
+			   d_packets, d_in, n_packets, d_trials);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+		  btbbx_pkt_out *d_out, uint32_t mode, const TrialPlan *plan, hipStream_t stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!n_packets)
+		return BTBBX_OK;
+	TrialPlan p = {0, 0, 0};
+	if (plan)
+		p = *plan;
+	hipLaunchKernelGGL(decode_kernel, dim3((n_packets + 63) / 64), dim3(64), 0, stream,
+			   d_packets, d_in, n_packets, d_out, mode, p);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+				   btbbx_pkt_out *d_out, void *hip_stream)
+{
+	return launch_decode(d_packets, d_in, n_packets, d_out, DEC_HEADER | DEC_PAYLOAD, nullptr, (hipStream_t)hip_stream);
+}

@@ -1,0 +1,609 @@
+// scan.hip -- sliding 64-bit access-code correlator for gfx950 (MI355X).
+//
+// Replaces the per-symbol loops of promiscuous_packet_search()
+// (lib/src/bluetooth_packet.c:368-420) and find_known_lap() (:423-441) behind
+// btbb_find_ac() (:444-464).  Input is the PACKED stream (1 bit per symbol); one
+// lane owns the 64 bit-offsets that start in one 64-bit word.
+//
+// LAP_ANY, per lane and word:
+//   1. bit-sliced barker pre-filter: seven funnel-shifted copies of the stream give the
+//      7-bit window (LAP MSB + 6 barker bits, :378-385) of all 32 offsets of a dword at
+//      once; a carry-save adder counts mismatches against 0x27 and `count in {0,1,6,7}`
+//      is BARKER_DISTANCE[window] <= 1.  1/8 of the offsets survive.
+//   2. per survivor: 64-bit window by two v_alignbit, barker correction + `^ pn`
+//      (:390-393) folded into table constants, low 32 syndrome bits from two
+//      LDS-resident tables (gen_syndrome, :147-159, is GF(2)-linear), then one probe of
+//      an LDS bitmap holding the 18-bit projection of every acceptable syndrome
+//      (the syndrome map of :161-185 and the zero syndrome).  ~0.65 % pass.
+//   3. candidates go to a per-wave LDS ring and are verified 64 at a time with the
+//      exact reference rule: full 34-bit syndrome, open-addressing lookup of the
+//      error pattern, popcount <= max_ac_errors, LAP from the corrected word
+//      (:396-416).  Results are therefore bit-exact, the bitmap only prunes.
+// Known LAP: bit-sliced mismatch count of the top 8 sync-word bits prunes, the
+// survivors get the full popcount(window ^ syncword) of :433.
+//
+// One persistent 1024-thread workgroup per CU (16 wave64) keeps the 112 KiB of tables in
+// LDS; workgroups stride over 64 KiB-bit tiles of the stream(s).  Pure integer work, no
+// MFMA; bound by VALU/LDS issue, not by HBM (see DESIGN.md for the roofline accounting).
+#include "common.h"
+
+#define FULL_MASK 0xffffffffffffffffULL
+
+struct ScanArgs {
+	const uint64_t *words;
+	uint64_t n_words;        // valid words per stream
+	uint64_t pitch_words;    // distance between streams
+	uint64_t search_bits;    // offsets [0, search_bits) are tested
+	uint64_t tiles_per_stream;
+	uint64_t n_tiles;
+	uint32_t n_streams;
+	uint32_t lap;            // known-LAP mode
+	uint64_t syncword;       // known-LAP mode
+	int max_err;
+	btbbx_hit *hits;
+	uint32_t hit_cap;
+	uint32_t *hit_count;
+	unsigned long long *first;   // first-match mode (atomicMin target) or nullptr
+	ScanTables t;
+};
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// full adder on bit planes
+__device__ __forceinline__ void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry)
+{
+	sum = a ^ b ^ c;
+	carry = (a & b) | (c & (a ^ b));
+}
+
+// Barker pre-filter for the 32 offsets whose window starts in the dword before `dm`:
+// bit k of the 7-bit window at offset p is stream bit p + 57 + k = bit (p + 25 + k) of dh:dm.
+__device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t &pass, uint32_t &cls)
+{
+	// mismatch planes against BARKER1 = 0b0100111 (bit k set for k = 0,1,2,5)
+	uint32_t m0 = ~alignbit(dh, dm, 25);
+	uint32_t m1 = ~alignbit(dh, dm, 26);
+	uint32_t m2 = ~alignbit(dh, dm, 27);
+	uint32_t m3 = alignbit(dh, dm, 28);
+	uint32_t m4 = alignbit(dh, dm, 29);
+	uint32_t m5 = ~alignbit(dh, dm, 30);
+	uint32_t m6 = alignbit(dh, dm, 31);
+	uint32_t a, ca, b, cb, ones, cc, twos, fours;
+	csa(m0, m1, m2, a, ca);
+	csa(m3, m4, m5, b, cb);
+	csa(a, b, m6, ones, cc);
+	csa(ca, cb, cc, twos, fours);
+	(void)ones;
+	uint32_t near1 = ~(twos | fours);     // 0 or 1 mismatches -> corrected to BARKER1
+	uint32_t near0 = twos & fours;        // 6 or 7 mismatches -> corrected to BARKER0
+	pass = near1 | near0;
+	cls = near1;
+}
+
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uint64_t offset,
+					 uint32_t lap, uint32_t nerr)
+{
+	if (a.first) {
+		unsigned long long v = ((unsigned long long)offset << 32) | ((unsigned long long)(lap & 0xffffff) << 8) | nerr;
+		atomicMin(a.first, v);
+		return;
+	}
+	uint32_t idx = atomicAdd(a.hit_count, 1u);
+	if (idx < a.hit_cap) {
+		btbbx_hit h;
+		h.offset = offset;
+		h.lap = lap;
+		h.ac_errors = (uint8_t)nerr;
+		h.reserved = 0;
+		h.stream = (uint16_t)stream;
+		a.hits[idx] = h;
+	}
+}
+
+__device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, uint64_t n_words)
+{
+	return j < n_words ? base[j] : 0ULL;
+}
+
+// The exact acceptance rule of promiscuous_packet_search for one offset that passed the
+// barker filter (bluetooth_packet.c:387-416).
+__device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t stream, uint64_t word, uint32_t p)
+{
+	const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
+	uint64_t lo = load_word(base, word, a.n_words);
+	uint64_t hi = load_word(base, word + 1, a.n_words);
+	uint64_t w = p ? (lo >> p) | (hi << (64 - p)) : lo;
+	uint32_t win = (uint32_t)(w >> 57);
+	uint32_t cls = __popc(win ^ BARKER1) <= 1 ? 1u : 0u;
+	uint64_t sw = (w & LOW57) | ((uint64_t)(cls ? BARKER1 : BARKER0) << 57);
+	// syndrome of (sw ^ pn): linear, so bytes 0..6 of w, bit 56, and a class constant
+	uint64_t syn = a.t.kclass[cls];
+	uint64_t low = w & LOW57;
+#pragma unroll
+	for (int b = 0; b < 8; b++)
+		syn ^= a.t.bytetab[b * 256 + ((low >> (8 * b)) & 0xff)];
+	uint32_t nerr = 0;
+	if (syn) {
+		uint64_t h = ((((uint32_t)syn ^ (uint32_t)(syn >> 32)) * 0x9E3779B1u) >> (32 - __popcll(a.t.hmask))) & a.t.hmask;
+		for (;;) {
+			uint64_t slot = a.t.hslots[h];
+			if (slot == HSLOT_EMPTY)
+				return;                               // no pattern -> ac_errors = 0xff -> reject
+			if ((slot & 0x3ffffffffULL) == syn) {
+				uint64_t err = 0;
+#pragma unroll
+				for (int i = 0; i < 5; i++) {
+					uint32_t pos = (uint32_t)(slot >> (34 + 6 * i)) & 63;
+					if (pos != 63)
+						err |= 1ULL << pos;
+				}
+				sw ^= err;
+				nerr = __popcll(err);
+				break;
+			}
+			h = (h + 1) & a.t.hmask;
+		}
+	}
+	if ((int)nerr <= a.max_err)
+		emit_hit(a, stream, word * 64 + p, (uint32_t)(sw >> 34) & 0xffffff, nerr);
+}
+
+// ---- LAP_ANY ----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
+{
+	extern __shared__ uint32_t lds[];
+	uint32_t *ldsA = lds;
+	uint32_t *ldsB = ldsA + LDS_TABA_WORDS;
+	uint32_t *ldsM = ldsB + LDS_TABB_WORDS;
+	uint32_t *ldsQ = ldsM + LDS_BITMAP_WORDS;
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t wave = tid >> 6;
+	uint32_t *ring = ldsQ + wave * QRING;
+
+	// tables -> LDS, 16 bytes per lane per step, coalesced
+	{
+		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
+		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
+		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
+		uint4 *dA = reinterpret_cast<uint4 *>(ldsA);
+		uint4 *dB = reinterpret_cast<uint4 *>(ldsB);
+		uint4 *dM = reinterpret_cast<uint4 *>(ldsM);
+		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
+		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
+		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
+	}
+	__syncthreads();
+
+	uint32_t q_head = 0, q_tail = 0;      // wave-uniform ring cursors (free running)
+
+	// verify the oldest `n` ring entries, one per lane
+	auto drain = [&](uint32_t n) {
+		if (lane < n) {
+			uint32_t code = ring[(q_head + lane) & (QRING - 1)];
+			uint32_t it = code >> 12;
+			uint32_t src_lane = (code >> 6) & 63;
+			uint32_t p = code & 63;
+			uint64_t tile = blockIdx.x + (uint64_t)it * gridDim.x;
+			uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
+			uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + src_lane;
+			verify_lap_any(a, stream, word, p);
+		}
+		q_head += n;
+	};
+
+	uint32_t it = 0;
+	for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
+		const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
+		const uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + tid;
+		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
+		const uint64_t lo = load_word(base, word, a.n_words);
+		const uint64_t hi = load_word(base, word + 1, a.n_words);
+		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
+		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
+
+		// offsets of this word that lie inside [0, search_bits)
+		uint64_t first_off = word * 64;
+		uint64_t valid = first_off >= a.search_bits ? 0ULL
+			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+
+		uint32_t passA, clsA, passB, clsB;
+		barker32(d1, d2, passA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
+		barker32(d2, d3, passB, clsB);       // offsets 32..63
+		passA &= (uint32_t)valid;
+		passB &= (uint32_t)(valid >> 32);
+
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			uint32_t m = half ? passB : passA;
+			const uint32_t cls = half ? clsB : clsA;
+			const uint32_t e0 = half ? d1 : d0, e1 = half ? d2 : d1, e2 = half ? d3 : d2;
+			// The loop is kept WAVE-UNIFORM (runs while any lane has survivors) so that the
+			// ring cursors stay uniform; lanes without work are masked only around the
+			// table look-ups.
+			while (__ballot(m != 0)) {
+				uint32_t bit = 0, p = 0;
+				if (m) {
+					p = __builtin_ctz(m);
+					m &= m - 1;
+					const uint32_t wlo = alignbit(e1, e0, p);
+					const uint32_t whi = alignbit(e2, e1, p);
+					const uint32_t c = (cls >> p) & 1;
+					const uint32_t ia = whi & ((1u << TABA_BITS) - 1);
+					const uint32_t ib = ((whi >> TABA_BITS) & ((1u << TABB_BITS) - 1)) | (c << TABB_BITS);
+					const uint32_t proj = wlo ^ ldsA[ia] ^ ldsB[ib];
+					bit = (ldsM[(proj >> 5) & (LDS_BITMAP_WORDS - 1)] >> (proj & 31)) & 1;
+				}
+				const uint64_t cand = __ballot(bit);
+				if (cand) {
+					const uint32_t n = __popcll(cand);
+					if (q_tail - q_head + n > QRING) {
+						// ring full (adversarial input): verify in place, no queueing
+						if (bit)
+							verify_lap_any(a, stream, word, p + 32 * half);
+					} else {
+						if (bit) {
+							uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(cand >> 32),
+									__builtin_amdgcn_mbcnt_lo((uint32_t)cand, 0));
+							ring[slot & (QRING - 1)] = (it << 12) | (lane << 6) | (p + 32 * half);
+						}
+						q_tail += n;
+					}
+				}
+			}
+		}
+		// wave-uniform: verify in full-wave batches
+		while (q_tail - q_head >= 64)
+			drain(64);
+	}
+	if (q_tail != q_head)
+		drain(q_tail - q_head);
+}
+
+// ---- known LAP --------------------------------------------------------------------------
+
+// bit-sliced "mismatches in sync-word bits 56..63 <= limit" for 32 offsets
+__device__ __forceinline__ uint32_t top8_filter(uint32_t dm, uint32_t dh, uint32_t ac_top8, int limit)
+{
+	uint32_t m[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		uint32_t s = alignbit(dh, dm, 24 + k);           // window bit 56 + k
+		m[k] = ((ac_top8 >> k) & 1) ? ~s : s;
+	}
+	uint32_t s1, c1, s2, c2, s3, c3, o, c4, t, f1, t2, f2, f, e;
+	csa(m[0], m[1], m[2], s1, c1);
+	csa(m[3], m[4], m[5], s2, c2);
+	s3 = m[6] ^ m[7]; c3 = m[6] & m[7];
+	csa(s1, s2, s3, o, c4);
+	csa(c1, c2, c3, t, f1);
+	t2 = t ^ c4; f2 = t & c4;
+	f = f1 ^ f2; e = f1 & f2;
+	// count = o + 2*t2 + 4*f + 8*e ; keep offsets with count <= limit
+	if (limit >= 8) return 0xffffffffu;
+	uint32_t gt = 0, eq = 0xffffffffu;
+	const uint32_t planes[4] = { e, f, t2, o };
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		uint32_t lim_bit = ((limit >> (3 - b)) & 1) ? 0xffffffffu : 0u;
+		gt |= eq & planes[b] & ~lim_bit;
+		eq &= ~(planes[b] ^ lim_bit);
+	}
+	return ~gt;
+}
+
+__global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
+	const uint32_t ac_top8 = ac_hi >> 24;
+	const int limit = a.max_err < 0 ? -1 : a.max_err;
+	if (limit < 0)
+		return;
+	for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+		const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
+		const uint64_t word = (tile % a.tiles_per_stream) * 256 + tid;
+		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
+		const uint64_t lo = load_word(base, word, a.n_words);
+		const uint64_t hi = load_word(base, word + 1, a.n_words);
+		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
+		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
+		uint64_t first_off = word * 64;
+		uint64_t valid = first_off >= a.search_bits ? 0ULL
+			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+		uint32_t passA = top8_filter(d1, d2, ac_top8, limit) & (uint32_t)valid;
+		uint32_t passB = top8_filter(d2, d3, ac_top8, limit) & (uint32_t)(valid >> 32);
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			uint32_t m = half ? passB : passA;
+			const uint32_t e0 = half ? d1 : d0, e1 = half ? d2 : d1, e2 = half ? d3 : d2;
+			while (m) {
+				const uint32_t p = __builtin_ctz(m);
+				m &= m - 1;
+				const uint32_t wlo = alignbit(e1, e0, p);
+				const uint32_t whi = alignbit(e2, e1, p);
+				const int nerr = __popc(wlo ^ ac_lo) + __popc(whi ^ ac_hi);     // :433
+				if (nerr <= limit)
+					emit_hit(a, stream, word * 64 + p + 32 * half, a.lap, (uint32_t)nerr);
+			}
+		}
+	}
+}
+
+// ---- symbol <-> packed conversion ---------------------------------------------------------
+
+// 16 symbols (bit 0 of 16 bytes) -> 16 bits
+__device__ __forceinline__ uint32_t gather16(uint4 v)
+{
+	auto nib = [](uint32_t x) {
+		x &= 0x01010101u;
+		return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
+	};
+	return nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *sym, uint64_t n_sym, uint64_t *words, uint64_t n_words)
+{
+	// each lane converts 16 symbols; 4 adjacent lanes make one word
+	uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint64_t n_chunks = n_words * 4;
+	for (; chunk < ((n_chunks + 63) & ~63ULL); chunk += stride) {
+		uint64_t s0 = chunk * 16;
+		uint32_t bits = 0;
+		if (s0 + 16 <= n_sym && (((uintptr_t)(sym + s0)) & 15) == 0) {
+			bits = gather16(*reinterpret_cast<const uint4 *>(sym + s0));
+		} else if (s0 < n_sym) {
+			for (uint32_t i = 0; i < 16 && s0 + i < n_sym; i++)
+				bits |= (uint32_t)(sym[s0 + i] & 1) << i;
+		}
+		uint32_t q = threadIdx.x & 3;
+		uint64_t part = (uint64_t)bits << (16 * q);
+		part |= __shfl_xor(part, 1);
+		part |= __shfl_xor(part, 2);
+		if (q == 0 && chunk < n_chunks)
+			words[chunk >> 2] = part;
+	}
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const uint64_t *words, uint64_t n_sym, uint8_t *sym)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i * 8 < n_sym; i += stride) {              // 8 symbols per lane
+		uint32_t byte = (uint32_t)(words[i >> 3] >> (8 * (i & 7))) & 0xff;
+		uint64_t out = 0;
+#pragma unroll
+		for (int b = 0; b < 8; b++)
+			out |= (uint64_t)((byte >> b) & 1) << (8 * b);
+		if (i * 8 + 8 <= n_sym && (((uintptr_t)(sym + i * 8)) & 7) == 0) {
+			*reinterpret_cast<uint64_t *>(sym + i * 8) = out;
+		} else {
+			for (uint32_t b = 0; b < 8 && i * 8 + b < n_sym; b++)
+				sym[i * 8 + b] = (uint8_t)(out >> (8 * b));
+		}
+	}
+}
+
+// ---- launchers ----------------------------------------------------------------------------
+
+static int check_scan_args(uint64_t n_words, uint64_t pitch_words, uint32_t n_streams, uint64_t search_bits)
+{
+	if (n_streams == 0 || n_streams > 65535) {
+		set_error("btbbx_scan: n_streams must be 1..65535");
+		return BTBBX_E_ARG;
+	}
+	if (n_streams > 1 && pitch_words < n_words) {
+		set_error("btbbx_scan: pitch_words < n_words");
+		return BTBBX_E_ARG;
+	}
+	if (search_bits + 63 > n_words * 64) {
+		set_error("btbbx_scan: search_bits + 63 exceeds the stream (%llu > %llu bits)",
+			  (unsigned long long)(search_bits + 63), (unsigned long long)(n_words * 64));
+		return BTBBX_E_ARG;
+	}
+	return BTBBX_OK;
+}
+
+static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+		       uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
+		       btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
+		       unsigned long long *d_first, hipStream_t stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	rc = check_scan_args(n_words, pitch_words, n_streams, search_bits);
+	if (rc)
+		return rc;
+	if (search_bits == 0)
+		return BTBBX_OK;
+	Ctx &c = ctx();
+	ScanArgs a;
+	a.words = d_words;
+	a.n_words = n_words;
+	a.pitch_words = pitch_words;
+	a.search_bits = search_bits;
+	a.n_streams = n_streams;
+	a.lap = lap;
+	a.syncword = 0;
+	a.max_err = max_ac_errors;
+	a.hits = d_hits;
+	a.hit_cap = hit_cap;
+	a.hit_count = d_hit_count;
+	a.first = d_first;
+	a.t = c.scan;
+	const uint64_t search_words = (search_bits + 63) / 64;
+	if (lap == BTBBX_LAP_ANY) {
+		a.tiles_per_stream = (search_words + SCAN_THREADS - 1) / SCAN_THREADS;
+		a.n_tiles = a.tiles_per_stream * n_streams;
+		uint64_t grid = a.n_tiles < (uint64_t)c.num_cus ? a.n_tiles : (uint64_t)c.num_cus;
+		if ((a.n_tiles + grid - 1) / grid >= (1u << 20)) {
+			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
+			return BTBBX_E_ARG;
+		}
+		static bool attr_set = false;
+		if (!attr_set) {
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel),
+						    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES));
+			attr_set = true;
+		}
+		hipLaunchKernelGGL(scan_lap_any_kernel, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a);
+	} else {
+		a.syncword = host_gen_syncword(lap & 0xffffff);
+		a.lap = lap;
+		a.tiles_per_stream = (search_words + 255) / 256;
+		a.n_tiles = a.tiles_per_stream * n_streams;
+		uint64_t cap = (uint64_t)c.num_cus * 8;
+		uint64_t grid = a.n_tiles < cap ? a.n_tiles : cap;
+		hipLaunchKernelGGL(scan_known_lap_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a);
+	}
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+				 uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
+				 btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count, void *hip_stream)
+{
+	if (!d_words || !d_hit_count || (!d_hits && hit_cap)) {
+		set_error("btbbx_scan_device: null pointer");
+		return BTBBX_E_ARG;
+	}
+	return launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors,
+			   d_hits, hit_cap, d_hit_count, nullptr, (hipStream_t)hip_stream);
+}
+
+extern "C" int btbbx_scan_first_device(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits,
+				       uint32_t lap, int max_ac_errors, uint64_t *d_first, void *hip_stream)
+{
+	if (!d_words || !d_first || search_bits >= (1ULL << 32)) {
+		set_error("btbbx_scan_first_device: bad argument");
+		return BTBBX_E_ARG;
+	}
+	return launch_scan(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors,
+			   nullptr, 0, nullptr, reinterpret_cast<unsigned long long *>(d_first),
+			   (hipStream_t)hip_stream);
+}
+
+extern "C" int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, uint64_t *d_words, void *hip_stream)
+{
+	if (n_symbols == 0)
+		return BTBBX_OK;
+	uint64_t n_words = (n_symbols + 63) / 64;
+	uint64_t threads = n_words * 4;
+	uint64_t blocks = (threads + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream,
+			   d_symbols, n_symbols, d_words, n_words);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_symbols, void *hip_stream)
+{
+	if (n_symbols == 0)
+		return BTBBX_OK;
+	uint64_t threads = (n_symbols + 7) / 8;
+	uint64_t blocks = (threads + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream,
+			   d_words, n_symbols, d_symbols);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+// ---- host convenience wrappers ---------------------------------------------------------------
+
+#include <algorithm>
+
+extern "C" void btbbx_sort_hits(btbbx_hit *hits, size_t n)
+{
+	std::sort(hits, hits + n, [](const btbbx_hit &x, const btbbx_hit &y) {
+		if (x.stream != y.stream) return x.stream < y.stream;
+		return x.offset < y.offset;
+	});
+}
+
+static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits,
+			     uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap)
+{
+	uint32_t dev_cap = cap > 0xffffffffULL ? 0xffffffffu : (uint32_t)cap;
+	btbbx_hit *d_hits = nullptr;
+	uint32_t *d_count = nullptr;
+	if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) {
+		set_error("btbbx_scan: counter allocation failed");
+		return BTBBX_E_NOMEM;
+	}
+	if (dev_cap && hipMalloc(&d_hits, (size_t)dev_cap * sizeof(btbbx_hit)) != hipSuccess) {
+		(void)hipFree(d_count);
+		set_error("btbbx_scan: hit buffer allocation failed");
+		return BTBBX_E_NOMEM;
+	}
+	int64_t result;
+	uint32_t count = 0;
+	int rc = BTBBX_OK;
+	if (hipMemset(d_count, 0, sizeof(uint32_t)) != hipSuccess)
+		rc = BTBBX_E_NODEVICE;
+	if (!rc)
+		rc = btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors,
+				       d_hits, dev_cap, d_count, nullptr);
+	if (!rc && hipMemcpy(&count, d_count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess)
+		rc = hip_fail(hipGetLastError(), "hit count readback");
+	if (!rc) {
+		uint32_t n = count < dev_cap ? count : dev_cap;
+		if (n && hipMemcpy(hits, d_hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost) != hipSuccess)
+			rc = hip_fail(hipGetLastError(), "hit readback");
+		else
+			btbbx_sort_hits(hits, n);
+	}
+	result = rc ? rc : (int64_t)count;
+	if (d_hits) (void)hipFree(d_hits);
+	(void)hipFree(d_count);
+	return result;
+}
+
+extern "C" int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search_bits,
+				   uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	rc = check_scan_args(n_words, n_words, 1, search_bits);
+	if (rc)
+		return rc;
+	uint64_t *d_words = (uint64_t *)ctx_scratch((n_words + 2) * 8);
+	if (!d_words)
+		return BTBBX_E_NOMEM;
+	HIP_TRY(hipMemcpy(d_words, words, n_words * 8, hipMemcpyHostToDevice));
+	return scan_resident(d_words, n_words, search_bits, lap, max_ac_errors, hits, cap);
+}
+
+extern "C" int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
+				      uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (search_length + 63 > n_symbols) {
+		set_error("btbbx_scan_symbols: search_length + 63 exceeds n_symbols");
+		return BTBBX_E_ARG;
+	}
+	uint64_t n_words = (n_symbols + 63) / 64;
+	size_t sym_bytes = (n_symbols + 15) & ~15ULL;
+	char *block = (char *)ctx_scratch(sym_bytes + (n_words + 2) * 8);
+	if (!block)
+		return BTBBX_E_NOMEM;
+	uint8_t *d_sym = (uint8_t *)block;
+	uint64_t *d_words = (uint64_t *)(block + sym_bytes);
+	HIP_TRY(hipMemcpy(d_sym, symbols, n_symbols, hipMemcpyHostToDevice));
+	rc = btbbx_pack_device(d_sym, n_symbols, d_words, nullptr);
+	if (rc)
+		return rc;
+	return scan_resident(d_words, n_words, search_length, lap, max_ac_errors, hits, cap);
+}

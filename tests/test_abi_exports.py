@@ -1,0 +1,74 @@
+"""The C-ABI library builds (hipcc cross-compiles gfx950 without a GPU), loads, and exports
+every symbol include/btbb.h and include/btbbx.h declare.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import libbtbb_amd
+    if not os.path.exists(libbtbb_amd.LIB_PATH):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "libbtbb_amd", "csrc")], check=True)
+    return libbtbb_amd.lib()
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    return sorted(set(re.findall(r"\b(btbbx?_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header", ["btbb.h", "btbbx.h"])
+def test_every_declared_symbol_is_exported(lib, header):
+    import libbtbb_amd
+    names = declared(header)
+    assert len(names) > 20
+    for n in names:
+        assert n in libbtbb_amd.SIGNATURES, "no ctypes signature for %s" % n
+        assert getattr(lib, n) is not None
+
+
+def test_soname():
+    import libbtbb_amd
+    out = subprocess.run(["readelf", "-d", libbtbb_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libbtbb.so.1" in out
+
+
+def test_host_only_entry_points(lib):
+    """Entry points that are pure host bookkeeping work without a GPU."""
+    assert lib.btbb_get_version() == b"1.0"
+    assert lib.btbb_gen_syncword(0x9E8B33) == 0x4E7A2CCE331A3AE2
+    assert lib.btbb_gen_syncword(0x123456) == 0xB048D15A658627C0
+    p = lib.btbb_packet_new()
+    lib.btbb_packet_set_flag(p, 4, 1)
+    assert lib.btbb_packet_get_flag(p, 4) == 1 and lib.btbb_packet_get_flag(p, 2) == 0
+    lib.btbb_packet_set_uap(p, 0x47)
+    assert lib.btbb_packet_get_uap(p) == 0x47 and lib.btbb_packet_get_flag(p, 2) == 1
+    lib.btbb_packet_unref(p)
+    pn = lib.btbb_piconet_new()
+    lib.btbb_init_piconet(pn, 0xABCDEF)
+    assert lib.btbb_piconet_get_lap(pn) == 0xABCDEF and lib.btbb_piconet_get_flag(pn, 3) == 1
+    assert lib.btbb_piconet_set_channel_seen(pn, 17) == 1 and lib.btbb_piconet_set_channel_seen(pn, 17) == 0
+    lib.btbb_piconet_unref(pn)
+    assert lib.btbb_init(9) == -1          # range check happens before any device work
+
+
+def test_fails_loudly_without_gpu(lib):
+    """No CPU fallback: without a device the compute entry points report an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert lib.btbbx_init(2) < 0
+    assert b"no CPU path" in lib.btbbx_last_error() or b"HIP" in lib.btbbx_last_error()
+    import numpy as np
+    import libbtbb_amd
+    with pytest.raises(libbtbb_amd.BtbbError):
+        libbtbb_amd.scan_words(np.zeros(64, np.uint64), 1000)

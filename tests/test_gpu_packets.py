@@ -1,0 +1,231 @@
+"""GPU parity for the bit chain behind an access code: 64-clock trial tables, header /
+payload decode (batch API) and the drop-in packet functions, all against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs
+import _pkt
+import libbtbb_amd as bt
+from libbtbb_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def ready():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    bt.init(2)
+    _libs.oracle().orc_init(2)
+
+
+def _oracle_trials(orc, sym, entry_type=0, entry_uap=0, whitened=1):
+    p = orc.orc_packet_new()
+    orc.orc_packet_init_found(p, 0, 0)
+    orc.orc_packet_set_flag(p, 0, whitened)
+    orc.orc_packet_set_data(p, _libs.ptr(sym), len(sym), 0, 0)
+    p.contents.packet_type = entry_type
+    p.contents.UAP = entry_uap
+    out = []
+    for clock in range(64):
+        # every trial starts from the entry state: only type/UAP can leak between trials, and
+        # only when FEC 1/3 fails, which does not depend on the clock
+        p.contents.packet_type = entry_type
+        p.contents.UAP = entry_uap
+        u = orc.orc_try_clock(clock, p)
+        rv = orc.orc_crc_check(clock, p)
+        out.append((u, p.contents.packet_type, rv))
+    orc.orc_packet_free(p)
+    return out
+
+
+def test_trial_tables():
+    orc = _libs.oracle()
+    rng = np.random.default_rng(31)
+    pk = _pkt.random_packets(rng, 360)
+    syms = [np.ascontiguousarray(s[:bt.MAX_SYMBOLS]) for s, _ in pk]
+    words, lengths = bt.packets_to_words(syms)
+    pin = np.zeros(len(syms), bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    pin["flags"] = 1
+    pin["type"] = rng.integers(0, 16, len(syms))
+    pin["uap"] = rng.integers(0, 256, len(syms))
+    pin["flags"][::17] = 0                      # a few unwhitened
+    got = bt.run_trials(words, pin)
+    hist = {}
+    for i, s in enumerate(syms):
+        want = _oracle_trials(orc, s, int(pin["type"][i]), int(pin["uap"][i]), int(pin["flags"][i]) & 1)
+        g = [(int(t["uap"]), int(t["type"]), int(t["rv"])) for t in got[i]]
+        assert g == want, (i, pk[i][1], [j for j in range(64) if g[j] != want[j]][:5])
+        for _, _, rv in want:
+            hist[rv] = hist.get(rv, 0) + 1
+    assert hist.get(10, 0) > 30 and hist.get(1000, 0) > 5 and hist.get(0, 0) > 0 and hist.get(2, 0) > 0
+
+
+def _oracle_decode(orc, sym, clkn, uap, clk_valid=True):
+    p = orc.orc_packet_new()
+    orc.orc_packet_init_found(p, 0, 0)
+    orc.orc_packet_set_data(p, _libs.ptr(sym), len(sym), 0, clkn << 1)
+    p.contents.UAP = uap
+    orc.orc_packet_set_flag(p, 2, 1)
+    orc.orc_packet_set_flag(p, 4, 1 if clk_valid else 0)
+    present = orc.orc_header_present(p)
+    h = orc.orc_decode_header(p)
+    r = orc.orc_decode_payload(p) if h else 0
+    st = _pkt.orc_state(p)
+    orc.orc_packet_free(p)
+    return present, h, r, st
+
+
+def test_batch_decode():
+    orc = _libs.oracle()
+    rng = np.random.default_rng(32)
+    pk = _pkt.random_packets(rng, 300, max_sym_errors=2)
+    syms = [np.ascontiguousarray(s[:bt.MAX_SYMBOLS]) for s, _ in pk]
+    words, lengths = bt.packets_to_words(syms)
+    pin = np.zeros(len(syms), bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    clk = np.array([m["clk6"] for _, m in pk], dtype=np.uint32)
+    wrong = rng.random(len(syms)) < 0.2
+    clk[wrong] ^= 5
+    pin["clkn"] = clk | (rng.integers(0, 1 << 20, len(syms)).astype(np.uint32) << 6)
+    pin["uap"] = [m["uap"] for _, m in pk]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    pin["flags"][::23] &= ~np.uint32(1 << 4)                  # CLK6 unknown -> header fails
+    out = bt.run_decode(words, pin)
+    good = 0
+    for i, s in enumerate(syms):
+        present, h, r, st = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]),
+                                          bool(pin["flags"][i] & 16))
+        o = out[i]
+        ctx = (i, pk[i][1])
+        assert int(o["header_present"]) == present, ctx
+        assert int(o["header_rv"]) == h and int(o["payload_rv"]) == r, ctx
+        assert int(o["flags"]) == st["flags"], ctx
+        assert int(o["header_packed"]) == int(sum(int(b) << k for k, b in enumerate(st["packet_header"]))), ctx
+        if h:
+            assert (int(o["type"]), int(o["lt_addr"]), int(o["hdr_flags"]), int(o["hec"])) == \
+                   (st["packet_type"], st["packet_lt_addr"], st["packet_flags"], st["packet_hec"]), ctx
+            assert int(o["payload_length"]) == st["payload_length"], ctx
+            assert int(o["payload_header_length"]) == st["payload_header_length"], ctx
+            assert (int(o["llid"]), int(o["flow"])) == (st["payload_llid"], st["payload_flow"]), ctx
+            assert int(o["payload_header"]) == int(sum(int(b) << k for k, b in enumerate(st["payload_header"]))), ctx
+            bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+            assert (bits == st["payload"]).all(), (ctx, np.nonzero(bits != st["payload"])[0][:8])
+            good += r in (10, 1000)
+    assert good > 50
+
+
+class DropIn:
+    """The same packet in the product (C ABI) and in the oracle."""
+
+    def __init__(self, lib, orc, lap):
+        self.lib, self.orc = lib, orc
+        self.p = C.c_void_p(lib.btbb_packet_new())
+        self.o = orc.orc_packet_new()
+        orc.orc_packet_init_found(self.o, lap, 0)
+        lib.btbb_packet_set_flag(self.p, 0, 1)
+
+    def set_data(self, sym, channel, clkn):
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        self.lib.btbb_packet_set_data(self.p, _libs.ptr(sym), len(sym), channel, clkn)
+        self.orc.orc_packet_set_data(self.o, _libs.ptr(sym), len(sym), channel, clkn)
+
+    def check(self, ctx=""):
+        lib, p, st = self.lib, self.p, _pkt.orc_state(self.o)
+        for f in range(15):
+            assert lib.btbb_packet_get_flag(p, f) == ((st["flags"] >> f) & 1), (ctx, "flag", f)
+        assert lib.btbb_packet_get_uap(p) == st["UAP"], ctx
+        assert lib.btbb_packet_get_type(p) == st["packet_type"], ctx
+        assert lib.btbb_packet_get_lt_addr(p) == st["packet_lt_addr"], ctx
+        assert lib.btbb_packet_get_header_flags(p) == st["packet_flags"], ctx
+        assert lib.btbb_packet_get_hec(p) == st["packet_hec"], ctx
+        assert lib.btbb_packet_get_header_packed(p) == int(sum(int(b) << k for k, b in enumerate(st["packet_header"]))), ctx
+        assert lib.btbb_packet_get_payload_length(p) == st["payload_length"], ctx
+        assert lib.btbb_packet_get_clkn(p) == st["clkn"], ctx
+        pay = np.frombuffer((C.c_uint8 * 2744).from_address(lib.btbb_get_payload(p)), dtype=np.uint8)
+        assert (pay == st["payload"]).all(), (ctx, "payload", np.nonzero(pay != st["payload"])[0][:8])
+
+    def close(self):
+        self.lib.btbb_packet_unref(self.p)
+        self.orc.orc_packet_free(self.o)
+
+
+def test_drop_in_decode(capfd):
+    lib, orc = bt.lib(), _libs.oracle()
+    rng = np.random.default_rng(33)
+    ok = 0
+    for sym, meta in _pkt.random_packets(rng, 60, max_sym_errors=1):
+        d = DropIn(lib, orc, meta["lap"])
+        clkn = (int(rng.integers(0, 1 << 20)) << 7) | (meta["clk6"] << 1)
+        d.set_data(sym, 5, clkn)
+        lib.btbb_packet_set_uap(d.p, meta["uap"])
+        d.o.contents.UAP = meta["uap"]
+        orc.orc_packet_set_flag(d.o, 2, 1)
+        assert lib.btbb_header_present(d.p) == orc.orc_header_present(d.o)
+        assert lib.btbb_decode_header(d.p) == orc.orc_decode_header(d.o) == 0
+        lib.btbb_packet_set_flag(d.p, 4, 1)
+        orc.orc_packet_set_flag(d.o, 4, 1)
+        h1, h2 = lib.btbb_decode_header(d.p), orc.orc_decode_header(d.o)
+        assert h1 == h2
+        d.check(("hdr", meta))
+        if h1:
+            r1, r2 = lib.btbb_decode_payload(d.p), orc.orc_decode_payload(d.o)
+            assert r1 == r2
+            ok += r1 in (10, 1000)
+            d.check(("payload", meta))
+            b1, b2 = np.zeros(400, np.uint8), np.zeros(400, np.uint8)
+            assert lib.btbb_get_payload_packed(d.p, _libs.ptr(b1)) == orc.orc_payload_packed(d.o, _libs.ptr(b2))
+            assert (b1 == b2).all()
+        assert lib.btbb_decode(d.p) == orc.orc_decode(d.o)
+        d.check(("decode", meta))
+        d.close()
+    capfd.readouterr()
+    assert ok > 8
+
+
+def test_drop_in_uap_from_header(capfd):
+    """Piconet UAP / CLK1-6 discovery over packet sequences: return values, piconet state and
+    the packet object after each call equal the oracle's."""
+    lib, orc = bt.lib(), _libs.oracle()
+    rng = np.random.default_rng(34)
+    found = 0
+    for seq in range(12):
+        lap, uap = int(rng.integers(0, 1 << 24)), int(rng.integers(1, 256))
+        pn = C.c_void_p(lib.btbb_piconet_new())
+        on = orc.orc_piconet_new()
+        lib.btbb_init_piconet(pn, lap)
+        orc.orc_init_piconet(on, lap)
+        clk = int(rng.integers(0, 1 << 26))
+        for k in range(10):
+            clk += int(rng.integers(1, 40)) * 2
+            clk6 = (clk >> 1) & 0x3F
+            t = [0, 1, 9, 6][k % 4] if k < int(rng.integers(2, 7)) else [3, 4, 10, 2][k % 4]
+            body = rng.integers(0, 256, 12, dtype=np.uint8).tobytes()
+            sym = synth.build_packet(lap, uap, clk6, t, lt_addr=1, body=body, fhs_bits=synth.fhs_payload(lap, uap, 1, 2, rng))
+            sym = np.concatenate([sym, rng.integers(0, 2, 50, dtype=np.uint8)])
+            if rng.random() < 0.3:
+                sym[int(rng.integers(68, len(sym)))] ^= 1
+            d = DropIn(lib, orc, lap)
+            d.set_data(sym, int(rng.integers(0, 79)), (clk + 34) & 0xFFFFFFF)
+            if seq % 2:
+                a, b = lib.btbb_uap_from_header(d.p, pn), orc.orc_uap_from_header(d.o, on)
+            else:
+                a, b = lib.btbb_process_packet(d.p, pn), orc.orc_process_packet(d.o, on)
+            assert a == b, (seq, k)
+            d.check((seq, k))
+            c = on.contents
+            for f in range(15):
+                assert lib.btbb_piconet_get_flag(pn, f) == ((c.flags >> f) & 1), (seq, k, f)
+            assert lib.btbb_piconet_get_uap(pn) == c.UAP and lib.btbb_piconet_get_clk_offset(pn) == c.clk_offset
+            d.close()
+            if orc.orc_piconet_get_flag(on, 2) and orc.orc_piconet_get_flag(on, 4):
+                found += c.UAP == uap
+                if seq % 2 == 0:
+                    break
+        lib.btbb_piconet_unref(pn)
+        orc.orc_piconet_free(on)
+    capfd.readouterr()
+    assert found >= 7

@@ -1,0 +1,255 @@
+"""GPU parity: the HIP access-code scan (through the C ABI) vs the oracle on the same seeded
+streams -- bit-exact hit lists (offset, LAP, ac_errors).  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs
+import libbtbb_amd as bt
+from libbtbb_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def ready():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    bt.lib().btbbx_shutdown()
+    bt.init(2)
+    orc = _libs.oracle()
+    orc.orc_reset_syndrome_map()
+    orc.orc_init(2)
+    yield
+    bt.lib().btbbx_shutdown()
+
+
+def as_tuples(hits):
+    return [(int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in hits]
+
+
+def stream(seed, nwords, **kw):
+    words, inj = synth.make_stream(seed, nwords, **kw)
+    return words, np.ascontiguousarray(synth.unpack_bits(words)), inj
+
+
+@pytest.mark.parametrize("max_err", [0, 1, 2, 3])
+def test_lap_any_parity(max_err):
+    words, sym, inj = stream(101, 1 << 14, stride=1024)          # 1 Mi symbols, 1024 injections
+    n = len(sym) - 63
+    got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, max_err))
+    want = _libs.orc_find_all(sym, n, _libs.LAP_ANY, max_err)
+    assert got == want
+    assert len(got) > 200
+
+
+@pytest.mark.parametrize("max_err", [0, 1, 2, 3, 5, 9])
+def test_known_lap_parity(max_err):
+    lap = 0x9E8B33
+    words, sym, inj = stream(102, 1 << 14, stride=1024, lap=lap)
+    n = len(sym) - 63
+    got = as_tuples(bt.scan_words(words, n, lap, max_err))
+    want = _libs.orc_find_all(sym, n, lap, max_err)
+    assert got == want and len(got) > 200
+
+
+def test_negative_and_edge_arguments():
+    words, sym, _ = stream(103, 256, stride=512)
+    assert len(bt.scan_words(words, 1000, bt.LAP_ANY, -1)) == 0
+    assert len(bt.scan_words(words, 1000, 0x123456, -1)) == 0
+    assert len(bt.scan_words(words, 0, bt.LAP_ANY, 2)) == 0
+    with pytest.raises(bt.BtbbError):
+        bt.scan_words(words, len(words) * 64, bt.LAP_ANY, 2)       # would read past the end
+    # ragged search lengths around word / tile boundaries
+    for n in (1, 63, 64, 65, 1023, 4096 + 17, len(sym) - 63):
+        for lap in (bt.LAP_ANY, 0x9E8B33):
+            assert as_tuples(bt.scan_words(words, n, lap, 2)) == _libs.orc_find_all(sym, n, lap, 2), (n, lap)
+
+
+def test_quirks_barker_and_bit57():
+    """barker errors corrected but not counted; bit 57 both ways."""
+    lap = 0x654321
+    sw = synth.syncword(lap)
+    for flips in [(60, 3, 30), (57,), (3, 30, 44), (58, 59), (63,), (57, 3), (0, 1), (56, 55, 54), (61, 2), ()]:
+        w = sw
+        for b in flips:
+            w ^= 1 << b
+        for shift in (0, 1, 31, 32, 33, 63):
+            sym = np.concatenate([np.zeros(128 + shift, np.uint8), synth.bits_lsb(w, 64), np.zeros(200, np.uint8)])
+            words = synth.pack_bits(sym)
+            n = len(sym) - 63
+            for mode_lap in (bt.LAP_ANY, lap):
+                for me in (0, 1, 2, 3):
+                    got = as_tuples(bt.scan_words(words, n, mode_lap, me))
+                    assert got == _libs.orc_find_all(sym, n, mode_lap, me), (flips, shift, mode_lap, me)
+
+
+def test_adversarial_all_candidates():
+    """A stream made only of sync words back to back: every 64th offset matches and the
+    candidate rings overflow into the in-place verification path."""
+    rng = np.random.default_rng(5)
+    laps = rng.integers(0, 1 << 24, 4096)
+    words = np.array([synth.syncword(int(l)) for l in laps], dtype=np.uint64)
+    words = np.concatenate([words, np.zeros(1, np.uint64)])
+    sym = np.ascontiguousarray(synth.unpack_bits(words))
+    n = len(sym) - 63
+    got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, 2))
+    assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, 2)
+    assert len(got) >= 4096
+
+
+def test_symbols_entry_and_pack_roundtrip():
+    words, sym, _ = stream(104, 1 << 10, stride=512)
+    n = len(sym) - 63
+    a = as_tuples(bt.scan_symbols(sym, n, bt.LAP_ANY, 2))
+    assert a == _libs.orc_find_all(sym, n, _libs.LAP_ANY, 2) and len(a) > 50
+    # odd lengths through pack/unpack
+    lib = bt.lib()
+    for ns in (1, 15, 16, 17, 63, 64, 65, 1000, 65536 + 3):
+        s = np.ascontiguousarray(sym[:ns])
+        d_s = bt.DeviceBuffer(ns + 64).upload(s)
+        d_w = bt.DeviceBuffer(((ns + 63) // 64) * 8 + 8)
+        d_o = bt.DeviceBuffer(ns + 64).zero()
+        bt.check(lib.btbbx_pack_device(d_s.ptr, ns, d_w.ptr, None))
+        bt.check(lib.btbbx_unpack_device(d_w.ptr, ns, d_o.ptr, None))
+        bt.check(lib.btbbx_sync(None))
+        w = d_w.download(np.uint64, (ns + 63) // 64)
+        assert (w == synth.pack_bits(s)).all()
+        assert (d_o.download(np.uint8, ns) == s).all()
+
+
+def test_device_generator_matches_host():
+    lib = bt.lib()
+    for first, nw, stride, lap, cyc in [(0, 4096, 1024, -1, 4), (777, 5000, 512, 0x9E8B33, 3), (1 << 20, 3000, 4096, -1, 4)]:
+        d = bt.DeviceBuffer(nw * 8)
+        bt.check(lib.btbbx_synth_device(d.ptr, first, nw, 0xC0FFEE, stride, lap, cyc, None))
+        bt.check(lib.btbbx_sync(None))
+        got = d.download(np.uint64, nw)
+        want, _ = synth.make_stream(0xC0FFEE, nw, stride=stride, first_word=first,
+                                    lap=None if lap < 0 else lap, err_cycle=cyc)
+        assert (got == want).all()
+
+
+def test_multi_stream_launch():
+    """79 channels in one launch: hits carry their stream index."""
+    lib = bt.lib()
+    nstreams, nw, pitch = 79, 600, 640
+    host = np.zeros(nstreams * pitch, np.uint64)
+    want = []
+    for s in range(nstreams):
+        w, _ = synth.make_stream(1000 + s, nw, stride=512)
+        host[s * pitch: s * pitch + nw] = w
+        sym = np.ascontiguousarray(synth.unpack_bits(w))
+        want += [(s,) + t for t in _libs.orc_find_all(sym, nw * 64 - 63, _libs.LAP_ANY, 2)]
+    d_w = bt.DeviceBuffer(host.nbytes).upload(host)
+    cap = 1 << 16
+    d_h = bt.DeviceBuffer(cap * 16)
+    d_c = bt.DeviceBuffer(4).zero()
+    bt.check(lib.btbbx_scan_device(d_w.ptr, nw, pitch, nstreams, nw * 64 - 63, bt.LAP_ANY, 2, d_h.ptr, cap, d_c.ptr, None))
+    bt.check(lib.btbbx_sync(None))
+    cnt = int(d_c.download(np.uint32, 1)[0])
+    hits = d_h.download(bt.HIT_DTYPE, cnt)
+    lib.btbbx_sort_hits(hits.ctypes.data_as(C.c_void_p), cnt)
+    got = [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in hits]
+    assert got == want and cnt > 2000
+
+
+def test_init_semantics_first_nonzero_wins():
+    """tables come from the first non-zero btbb_init; later values only filter."""
+    lib = bt.lib()
+    orc = _libs.oracle()
+    words, sym, _ = stream(105, 1 << 12, stride=512)
+    n = len(sym) - 63
+    try:
+        for first_init in (0, 1, 3):
+            lib.btbbx_shutdown()
+            orc.orc_reset_syndrome_map()
+            assert lib.btbb_init(first_init) == 0 and orc.orc_init(first_init) == 0
+            assert lib.btbb_init(2) == 0 and orc.orc_init(2) == 0
+            for me in (0, 1, 2, 3):
+                assert as_tuples(bt.scan_words(words, n, bt.LAP_ANY, me)) == _libs.orc_find_all(sym, n, _libs.LAP_ANY, me), (first_init, me)
+    finally:
+        lib.btbbx_shutdown()
+        orc.orc_reset_syndrome_map()
+        bt.init(2)
+        orc.orc_init(2)
+
+
+def test_find_ac_drop_in():
+    """btbb_find_ac through the C ABI: first match, packet allocation, LAP / ac_errors."""
+    lib = bt.lib()
+    orc = _libs.oracle()
+    words, sym, _ = stream(106, 1 << 10, stride=2048)
+    for lap in (bt.LAP_ANY, 0x9E8B33):
+        off = 0
+        found = 0
+        pkt = C.c_void_p(None)
+        while True:
+            n = len(sym) - 63 - off
+            if n <= 0:
+                break
+            lo, eo = C.c_uint32(0), C.c_uint8(0)
+            want = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + off), n, lap, 2, C.byref(lo), C.byref(eo))
+            got = lib.btbb_find_ac(C.c_void_p(sym.ctypes.data + off), n, lap, 2, C.byref(pkt))
+            assert (got if got >= 0 else -1) == want
+            if want < 0:
+                break
+            assert lib.btbb_packet_get_lap(pkt) == lo.value and lib.btbb_packet_get_ac_errors(pkt) == eo.value
+            assert lib.btbb_packet_get_flag(pkt, 0) == 1
+            found += 1
+            off += want + 1
+            if lap != bt.LAP_ANY:
+                break
+        if lap == bt.LAP_ANY:
+            assert found > 20
+        if pkt.value:
+            lib.btbb_packet_unref(pkt)
+    # nothing found: *pkt stays NULL
+    z = np.zeros(5000, np.uint8)
+    pkt = C.c_void_p(None)
+    assert lib.btbb_find_ac(_libs.ptr(z), 4000, bt.LAP_ANY, 2, C.byref(pkt)) < 0 and not pkt.value
+
+
+def test_large_stream_properties():
+    """512 MiB of packed stream generated in HBM: every injected sync word with <= 2 bit errors
+    is reported with its LAP and error count, nothing is reported twice, the count equals
+    injections + a plausible number of chance matches, and two sampled slices equal the oracle."""
+    import torch
+    lib = bt.lib()
+    nwords = 1 << 26                       # 2^32 symbols
+    stride = 4096
+    t = torch.empty(nwords + 8, dtype=torch.int64, device="cuda")
+    bt.check(lib.btbbx_synth_device(t.data_ptr(), 0, nwords, 7, stride, -1, 4, None))
+    cap = 1 << 21
+    hits_t = torch.zeros(cap * 2, dtype=torch.int64, device="cuda")
+    cnt_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nbits = nwords * 64 - 63
+    bt.check(lib.btbbx_scan_device(t.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2,
+                                   hits_t.data_ptr(), cap, cnt_t.data_ptr(), None))
+    torch.cuda.synchronize()
+    cnt = int(cnt_t.item())
+    assert cnt <= cap
+    hits = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:cnt]
+    hits = hits[np.argsort(hits["offset"], kind="stable")]
+    assert len(np.unique(hits["offset"])) == cnt
+    k = np.arange(nbits // stride, dtype=np.uint64)
+    pos, laps, nerr, mask = synth.injection_params(7, k, stride, 4)
+    popc = np.unpackbits(mask.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)   # repeated positions cancel
+    ok = (popc <= 2) & (pos + np.uint64(64) <= np.uint64(nwords * 64))
+    idx = np.searchsorted(hits["offset"], pos[ok])
+    assert (idx < cnt).all() and (hits["offset"][idx] == pos[ok]).all()
+    assert (hits["lap"][idx] == laps[ok]).all()
+    assert (hits["ac_errors"][idx] == popc[ok]).all()
+    extra = cnt - int(ok.sum())
+    assert 0 <= extra < 400                # theory: ~1.25e-8 * 2^32 = 54 chance matches
+    # sampled slices against the oracle
+    for first in (12345, nwords - 40000):
+        nw = 32768
+        sl = t[first:first + nw].cpu().numpy().view(np.uint64)
+        sym = np.ascontiguousarray(synth.unpack_bits(sl))
+        want = _libs.orc_find_all(sym, nw * 64 - 63, _libs.LAP_ANY, 2)
+        lo, hi = first * 64, first * 64 + nw * 64 - 63
+        sel = hits[(hits["offset"] >= lo) & (hits["offset"] < hi)]
+        got = [(int(h["offset"]) - lo, int(h["lap"]), int(h["ac_errors"])) for h in sel]
+        assert got == want
