@@ -56,19 +56,10 @@ def cpu_baseline(words_host, first_word, gpu_hits, cores):
     def work(i):
         lo, hi = int(bounds[i]), int(bounds[i + 1])
         if ref is not None:
-            # the caller loop of SURVEY.md 8(b): first-match API, resume one past each hit
-            out, off = [], lo
-            pkt = C.c_void_p(None)
-            base = sym.ctypes.data
-            while off < hi:
-                r = ref.btbb_find_ac(C.c_void_p(base + off), hi - off, 0xFFFFFFFF, 2, C.byref(pkt))
-                if r < 0:
-                    break
-                out.append((off + r, int(ref.btbb_packet_get_lap(pkt)), int(ref.btbb_packet_get_ac_errors(pkt))))
-                off += r + 1
-            if pkt.value:
-                ref.btbb_packet_unref(pkt)
-            return out
+            # the caller loop of SURVEY.md 8(b) (first-match btbb_find_ac, resume one past each
+            # hit), run natively by oracle/ref_internals.c so that the GIL is not in the way
+            return [(o + lo, l, e) for (o, l, e) in
+                    _libs.ref_find_all_native(sym, hi - lo, 0xFFFFFFFF, 2, cap=(hi - lo) // 2048 + 4096, base_offset=lo)]
         seg = sym[lo:hi + 63]
         return [(o + lo, l, e) for (o, l, e) in _libs.orc_find_all(np.ascontiguousarray(seg), hi - lo, 0xFFFFFFFF, 2)]
 

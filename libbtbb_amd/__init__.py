@@ -175,7 +175,7 @@ def lib():
             raise BtbbError(
                 "%s is missing: build it with `make -C libbtbb_amd/csrc` "
                 "(or __graft_entry__.build()); there is no Python/CPU fallback" % LIB_PATH)
-        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        handle = C.CDLL(LIB_PATH)          # RTLD_LOCAL: same symbol names as the reference checker
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError = missing export
             fn.restype, fn.argtypes = res, args

@@ -90,6 +90,36 @@ int refint_find_syndrome(uint64_t syndrome, uint64_t *error)
 	return 1;
 }
 
+/* The caller loop of an all-matches scan, natively: first-match btbb_find_ac resumed one
+ * symbol past every hit.  hits[] receives offset / LAP / ac_errors triples.
+ * Used by the test-suite and by bench.py's cpu_baseline leg ("kind": "reference"). */
+size_t refint_find_all(char *stream, uint64_t search_length, uint32_t lap, int max_ac_errors,
+		       uint64_t *hit_offset, uint32_t *hit_lap, uint8_t *hit_err, size_t cap)
+{
+	size_t n = 0;
+	uint64_t off = 0;
+	btbb_packet *pkt = NULL;
+	while (off < search_length) {
+		uint64_t left = search_length - off;
+		int chunk = left > 0x40000000ULL ? 0x40000000 : (int)left;
+		int r = btbb_find_ac(stream + off, chunk, lap, max_ac_errors, &pkt);
+		if (r < 0) {
+			off += (uint64_t)chunk;
+			continue;
+		}
+		if (n < cap) {
+			hit_offset[n] = off + (uint64_t)r;
+			hit_lap[n] = btbb_packet_get_lap(pkt);
+			hit_err[n] = btbb_packet_get_ac_errors(pkt);
+		}
+		n++;
+		off += (uint64_t)r + 1;
+	}
+	if (pkt)
+		btbb_packet_unref(pkt);
+	return n;
+}
+
 /* packet object layout (bluetooth_packet.h:52-112) so tests can peek at fields */
 size_t refint_packet_sizeof(void) { return sizeof(btbb_packet); }
 size_t refint_packet_offsetof(const char *field)

@@ -165,6 +165,7 @@ def ref():
         "btbb_piconet_get_clk_offset": (C.c_int, [vp]),
         "btbb_uap_from_header": (C.c_int, [vp, vp]),
         "btbb_process_packet": (C.c_int, [vp, vp]),
+        "refint_find_all": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, C.c_size_t]),
         "refint_gen_syndrome": (C.c_uint64, [C.c_uint64]),
         "refint_unfec13": (C.c_int, [vp, vp, C.c_int]),
         "refint_fec23": (C.c_uint16, [C.c_uint16]),
@@ -212,6 +213,18 @@ def orc_find_all(stream_u8, search_length, lap, max_err, cap=1 << 20):
     n = lib.orc_find_all(ptr(stream_u8), search_length, lap, max_err, hits, cap)
     assert n <= cap
     return [(int(h.offset), int(h.lap), int(h.ac_errors)) for h in hits[:n]]
+
+
+def ref_find_all_native(stream_u8, search_length, lap, max_err, cap=1 << 22, base_offset=0):
+    """Same loop as ref_find_all but run in C (oracle/ref_internals.c: refint_find_all)."""
+    lib = ref()
+    off = np.zeros(cap, np.uint64)
+    laps = np.zeros(cap, np.uint32)
+    errs = np.zeros(cap, np.uint8)
+    n = lib.refint_find_all(C.c_void_p(stream_u8.ctypes.data + base_offset), search_length, lap, max_err,
+                            ptr(off), ptr(laps), ptr(errs), cap)
+    assert n <= cap
+    return [(int(off[i]), int(laps[i]), int(errs[i])) for i in range(n)]
 
 
 def ref_find_all(stream_u8, search_length, lap, max_err):

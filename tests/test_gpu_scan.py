@@ -106,8 +106,9 @@ def test_symbols_entry_and_pack_roundtrip():
     assert a == _libs.orc_find_all(sym, n, _libs.LAP_ANY, 2) and len(a) > 50
     # odd lengths through pack/unpack
     lib = bt.lib()
+    big = np.ascontiguousarray(synth.unpack_bits(synth.noise_words(9, 0, 2048)))
     for ns in (1, 15, 16, 17, 63, 64, 65, 1000, 65536 + 3):
-        s = np.ascontiguousarray(sym[:ns])
+        s = np.ascontiguousarray(big[:ns])
         d_s = bt.DeviceBuffer(ns + 64).upload(s)
         d_w = bt.DeviceBuffer(((ns + 63) // 64) * 8 + 8)
         d_o = bt.DeviceBuffer(ns + 64).zero()
