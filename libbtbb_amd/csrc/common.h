@@ -21,25 +21,33 @@
 #define SCAN_THREADS   1024                // one workgroup per CU, 16 wave64
 #define SCAN_WAVES     (SCAN_THREADS / 64)
 #define TABA_BITS      13                  // window bits 32..44
-#define TABB_BITS      12                  // window bits 45..56 (+1 class bit)
-#define BITMAP_BITS    18                  // projection width of the candidate bitmap
+#define TABB_BITS      12                  // window bits 45..56
+#define BITMAP_BITS    19                  // projection width of the candidate bitmap
 #define QRING          256                 // per-wave candidate ring (entries)
 
-#define LDS_TABA_WORDS   (1u << TABA_BITS)            // 8192 u32
-#define LDS_TABB_WORDS   (2u << TABB_BITS)            // 8192 u32
-#define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 8192 u32
-#define LDS_QUEUE_WORDS  (SCAN_WAVES * QRING)         // 4096 u32
-#define SCAN_LDS_BYTES   (4u * (LDS_TABA_WORDS + LDS_TABB_WORDS + LDS_BITMAP_WORDS + LDS_QUEUE_WORDS))
+// LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
+// probe needs no address adds.
+#define LDS_TABB_WORDS   (1u << TABB_BITS)            // 4096 u32  = 16 KiB
+#define LDS_TABA_WORDS   (1u << TABA_BITS)            // 8192 u32  = 32 KiB
+#define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 16384 u32 = 64 KiB
+#define LDS_QUEUE_WORDS  (SCAN_WAVES * QRING)         // 4096 u32  = 16 KiB
+#define LDS_OFF_TABB     0u
+#define LDS_OFF_TABA     (LDS_OFF_TABB + 4u * LDS_TABB_WORDS)
+#define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
+#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)
+#define LDS_OFF_PARK     (LDS_OFF_QUEUE + 4u * LDS_QUEUE_WORDS)          // 64 lanes x 4 slots per wave
+#define SCAN_LDS_BYTES   (LDS_OFF_PARK + 4u * SCAN_WAVES * 64u * 4u)
 
 // ---- device-side table bundle -----------------------------------------------------
 struct ScanTables {
 	const uint32_t *tabA;      // [8192]   low-32 syndrome of window bits 32..44
-	const uint32_t *tabB;      // [2][4096] low-32 syndrome of bits 45..56 ^ class constant
-	const uint32_t *bitmap;    // [8192]   2^18-bit set: projection of acceptable syndromes
+	const uint32_t *tabB;      // [4096]   low-32 syndrome of bits 45..56 ^ class-0 constant
+	const uint32_t *bitmap;    // 2^BITMAP_BITS-bit set: projection of acceptable syndromes
 	const uint64_t *bytetab;   // [8][256] full 34-bit syndrome per window byte
 	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)
 	uint64_t hmask;            // slots - 1
 	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1
+	uint32_t kdiff;            // low 32 bits of kclass[0] ^ kclass[1]
 };
 
 // packed hash slot: bits 0..33 syndrome, then five 6-bit error positions (63 = unused),

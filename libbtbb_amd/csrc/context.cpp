@@ -162,14 +162,13 @@ static int upload_tables(int max_ac_errors)
 	uint64_t kclass[2];
 	kclass[0] = host_syndrome(((uint64_t)BARKER0 << 57) ^ SW_PN);
 	kclass[1] = host_syndrome(((uint64_t)BARKER1 << 57) ^ SW_PN);
-	for (int cls = 0; cls < 2; cls++)
-		for (uint32_t v = 0; v < (1u << TABB_BITS); v++) {
-			uint64_t s = kclass[cls];
-			for (int i = 0; i < TABB_BITS; i++)
-				if ((v >> i) & 1)
-					s ^= t.col[32 + TABA_BITS + i];
-			tabB[(cls << TABB_BITS) | v] = (uint32_t)s;
-		}
+	for (uint32_t v = 0; v < (1u << TABB_BITS); v++) {
+		uint64_t s = kclass[0];
+		for (int i = 0; i < TABB_BITS; i++)
+			if ((v >> i) & 1)
+				s ^= t.col[32 + TABA_BITS + i];
+		tabB[v] = (uint32_t)s;
+	}
 
 	// one block: tabA | tabB | bitmap | bytetab
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
@@ -192,6 +191,7 @@ static int upload_tables(int max_ac_errors)
 	c.scan.hmask = mb.mask;
 	c.scan.kclass[0] = kclass[0];
 	c.scan.kclass[1] = kclass[1];
+	c.scan.kdiff = (uint32_t)(kclass[0] ^ kclass[1]);
 	c.table_errors = max_ac_errors;
 	return BTBBX_OK;
 }

@@ -25,6 +25,7 @@
 // One persistent 1024-thread workgroup per CU (16 wave64) keeps the 112 KiB of tables in
 // LDS; workgroups stride over 64 KiB-bit tiles of the stream(s).  Pure integer work, no
 // MFMA; bound by VALU/LDS issue, not by HBM (see DESIGN.md for the roofline accounting).
+#include <stdlib.h>
 #include "common.h"
 
 #define FULL_MASK 0xffffffffffffffffULL
@@ -153,116 +154,212 @@ __device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t strea
 
 // ---- LAP_ANY ----------------------------------------------------------------------------
 
+// The kernel has no static __shared__, so the dynamic LDS allocation starts at LDS byte 0
+// and table addresses are plain byte offsets: every DS access below is `base + offset:imm`
+// with the table base folded into the 16-bit immediate.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off)
+{
+	return *reinterpret_cast<lds_u32_t *>(byte_off);
+}
+__device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v)
+{
+	*reinterpret_cast<lds_u32_t *>(byte_off) = v;
+}
+
+// index of the lowest set bit; 0xffffffff for 0 (v_ffbl_b32), which the callers use as
+// "offset 31 of a lane that has nothing left" -- its result is masked out afterwards
+__device__ __forceinline__ uint32_t lowest_bit(uint32_t m)
+{
+	uint32_t p;
+	asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(m));
+	return p;
+}
+
+// a ^ b ^ c in one instruction
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// One survivor (about 20 VALU, 3 DS): low 32 syndrome bits of the window at offset p of the
+// dword triple (e0,e1,e2)
+//   syndrome_low32 = w[31:0] ^ tabA[w[44:32]] ^ tabB[w[56:45]] ^ (class ? kdiff : 0)
+// then the candidate-bitmap probe with its low 19 bits.  `live` (0/1) masks the result.
+// Instruction choice follows tools/valu_rate.hip: two-operand logic/shift ops and v_bitop3
+// issue at full rate on gfx950, v_bfe/v_alignbit/v_lshl_add/v_and_or at half rate.
+template <int VARIANT>
+__device__ __forceinline__ uint32_t probe(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t cls,
+					  uint32_t kdiff, uint32_t p, uint32_t live)
+{
+	const uint32_t wlo = alignbit(e1, e0, p);
+	const uint32_t whi = alignbit(e2, e1, p);
+	const uint32_t offA = (whi << 2) & (((1u << TABA_BITS) - 1) << 2);
+	const uint32_t offB = (whi >> (TABA_BITS - 2)) & (((1u << TABB_BITS) - 1) << 2);
+	const uint32_t cmask = (uint32_t)__builtin_amdgcn_sbfe(cls, p, 1);     // 0 or ~0
+	const uint32_t x = __builtin_amdgcn_bitop3_b32(cmask, kdiff, wlo, 0x6a); // wlo ^ (cmask & kdiff)
+	uint32_t proj;
+	if (VARIANT == 2)        // ablation: no LDS at all
+		proj = xor3(x, offA + 77u, offB + 99u);
+	else
+		proj = xor3(x, lds_ld(LDS_OFF_TABA + offA), lds_ld(LDS_OFF_TABB + offB));
+	if (VARIANT == 2 || VARIANT == 3)        // ablation: no bitmap probe
+		return (proj == 0x12345678u) & live;
+	const uint32_t word = lds_ld(LDS_OFF_BITMAP + ((proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2)));
+	const uint32_t bit = (word >> (proj & 31)) & live;
+	if (VARIANT == 4)        // ablation: full probe, no candidates
+		return bit & (proj == 0x12345678u);
+	return bit;
+}
+
+#define LANE_SLOTS 4      // private candidate slots per lane
+
+template <int VARIANT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 {
 	extern __shared__ uint32_t lds[];
-	uint32_t *ldsA = lds;
-	uint32_t *ldsB = ldsA + LDS_TABA_WORDS;
-	uint32_t *ldsM = ldsB + LDS_TABB_WORDS;
-	uint32_t *ldsQ = ldsM + LDS_BITMAP_WORDS;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t wave = tid >> 6;
-	uint32_t *ring = ldsQ + wave * QRING;
+	// candidate slots of this lane (LANE_SLOTS consecutive dwords) and the wave's ring
+	const uint32_t slot_off = LDS_OFF_PARK + 4u * (wave * 64 * LANE_SLOTS + lane * LANE_SLOTS);
+	const uint32_t ring_off = LDS_OFF_QUEUE + 4u * wave * QRING;
+	const uint32_t kdiff = a.t.kdiff;
 
 	// tables -> LDS, 16 bytes per lane per step, coalesced
 	{
+		char *ldsb = reinterpret_cast<char *>(lds);
 		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
 		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
 		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
-		uint4 *dA = reinterpret_cast<uint4 *>(ldsA);
-		uint4 *dB = reinterpret_cast<uint4 *>(ldsB);
-		uint4 *dM = reinterpret_cast<uint4 *>(ldsM);
+		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
+		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
+		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
 		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
 		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
 		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
 	}
 	__syncthreads();
 
-	uint32_t q_head = 0, q_tail = 0;      // wave-uniform ring cursors (free running)
+	// tile -> (stream, first word) without divisions: uniform counters stepped per tile
+	struct Cursor { uint32_t stream; uint64_t t; };
+	auto advance = [&](Cursor &c) {
+		c.t += gridDim.x;
+		while (c.t >= a.tiles_per_stream) {
+			c.t -= a.tiles_per_stream;
+			c.stream++;
+		}
+	};
 
-	// verify the oldest `n` ring entries, one per lane
+	// Candidate = passed the bitmap (0.3 % of survivors).  Three stages keep it cheap:
+	//  1. park: one DS write into a private slot of the lane -- no atomics and no ballots in
+	//     the survivor loop (a lane with all slots full verifies in place: adversarial input);
+	//  2. compact: at a tile end, once enough lanes hold one, the parked codes are packed
+	//     into the wave's ring with ballot + mbcnt;
+	//  3. verify: the exact reference rule, 64 ring entries at a time (full wave, and the
+	//     compiler merges the 64 hit-counter atomics into one).
+	uint32_t n_parked = 0;
+	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
+	auto park = [&](uint32_t it, uint32_t p, uint32_t stream, uint64_t word) {
+		if (n_parked < LANE_SLOTS) {
+			lds_st(slot_off + 4u * n_parked, (it << 12) | (lane << 6) | p);
+			n_parked++;
+		} else {
+			verify_lap_any(a, stream, word, p);
+		}
+	};
+	// `it` -> tile needs a division, but only here on the rare path
 	auto drain = [&](uint32_t n) {
 		if (lane < n) {
-			uint32_t code = ring[(q_head + lane) & (QRING - 1)];
-			uint32_t it = code >> 12;
-			uint32_t src_lane = (code >> 6) & 63;
-			uint32_t p = code & 63;
-			uint64_t tile = blockIdx.x + (uint64_t)it * gridDim.x;
-			uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
-			uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + src_lane;
-			verify_lap_any(a, stream, word, p);
+			const uint32_t code = lds_ld(ring_off + 4u * ((q_head + lane) & (QRING - 1)));
+			const uint64_t tile = blockIdx.x + (uint64_t)(code >> 12) * gridDim.x;
+			const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
+			const uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+			verify_lap_any(a, stream, word, code & 63);
 		}
 		q_head += n;
 	};
+	auto compact = [&](bool final) {
+		for (uint32_t k = 0; k < LANE_SLOTS; k++) {
+			const uint64_t have = __ballot(n_parked > k);
+			if (!have)
+				break;
+			if (n_parked > k) {
+				const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32),
+						__builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
+				lds_st(ring_off + 4u * (slot & (QRING - 1)), lds_ld(slot_off + 4u * k));
+			}
+			q_tail += __popcll(have);
+			while (q_tail - q_head >= 64)       // keeps the ring below 128 entries
+				drain(64);
+		}
+		n_parked = 0;
+		if (final && q_tail != q_head)
+			drain(q_tail - q_head);
+	};
 
-	uint32_t it = 0;
-	for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
-		const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
-		const uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + tid;
-		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
-		const uint64_t lo = load_word(base, word, a.n_words);
-		const uint64_t hi = load_word(base, word + 1, a.n_words);
+	Cursor cur = {0, blockIdx.x};
+	while (cur.t >= a.tiles_per_stream && cur.stream < a.n_streams) {
+		cur.t -= a.tiles_per_stream;
+		cur.stream++;
+	}
+	uint64_t lo = 0, hi = 0;
+	if (cur.stream < a.n_streams) {
+		const uint64_t *base = a.words + (uint64_t)cur.stream * a.pitch_words;
+		lo = load_word(base, cur.t * SCAN_THREADS + tid, a.n_words);
+		hi = load_word(base, cur.t * SCAN_THREADS + tid + 1, a.n_words);
+	}
+	for (uint32_t it = 0; cur.stream < a.n_streams; ++it) {
+		const uint32_t stream = cur.stream;
+		const uint64_t word = cur.t * SCAN_THREADS + tid;
+		// software prefetch of the next tile: the loads fly while this tile is processed
+		advance(cur);
+		uint64_t nlo = 0, nhi = 0;
+		if (cur.stream < a.n_streams) {
+			const uint64_t *nb = a.words + (uint64_t)cur.stream * a.pitch_words;
+			nlo = load_word(nb, cur.t * SCAN_THREADS + tid, a.n_words);
+			nhi = load_word(nb, cur.t * SCAN_THREADS + tid + 1, a.n_words);
+		}
 		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
 		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
 
 		// offsets of this word that lie inside [0, search_bits)
-		uint64_t first_off = word * 64;
-		uint64_t valid = first_off >= a.search_bits ? 0ULL
+		const uint64_t first_off = word * 64;
+		const uint64_t valid = first_off >= a.search_bits ? 0ULL
 			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 
-		uint32_t passA, clsA, passB, clsB;
-		barker32(d1, d2, passA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
-		barker32(d2, d3, passB, clsB);       // offsets 32..63
-		passA &= (uint32_t)valid;
-		passB &= (uint32_t)(valid >> 32);
+		uint32_t mA, clsA, mB, clsB;
+		barker32(d1, d2, mA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
+		barker32(d2, d3, mB, clsB);       // offsets 32..63
+		mA &= (uint32_t)valid;
+		mB &= (uint32_t)(valid >> 32);
 
-#pragma unroll
-		for (int half = 0; half < 2; half++) {
-			uint32_t m = half ? passB : passA;
-			const uint32_t cls = half ? clsB : clsA;
-			const uint32_t e0 = half ? d1 : d0, e1 = half ? d2 : d1, e2 = half ? d3 : d2;
-			// The loop is kept WAVE-UNIFORM (runs while any lane has survivors) so that the
-			// ring cursors stay uniform; lanes without work are masked only around the
-			// table look-ups.
-			while (__ballot(m != 0)) {
-				uint32_t bit = 0, p = 0;
-				if (m) {
-					p = __builtin_ctz(m);
-					m &= m - 1;
-					const uint32_t wlo = alignbit(e1, e0, p);
-					const uint32_t whi = alignbit(e2, e1, p);
-					const uint32_t c = (cls >> p) & 1;
-					const uint32_t ia = whi & ((1u << TABA_BITS) - 1);
-					const uint32_t ib = ((whi >> TABA_BITS) & ((1u << TABB_BITS) - 1)) | (c << TABB_BITS);
-					const uint32_t proj = wlo ^ ldsA[ia] ^ ldsB[ib];
-					bit = (ldsM[(proj >> 5) & (LDS_BITMAP_WORDS - 1)] >> (proj & 31)) & 1;
-				}
-				const uint64_t cand = __ballot(bit);
-				if (cand) {
-					const uint32_t n = __popcll(cand);
-					if (q_tail - q_head + n > QRING) {
-						// ring full (adversarial input): verify in place, no queueing
-						if (bit)
-							verify_lap_any(a, stream, word, p + 32 * half);
-					} else {
-						if (bit) {
-							uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(cand >> 32),
-									__builtin_amdgcn_mbcnt_lo((uint32_t)cand, 0));
-							ring[slot & (QRING - 1)] = (it << 12) | (lane << 6) | (p + 32 * half);
-						}
-						q_tail += n;
-					}
-				}
+		if (VARIANT == 1) {      // ablation: pre-filter only
+			if (__popc(mA) + __popc(mB) == 33)
+				park(it, 0, stream, word);
+			mA = mB = 0;
+		}
+		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
+		// survivor of the low half AND one of the high half (two independent LDS chains).
+		while (__ballot((mA | mB) != 0)) {
+			const uint32_t pA = lowest_bit(mA), pB = lowest_bit(mB);
+			const uint32_t bitA = probe<VARIANT>(d0, d1, d2, clsA, kdiff, pA, mA ? 1u : 0u);
+			const uint32_t bitB = probe<VARIANT>(d1, d2, d3, clsB, kdiff, pB, mB ? 1u : 0u);
+			mA &= mA - 1;
+			mB &= mB - 1;
+			if (bitA | bitB) {
+				if (bitA) park(it, pA & 31, stream, word);
+				if (bitB) park(it, (pB & 31) + 32, stream, word);
 			}
 		}
-		// wave-uniform: verify in full-wave batches
-		while (q_tail - q_head >= 64)
-			drain(64);
+		// wave-uniform: compact (and verify) once enough lanes hold a candidate
+		if (__popcll(__ballot(n_parked != 0)) >= 24 || __ballot(n_parked >= LANE_SLOTS - 1))
+			compact(false);
+		lo = nlo;
+		hi = nhi;
 	}
-	if (q_tail != q_head)
-		drain(q_tail - q_head);
+	compact(true);
 }
 
 // ---- known LAP --------------------------------------------------------------------------
@@ -449,11 +546,26 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		}
 		static bool attr_set = false;
 		if (!attr_set) {
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel),
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<0>),
 						    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES));
 			attr_set = true;
 		}
-		hipLaunchKernelGGL(scan_lap_any_kernel, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a);
+		static int variant = -1;
+		if (variant < 0) {
+			const char *v = getenv("BTBBX_SCAN_VARIANT");      // ablation switch for profiling only
+			variant = v ? atoi(v) : 0;
+		}
+#define LAUNCH_VARIANT(V) do { \
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
+					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
+		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
+		switch (variant) {
+		case 1: LAUNCH_VARIANT(1); break;
+		case 2: LAUNCH_VARIANT(2); break;
+		case 3: LAUNCH_VARIANT(3); break;
+		case 4: LAUNCH_VARIANT(4); break;
+		default: LAUNCH_VARIANT(0); break;
+		}
 	} else {
 		a.syncword = host_gen_syncword(lap & 0xffffff);
 		a.lap = lap;

@@ -1,0 +1,102 @@
+// tools/valu_rate.hip -- micro-benchmark: issue rate of the integer VALU ops the scan kernel
+// is made of, on gfx950, at the scan kernel's occupancy (1024-thread workgroups, 1 per CU).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o gpurun_out/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#define ITERS 4096
+#define UNROLL 32
+
+#define KERNEL(name, body)                                                            \
+__global__ __launch_bounds__(1024) void name(uint32_t *out, uint32_t seed)             \
+{                                                                                      \
+	uint32_t a = threadIdx.x ^ seed, b = a * 3 + 1, c = a + 7, d = b ^ 0x55;            \
+	uint32_t e = a + 11, f = b + 13, g = c + 17, h = d + 19;                           \
+	for (int i = 0; i < ITERS; i++) {                                                  \
+		_Pragma("unroll") for (int u = 0; u < UNROLL / 8; u++) { body }                 \
+	}                                                                                  \
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;        \
+}
+
+// 8 independent chains per unroll step
+#define OP8(ins) asm volatile(ins " %0, %0, %8\n" ins " %1, %1, %8\n" ins " %2, %2, %8\n" ins " %3, %3, %8\n" \
+	ins " %4, %4, %8\n" ins " %5, %5, %8\n" ins " %6, %6, %8\n" ins " %7, %7, %8\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(seed));
+#define OP8_3(ins) asm volatile(ins " %0, %0, %1, %8\n" ins " %1, %1, %2, %8\n" ins " %2, %2, %3, %8\n" ins " %3, %3, %4, %8\n" \
+	ins " %4, %4, %5, %8\n" ins " %5, %5, %6, %8\n" ins " %6, %6, %7, %8\n" ins " %7, %7, %0, %8\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(seed));
+#define OP8_1(ins) asm volatile(ins " %0, %0\n" ins " %1, %1\n" ins " %2, %2\n" ins " %3, %3\n" \
+	ins " %4, %4\n" ins " %5, %5\n" ins " %6, %6\n" ins " %7, %7\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+
+KERNEL(k_and, OP8("v_and_b32"))
+KERNEL(k_xor, OP8("v_xor_b32"))
+KERNEL(k_add, OP8("v_add_u32"))
+KERNEL(k_lshr, OP8("v_lshrrev_b32"))
+KERNEL(k_alignbit, OP8_3("v_alignbit_b32"))
+KERNEL(k_bfe, OP8_3("v_bfe_u32"))
+KERNEL(k_lshl_add, OP8_3("v_lshl_add_u32"))
+KERNEL(k_and_or, OP8_3("v_and_or_b32"))
+KERNEL(k_ffbl, OP8_1("v_ffbl_b32"))
+KERNEL(k_bcnt, OP8("v_bcnt_u32_b32"))
+KERNEL(k_mul_lo, OP8_3("v_mad_u32_u24"))
+KERNEL(k_fma, OP8_3("v_fma_f32"))
+__global__ __launch_bounds__(1024) void k_bitop3(uint32_t *out, uint32_t seed)
+{
+	uint32_t a = threadIdx.x ^ seed, b = a * 3 + 1, c = a + 7, d = b ^ 0x55;
+	uint32_t e = a + 11, f = b + 13, g = c + 17, h = d + 19;
+	for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+		for (int u = 0; u < UNROLL / 8; u++) {
+			asm volatile("v_bitop3_b32 %0, %0, %1, %8 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %8 bitop3:0x96\n"
+				     "v_bitop3_b32 %2, %2, %3, %8 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %8 bitop3:0x96\n"
+				     "v_bitop3_b32 %4, %4, %5, %8 bitop3:0x96\n v_bitop3_b32 %5, %5, %6, %8 bitop3:0x96\n"
+				     "v_bitop3_b32 %6, %6, %7, %8 bitop3:0x96\n v_bitop3_b32 %7, %7, %0, %8 bitop3:0x96\n"
+				     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(seed));
+		}
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
+}
+
+template <typename K>
+static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	int threads = 256 * waves_per_simd;
+	hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, d_out, 1u);
+	hipEventRecord(e0);
+	hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, d_out, 2u);
+	hipEventRecord(e1);
+	hipEventSynchronize(e1);
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	double wave_instrs_per_simd = (double)ITERS * UNROLL * waves_per_simd;      // each SIMD hosts waves_per_simd waves
+	double cycles = ms * 1e-3 * 2.4e9;
+	printf("%-14s waves/SIMD=%d  %.3f ms  %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n",
+	       name, waves_per_simd, ms, cycles / wave_instrs_per_simd);
+}
+
+int main()
+{
+	uint32_t *d_out;
+	hipMalloc(&d_out, 256 * 1024 * 4);
+	for (int w = 1; w <= 4; w *= 2) {
+		run("v_and_b32", k_and, d_out, w);
+		run("v_xor_b32", k_xor, d_out, w);
+		run("v_add_u32", k_add, d_out, w);
+		run("v_lshrrev_b32", k_lshr, d_out, w);
+		run("v_alignbit_b32", k_alignbit, d_out, w);
+		run("v_bfe_u32", k_bfe, d_out, w);
+		run("v_lshl_add_u32", k_lshl_add, d_out, w);
+		run("v_and_or_b32", k_and_or, d_out, w);
+		run("v_bitop3_b32", k_bitop3, d_out, w);
+		run("v_ffbl_b32", k_ffbl, d_out, w);
+		run("v_bcnt_u32_b32", k_bcnt, d_out, w);
+		run("v_mad_u32_u24", k_mul_lo, d_out, w);
+		run("v_fma_f32", k_fma, d_out, w);
+	}
+	return 0;
+}
