@@ -394,17 +394,74 @@ __device__ __forceinline__ uint32_t top8_filter(uint32_t dm, uint32_t dh, uint32
 	return ~gt;
 }
 
+// Known-LAP hits are staged in a per-wave LDS ring and flushed 64 at a time: one global
+// counter atomic per 64 hits (a single counter word saturates near 88 M atomics/s on this
+// chip, which a dense hit stream would otherwise run into).
+#define KRING 128
+struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per staged hit
+
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
+	__shared__ KnownHit ring_mem[4][KRING];
 	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	KnownHit *ring = ring_mem[tid >> 6];
 	const uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
 	const uint32_t ac_top8 = ac_hi >> 24;
 	const int limit = a.max_err < 0 ? -1 : a.max_err;
 	if (limit < 0)
 		return;
-	for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-		const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
-		const uint64_t word = (tile % a.tiles_per_stream) * 256 + tid;
+	uint32_t q_head = 0, q_tail = 0;                // wave-uniform, free running
+
+	auto flush = [&](uint32_t n) {                  // n <= 64 oldest entries -> global hit list
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(a.hit_count, n);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (lane < n) {
+			const KnownHit k = ring[(q_head + lane) & (KRING - 1)];
+			const uint32_t idx = base + lane;
+			if (idx < a.hit_cap) {
+				btbbx_hit h;
+				h.offset = ((uint64_t)k.off_hi << 32) | k.off_lo;
+				h.lap = a.lap;
+				h.ac_errors = (uint8_t)(k.stream_err & 0xff);
+				h.reserved = 0;
+				h.stream = (uint16_t)(k.stream_err >> 8);
+				a.hits[idx] = h;
+			}
+		}
+		q_head += n;
+	};
+	auto stage = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t nerr) {
+		const uint64_t mask = __ballot(hit);
+		if (!mask)
+			return;
+		if (a.first) {                              // first-match mode: atomicMin, hits are sparse
+			if (hit)
+				emit_hit(a, stream, offset, a.lap, nerr);
+			return;
+		}
+		if (q_tail - q_head + 64 > KRING)
+			flush(64);
+		if (hit) {
+			const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+					__builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+			KnownHit k = { (uint32_t)offset, (uint32_t)(offset >> 32), (stream << 8) | nerr };
+			ring[slot & (KRING - 1)] = k;
+		}
+		q_tail += (uint32_t)__popcll(mask);
+	};
+
+	// division-free (stream, tile) cursor, as in the LAP_ANY kernel
+	uint32_t stream = 0;
+	uint64_t t = blockIdx.x;
+	while (t >= a.tiles_per_stream && stream < a.n_streams) {
+		t -= a.tiles_per_stream;
+		stream++;
+	}
+	while (stream < a.n_streams) {
+		const uint64_t word = t * 256 + tid;
 		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
 		const uint64_t lo = load_word(base, word, a.n_words);
 		const uint64_t hi = load_word(base, word + 1, a.n_words);
@@ -413,23 +470,31 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		uint64_t first_off = word * 64;
 		uint64_t valid = first_off >= a.search_bits ? 0ULL
 			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-		uint32_t passA = top8_filter(d1, d2, ac_top8, limit) & (uint32_t)valid;
-		uint32_t passB = top8_filter(d2, d3, ac_top8, limit) & (uint32_t)(valid >> 32);
-#pragma unroll
-		for (int half = 0; half < 2; half++) {
-			uint32_t m = half ? passB : passA;
-			const uint32_t e0 = half ? d1 : d0, e1 = half ? d2 : d1, e2 = half ? d3 : d2;
-			while (m) {
-				const uint32_t p = __builtin_ctz(m);
-				m &= m - 1;
-				const uint32_t wlo = alignbit(e1, e0, p);
-				const uint32_t whi = alignbit(e2, e1, p);
-				const int nerr = __popc(wlo ^ ac_lo) + __popc(whi ^ ac_hi);     // :433
-				if (nerr <= limit)
-					emit_hit(a, stream, word * 64 + p + 32 * half, a.lap, (uint32_t)nerr);
+		uint32_t mA = top8_filter(d1, d2, ac_top8, limit) & (uint32_t)valid;
+		uint32_t mB = top8_filter(d2, d3, ac_top8, limit) & (uint32_t)(valid >> 32);
+		// wave-uniform survivor loop, one offset of each half per pass
+		while (__ballot((mA | mB) != 0)) {
+			const uint32_t pA = __builtin_ctz(mA | 0x80000000u), pB = __builtin_ctz(mB | 0x80000000u);
+			const int eA = __popc(alignbit(d1, d0, pA) ^ ac_lo) + __popc(alignbit(d2, d1, pA) ^ ac_hi);   // :433
+			const int eB = __popc(alignbit(d2, d1, pB) ^ ac_lo) + __popc(alignbit(d3, d2, pB) ^ ac_hi);
+			const bool hitA = mA != 0 && eA <= limit, hitB = mB != 0 && eB <= limit;
+			if (__ballot(hitA || hitB)) {
+				stage(hitA, stream, word * 64 + pA, (uint32_t)eA);
+				stage(hitB, stream, word * 64 + 32 + pB, (uint32_t)eB);
 			}
+			mA &= mA - 1;
+			mB &= mB - 1;
+		}
+		while (q_tail - q_head >= 64)
+			flush(64);
+		t += gridDim.x;
+		while (t >= a.tiles_per_stream) {
+			t -= a.tiles_per_stream;
+			stream++;
 		}
 	}
+	if (q_tail != q_head)
+		flush(q_tail - q_head);
 }
 
 // ---- symbol <-> packed conversion ---------------------------------------------------------

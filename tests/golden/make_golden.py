@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures of tests/golden/ from the UNMODIFIED reference.
+
+Runs only where /root/reference exists (the build container): it compiles the reference into
+oracle/_ref/libbtbb_ref.so (oracle/Makefile) and records, for seeded synthetic inputs built by
+libbtbb_amd/synth.py, what the reference computes.  The fixtures hold DATA only (inputs are
+re-generated from seeds or stored as packed symbol words; outputs are numbers), no reference
+source text.  Re-run:  python tests/golden/make_golden.py
+
+  scan_hits.json   -- all-matches hit lists (offset, LAP, ac_errors) of btbb_find_ac for
+                      LAP_ANY and a known LAP, max_ac_errors 0..3, after btbb_init(2)
+  packets.npz      -- 160 synthetic packets (every type, symbol errors, junk with valid
+                      FEC-1/3 headers): per packet the 64-clock table {try_clock, type,
+                      crc_check} and btbb_header_present / btbb_decode_header /
+                      btbb_decode_payload results for the true clock
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(HERE)
+sys.path.insert(0, TESTS)
+sys.path.insert(0, os.path.dirname(TESTS))
+
+import _libs  # noqa: E402
+import _pkt  # noqa: E402
+from libbtbb_amd import synth  # noqa: E402
+
+SCAN_CASES = [
+    dict(name="lap_any_s4096", seed=0x9E3779B97F4A7C15, nwords=1 << 14, stride=4096, lap=None),
+    dict(name="lap_any_s512", seed=12345, nwords=1 << 12, stride=512, lap=None),
+    dict(name="known_9e8b33", seed=777, nwords=1 << 13, stride=1024, lap=0x9E8B33),
+]
+
+
+def main():
+    ref = _libs.ref()
+    assert ref is not None, "needs /root/reference (run in the build container)"
+    ref.btbb_init(2)
+
+    scan = {"_generator": "tests/golden/make_golden.py", "init_max_ac_errors": 2, "cases": []}
+    for case in SCAN_CASES:
+        words, _ = synth.make_stream(case["seed"], case["nwords"], stride=case["stride"], lap=case["lap"])
+        sym = np.ascontiguousarray(synth.unpack_bits(words))
+        n = len(sym) - 63
+        lap = _libs.LAP_ANY if case["lap"] is None else case["lap"]
+        out = dict(case)
+        out["search_bits"] = int(n)
+        out["hits"] = {}
+        for me in (0, 1, 2, 3):
+            hits = _libs.ref_find_all_native(sym, n, lap, me)
+            out["hits"][str(me)] = [list(h) for h in hits]
+        scan["cases"].append(out)
+    json.dump(scan, open(os.path.join(HERE, "scan_hits.json"), "w"), separators=(",", ":"))
+
+    rng = np.random.default_rng(20260926)
+    pk = _pkt.random_packets(rng, 160, max_sym_errors=2)
+    n = len(pk)
+    words = np.zeros((n, 50), np.uint64)
+    lengths = np.zeros(n, np.uint32)
+    meta = np.zeros((n, 4), np.int64)                 # lap, uap, clk6, type(-1 junk)
+    trials = np.zeros((n, 64, 3), np.int32)           # try_clock ret, type after, crc_check
+    dec = np.zeros((n, 10), np.int64)                 # present, hdr_rv, pay_rv, type, lt, flags, hec, plen, phl, hdr18
+    payload = np.zeros((n, 2744), np.uint8)
+    pflags = np.zeros(n, np.uint32)
+    view0 = None
+    for i, (sym, m) in enumerate(pk):
+        sym = np.ascontiguousarray(sym[:3125])
+        w = synth.pack_bits(sym)
+        words[i, :len(w)] = w
+        lengths[i] = len(sym)
+        meta[i] = (m["lap"], m["uap"], m["clk6"], m["type"])
+        # 64 trials on ONE packet object, in clock order, like btbb_uap_from_header
+        p = C.c_void_p(ref.btbb_packet_new())
+        ref.btbb_packet_set_flag(p, 0, 1)
+        ref.btbb_packet_set_data(p, _libs.ptr(sym), len(sym), 0, 0)
+        view = _libs.RefPacketView(ref, p.value)
+        for clock in range(64):
+            u = ref.try_clock(clock, p)
+            rv = ref.crc_check(clock, p)
+            trials[i, clock] = (u, int(view.field("packet_type", "u1")), rv)
+        ref.btbb_packet_unref(p)
+        # decode with the true clock and UAP
+        p = C.c_void_p(ref.btbb_packet_new())
+        ref.btbb_packet_set_flag(p, 0, 1)
+        ref.btbb_packet_set_data(p, _libs.ptr(sym), len(sym), 0, m["clk6"] << 1)
+        ref.btbb_packet_set_uap(p, m["uap"])
+        ref.btbb_packet_set_flag(p, 4, 1)
+        present = ref.btbb_header_present(p)
+        h = ref.btbb_decode_header(p)
+        r = ref.btbb_decode_payload(p) if h else 0
+        st = _pkt.ref_state(ref, p)
+        dec[i] = (present, h, r, st["packet_type"], st["packet_lt_addr"], st["packet_flags"], st["packet_hec"],
+                  st["payload_length"], st["payload_header_length"],
+                  int(sum(int(b) << k for k, b in enumerate(st["packet_header"]))))
+        payload[i] = st["payload"]
+        pflags[i] = st["flags"]
+        ref.btbb_packet_unref(p)
+    np.savez_compressed(os.path.join(HERE, "packets.npz"), words=words, lengths=lengths, meta=meta,
+                        trials=trials, decode=dec, payload=np.packbits(payload, axis=1, bitorder="little"),
+                        flags=pflags)
+    print("wrote scan_hits.json (%d cases) and packets.npz (%d packets)" % (len(scan["cases"]), n))
+
+
+if __name__ == "__main__":
+    main()

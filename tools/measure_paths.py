@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Secondary measurements quoted in DESIGN.md (run on the MI355X box):
+  * PCIe-inclusive scan rates (host packed words / host symbols -> hits on the host)
+  * latency of one small drop-in btbb_find_ac call
+  * known-LAP scan rate on the resident 4 GiB stream
+  * config 3: 79 channels, find -> gather -> header/payload decode, known LAP
+  * config 5: 64-clock trial tables for a stream of detected packets
+Prints one JSON object."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import libbtbb_amd as bt
+from libbtbb_amd import synth
+
+
+def ev_time(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def main():
+    out = {}
+    bt.init(2)
+    lib = bt.lib()
+    hs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- PCIe inclusive: 1 GiB of packed words / 1 Gi symbols from pageable host memory
+    nw = 1 << 27
+    d = torch.empty(nw, dtype=torch.int64, device="cuda")
+    bt.check(lib.btbbx_synth_device(d.data_ptr(), 0, nw, 5, 4096, -1, 4, hs))
+    host_words = d.cpu().numpy().view(np.uint64)
+    hits = np.zeros(1 << 22, bt.HIT_DTYPE)
+    lib.btbbx_scan_host(host_words.ctypes.data, nw, nw * 64 - 63, bt.LAP_ANY, 2, hits.ctypes.data, len(hits))   # warm-up (scratch alloc)
+    t0 = time.perf_counter()
+    n = lib.btbbx_scan_host(host_words.ctypes.data, nw, nw * 64 - 63, bt.LAP_ANY, 2, hits.ctypes.data, len(hits))
+    dt = time.perf_counter() - t0
+    out["scan_host_words"] = {"GiB": 1, "seconds": round(dt, 4), "Gbit_s": round(nw * 64 / dt / 1e9, 1), "hits": int(n)}
+    ns = 1 << 30
+    sym = np.ascontiguousarray(synth.unpack_bits(host_words[: ns // 64]))
+    lib.btbbx_scan_symbols(sym.ctypes.data, ns, ns - 63, bt.LAP_ANY, 2, hits.ctypes.data, len(hits))          # warm-up
+    t0 = time.perf_counter()
+    n2 = lib.btbbx_scan_symbols(sym.ctypes.data, ns, ns - 63, bt.LAP_ANY, 2, hits.ctypes.data, len(hits))
+    dt = time.perf_counter() - t0
+    out["scan_host_symbols"] = {"symbols": ns, "seconds": round(dt, 4), "Gbit_s": round(ns / dt / 1e9, 2), "hits": int(n2)}
+
+    # ---- drop-in btbb_find_ac latency on a 64 Ki-symbol window
+    small = np.ascontiguousarray(sym[: 65536 + 72])
+    pkt = C.c_void_p(None)
+    lib.btbb_find_ac(small.ctypes.data, 65536, bt.LAP_ANY, 2, C.byref(pkt))
+    t0 = time.perf_counter()
+    for _ in range(50):
+        lib.btbb_find_ac(small.ctypes.data, 65536, bt.LAP_ANY, 2, C.byref(pkt))
+    out["find_ac_call_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+
+    # ---- known-LAP scan of a resident 4 GiB stream
+    nw4 = 1 << 29
+    d4 = torch.empty(nw4, dtype=torch.int64, device="cuda")
+    bt.check(lib.btbbx_synth_device(d4.data_ptr(), 0, nw4, 6, 4096, 0x9E8B33, 4, hs))
+    cap = 1 << 24
+    hits_t = torch.empty(cap * 2, dtype=torch.int64, device="cuda")
+    cnt_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def known():
+        cnt_t.zero_()
+        bt.check(lib.btbbx_scan_device(d4.data_ptr(), nw4, nw4, 1, nw4 * 64 - 63, 0x9E8B33, 2,
+                                       hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
+    t = ev_time(known)
+    out["known_lap_4GiB"] = {"ms": round(t * 1e3, 3), "Gbit_s": round(nw4 * 64 / t / 1e9, 1), "hits": int(cnt_t.item())}
+    del d4
+
+    # ---- config 3: 79 channels x 2^21 words, DM1/DH1/DM3/FHS packets every 4096 symbols, known LAP
+    rng = np.random.default_rng(3)
+    lap, uap = 0x9E8B33, 0x47
+    nch, wpc = 79, 1 << 14
+    stream = synth.noise_words(99, 0, nch * wpc).reshape(nch, wpc)
+    truth = []
+    types = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_FHS]
+    for ch in range(nch):
+        symc = synth.unpack_bits(stream[ch])
+        for k in range(wpc * 64 // 4096 - 1):
+            clk6 = int(rng.integers(0, 64))
+            t_ = types[k % 4]
+            body = rng.integers(0, 256, int(rng.integers(1, 17)), dtype=np.uint8).tobytes()
+            p = synth.build_packet(lap, uap, clk6, t_, lt_addr=1 + k % 7, flags=k % 8, body=body,
+                                   fhs_bits=synth.fhs_payload(lap, uap, 0x1234, k, rng))
+            pos = k * 4096 + 100 + int(rng.integers(0, 64))
+            symc[pos:pos + len(p)] = p
+            truth.append((ch, pos, clk6, t_))
+        stream[ch] = synth.pack_bits(symc)
+    d3 = torch.from_numpy(stream.view(np.int64).reshape(-1)).cuda()
+    cap3 = 1 << 17
+    h3 = torch.zeros(cap3 * 2, dtype=torch.int64, device="cuda")
+    c3 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pk3 = torch.zeros(cap3 * 50, dtype=torch.int64, device="cuda")
+    ln3 = torch.zeros(cap3, dtype=torch.int32, device="cuda")
+    clk_of = {(ch, pos): (clk6, t_) for ch, pos, clk6, t_ in truth}
+
+    bt.check(lib.btbbx_scan_device(d3.data_ptr(), wpc, wpc, nch, wpc * 64 - 63, lap, 2, h3.data_ptr(), cap3, c3.data_ptr(), hs))
+    torch.cuda.synchronize()
+    n3 = int(c3.item())
+    hh = h3.cpu().numpy().view(bt.HIT_DTYPE)[:n3].copy()
+    lib.btbbx_sort_hits(hh.ctypes.data, n3)             # the device list is unordered
+    h3[: n3 * 2].copy_(torch.from_numpy(hh.view(np.int64)).cuda())
+    pin = np.zeros(n3, bt.PKTIN_DTYPE)
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    pin["uap"] = uap
+    for i, h in enumerate(hh):
+        pin["clkn"][i] = clk_of.get((int(h["stream"]), int(h["offset"])), (0, 0))[0]
+    d_in = torch.from_numpy(pin.view(np.uint8)).cuda()
+    d_out = torch.zeros(n3 * bt.PKTOUT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+
+    h3b = torch.zeros(cap3 * 2, dtype=torch.int64, device="cuda")
+
+    def scan_only():
+        c3.zero_()
+        bt.check(lib.btbbx_scan_device(d3.data_ptr(), wpc, wpc, nch, wpc * 64 - 63, lap, 2, h3b.data_ptr(), cap3, c3.data_ptr(), hs))
+    t_scan_only = ev_time(scan_only)
+
+    def chain():
+        bt.check(lib.btbbx_gather_packets_device(d3.data_ptr(), wpc, wpc, h3.data_ptr(), n3, 3125, pk3.data_ptr(), ln3.data_ptr(), hs))
+    t_scan = ev_time(chain)
+    # lengths -> pkt_in (device side copy of the gathered lengths)
+    lens = ln3.cpu().numpy()[:n3]
+    pin["length"] = lens
+    d_in.copy_(torch.from_numpy(pin.view(np.uint8)))
+
+    def dec():
+        bt.check(lib.btbbx_decode_device(pk3.data_ptr(), d_in.data_ptr(), n3, d_out.data_ptr(), hs))
+    t_dec = ev_time(dec)
+    res = d_out.cpu().numpy().view(bt.PKTOUT_DTYPE)
+    good = int(((res["payload_rv"] == 10) | (res["payload_rv"] == 1000)).sum())
+    out["config3_79ch"] = {"symbols": nch * wpc * 64, "packets_found": n3, "injected": len(truth), "crc_ok": good,
+                           "scan_ms": round(t_scan_only * 1e3, 3), "gather_ms": round(t_scan * 1e3, 3), "decode_ms": round(t_dec * 1e3, 3),
+                           "decode_packets_per_s": round(n3 / t_dec)}
+
+    # ---- config 5: 64-clock tables for the same detected packets, replicated to ~2^17 packets
+    reps = max(1, (1 << 17) // max(n3, 1))
+    npk = n3 * reps
+    pk5 = pk3[: n3 * 50].repeat(reps)
+    in5 = torch.from_numpy(np.tile(pin, reps).view(np.uint8)).cuda()
+    tr5 = torch.zeros(npk * 64, dtype=torch.int32, device="cuda")
+
+    def trials():
+        bt.check(lib.btbbx_trials_device(pk5.data_ptr(), in5.data_ptr(), npk, tr5.data_ptr(), hs))
+    t_tr = ev_time(trials, reps=3)
+    out["config5_trials"] = {"packets": npk, "ms": round(t_tr * 1e3, 3), "packets_per_s": round(npk / t_tr),
+                             "trials_per_s": round(npk * 64 / t_tr)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
