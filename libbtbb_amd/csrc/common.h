@@ -24,19 +24,19 @@
 #define TABB_BITS      12                  // window bits 45..56
 #define BITMAP_BITS    19                  // projection width of the candidate bitmap
 #define QRING          256                 // per-wave candidate ring (entries)
+#define PARK_SLOTS     4                   // private candidate slots per lane
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
 // probe needs no address adds.
 #define LDS_TABB_WORDS   (1u << TABB_BITS)            // 4096 u32  = 16 KiB
 #define LDS_TABA_WORDS   (1u << TABA_BITS)            // 8192 u32  = 32 KiB
 #define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 16384 u32 = 64 KiB
-#define LDS_QUEUE_WORDS  (SCAN_WAVES * QRING)         // 4096 u32  = 16 KiB
 #define LDS_OFF_TABB     0u
 #define LDS_OFF_TABA     (LDS_OFF_TABB + 4u * LDS_TABB_WORDS)
 #define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
-#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)
-#define LDS_OFF_PARK     (LDS_OFF_QUEUE + 4u * LDS_QUEUE_WORDS)          // 64 lanes x 4 slots per wave
-#define SCAN_LDS_BYTES   (LDS_OFF_PARK + 4u * SCAN_WAVES * 64u * 4u)
+#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING u32
+#define LDS_OFF_PARK     (LDS_OFF_QUEUE + 4u * SCAN_WAVES * QRING)            // 16 x 64 x PARK_SLOTS u32
+#define SCAN_LDS_BYTES   (LDS_OFF_PARK + 4u * SCAN_WAVES * 64u * PARK_SLOTS)
 
 // ---- device-side table bundle -----------------------------------------------------
 struct ScanTables {

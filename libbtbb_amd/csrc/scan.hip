@@ -60,30 +60,6 @@ __device__ __forceinline__ void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t
 	carry = (a & b) | (c & (a ^ b));
 }
 
-// Barker pre-filter for the 32 offsets whose window starts in the dword before `dm`:
-// bit k of the 7-bit window at offset p is stream bit p + 57 + k = bit (p + 25 + k) of dh:dm.
-__device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t &pass, uint32_t &cls)
-{
-	// mismatch planes against BARKER1 = 0b0100111 (bit k set for k = 0,1,2,5)
-	uint32_t m0 = ~alignbit(dh, dm, 25);
-	uint32_t m1 = ~alignbit(dh, dm, 26);
-	uint32_t m2 = ~alignbit(dh, dm, 27);
-	uint32_t m3 = alignbit(dh, dm, 28);
-	uint32_t m4 = alignbit(dh, dm, 29);
-	uint32_t m5 = ~alignbit(dh, dm, 30);
-	uint32_t m6 = alignbit(dh, dm, 31);
-	uint32_t a, ca, b, cb, ones, cc, twos, fours;
-	csa(m0, m1, m2, a, ca);
-	csa(m3, m4, m5, b, cb);
-	csa(a, b, m6, ones, cc);
-	csa(ca, cb, cc, twos, fours);
-	(void)ones;
-	uint32_t near1 = ~(twos | fours);     // 0 or 1 mismatches -> corrected to BARKER1
-	uint32_t near0 = twos & fours;        // 6 or 7 mismatches -> corrected to BARKER0
-	pass = near1 | near0;
-	cls = near1;
-}
-
 __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uint64_t offset,
 					 uint32_t lap, uint32_t nerr)
 {
@@ -158,14 +134,13 @@ __device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t strea
 // and table addresses are plain byte offsets: every DS access below is `base + offset:imm`
 // with the table base folded into the 16-bit immediate.
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off)
-{
-	return *reinterpret_cast<lds_u32_t *>(byte_off);
-}
-__device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v)
-{
-	*reinterpret_cast<lds_u32_t *>(byte_off) = v;
-}
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
+__device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
+__device__ __forceinline__ void lds_st16(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u16_t *>(byte_off) = (uint16_t)v; }
+__device__ __forceinline__ void lds_st64(uint32_t byte_off, uint64_t v) { *reinterpret_cast<lds_u64_t *>(byte_off) = v; }
 
 // index of the lowest set bit; 0xffffffff for 0 (v_ffbl_b32), which the callers use as
 // "offset 31 of a lane that has nothing left" -- its result is masked out afterwards
@@ -176,43 +151,61 @@ __device__ __forceinline__ uint32_t lowest_bit(uint32_t m)
 	return p;
 }
 
-// a ^ b ^ c in one instruction
-__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+// three-input boolean in one full-rate instruction (truth table index = a*4 + b*2 + c)
+#define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return BITOP3(a, b, c, 0x96); }
+
+// Barker pre-filter for the 32 offsets whose 7-bit window (LAP MSB + 6 barker bits,
+// bluetooth_packet.c:378-385) lives in dh:dm: bit k of the window at offset p is bit
+// (p + 25 + k) of dh:dm.  Counts mismatches against BARKER1 = 0b0100111 with a carry-save
+// adder of v_bitop3 full adders (inverted planes folded into the truth tables):
+//   count in {0,1} -> BARKER_DISTANCE <= 1, corrected to BARKER1 (class 1)
+//   count in {6,7} -> BARKER_DISTANCE <= 1, corrected to BARKER0 (class 0)
+__device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t valid, uint32_t &pass, uint32_t &cls)
 {
-	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+	const uint32_t s0 = alignbit(dh, dm, 25), s1 = alignbit(dh, dm, 26), s2 = alignbit(dh, dm, 27);
+	const uint32_t s3 = alignbit(dh, dm, 28), s4 = alignbit(dh, dm, 29), s5 = alignbit(dh, dm, 30);
+	const uint32_t s6 = alignbit(dh, dm, 31);
+	// mismatch planes: m0 = ~s0, m1 = ~s1, m2 = ~s2, m3 = s3, m4 = s4, m5 = ~s5, m6 = s6
+	const uint32_t a = BITOP3(s0, s1, s2, 0x69);       // m0 ^ m1 ^ m2
+	const uint32_t ca = BITOP3(s0, s1, s2, 0x17);      // maj(m0, m1, m2)
+	const uint32_t b = BITOP3(s3, s4, s5, 0x69);       // m3 ^ m4 ^ m5
+	const uint32_t cb = BITOP3(s3, s4, s5, 0xd4);      // maj(s3, s4, ~s5)
+	const uint32_t cc = BITOP3(a, b, s6, 0xe8);        // carry of the ones column
+	const uint32_t twos = BITOP3(ca, cb, cc, 0x96);
+	const uint32_t fours = BITOP3(ca, cb, cc, 0xe8);
+	pass = BITOP3(twos, fours, valid, 0x82);           // valid & ~(twos ^ fours)
+	cls = ~(twos | fours);
 }
 
-// One survivor (about 20 VALU, 3 DS): low 32 syndrome bits of the window at offset p of the
-// dword triple (e0,e1,e2)
+// One survivor costs about 19 VALU + 3 DS instructions:
 //   syndrome_low32 = w[31:0] ^ tabA[w[44:32]] ^ tabB[w[56:45]] ^ (class ? kdiff : 0)
-// then the candidate-bitmap probe with its low 19 bits.  `live` (0/1) masks the result.
+// for the window w at offset p of the dword triple (e0,e1,e2), then a probe of the candidate
+// bitmap with its low 19 bits.  The stages are separate functions so that the survivor loop
+// can issue the LDS reads of its two chains back to back, each under the exec mask of the
+// lanes that really have a survivor: the DS pipe (shared by the 16 waves of the CU) then
+// only pays bank conflicts for useful lanes.
 // Instruction choice follows tools/valu_rate.hip: two-operand logic/shift ops and v_bitop3
 // issue at full rate on gfx950, v_bfe/v_alignbit/v_lshl_add/v_and_or at half rate.
-template <int VARIANT>
-__device__ __forceinline__ uint32_t probe(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t cls,
-					  uint32_t kdiff, uint32_t p, uint32_t live)
+struct Probe { uint32_t x, offA, offB; };
+
+__device__ __forceinline__ Probe probe_addr(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t cls,
+					    uint32_t kdiff, uint32_t p)
 {
+	Probe r;
 	const uint32_t wlo = alignbit(e1, e0, p);
 	const uint32_t whi = alignbit(e2, e1, p);
-	const uint32_t offA = (whi << 2) & (((1u << TABA_BITS) - 1) << 2);
-	const uint32_t offB = (whi >> (TABA_BITS - 2)) & (((1u << TABB_BITS) - 1) << 2);
+	r.offA = (whi << 2) & (((1u << TABA_BITS) - 1) << 2);
+	r.offB = (whi >> (TABA_BITS - 2)) & (((1u << TABB_BITS) - 1) << 2);
 	const uint32_t cmask = (uint32_t)__builtin_amdgcn_sbfe(cls, p, 1);     // 0 or ~0
-	const uint32_t x = __builtin_amdgcn_bitop3_b32(cmask, kdiff, wlo, 0x6a); // wlo ^ (cmask & kdiff)
-	uint32_t proj;
-	if (VARIANT == 2)        // ablation: no LDS at all
-		proj = xor3(x, offA + 77u, offB + 99u);
-	else
-		proj = xor3(x, lds_ld(LDS_OFF_TABA + offA), lds_ld(LDS_OFF_TABB + offB));
-	if (VARIANT == 2 || VARIANT == 3)        // ablation: no bitmap probe
-		return (proj == 0x12345678u) & live;
-	const uint32_t word = lds_ld(LDS_OFF_BITMAP + ((proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2)));
-	const uint32_t bit = (word >> (proj & 31)) & live;
-	if (VARIANT == 4)        // ablation: full probe, no candidates
-		return bit & (proj == 0x12345678u);
-	return bit;
+	r.x = BITOP3(cmask, kdiff, wlo, 0x6a);                                 // wlo ^ (cmask & kdiff)
+	return r;
 }
 
-#define LANE_SLOTS 4      // private candidate slots per lane
+__device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
+{
+	return (proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2);
+}
 
 template <int VARIANT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
@@ -222,8 +215,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t wave = tid >> 6;
-	// candidate slots of this lane (LANE_SLOTS consecutive dwords) and the wave's ring
-	const uint32_t slot_off = LDS_OFF_PARK + 4u * (wave * 64 * LANE_SLOTS + lane * LANE_SLOTS);
+	const uint32_t slot_off = LDS_OFF_PARK + 4u * (wave * 64 * PARK_SLOTS + lane * PARK_SLOTS);
 	const uint32_t ring_off = LDS_OFF_QUEUE + 4u * wave * QRING;
 	const uint32_t kdiff = a.t.kdiff;
 
@@ -242,16 +234,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	}
 	__syncthreads();
 
-	// tile -> (stream, first word) without divisions: uniform counters stepped per tile
-	struct Cursor { uint32_t stream; uint64_t t; };
-	auto advance = [&](Cursor &c) {
-		c.t += gridDim.x;
-		while (c.t >= a.tiles_per_stream) {
-			c.t -= a.tiles_per_stream;
-			c.stream++;
-		}
-	};
-
 	// Candidate = passed the bitmap (0.3 % of survivors).  Three stages keep it cheap:
 	//  1. park: one DS write into a private slot of the lane -- no atomics and no ballots in
 	//     the survivor loop (a lane with all slots full verifies in place: adversarial input);
@@ -259,29 +241,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	//     into the wave's ring with ballot + mbcnt;
 	//  3. verify: the exact reference rule, 64 ring entries at a time (full wave, and the
 	//     compiler merges the 64 hit-counter atomics into one).
+	// code = (tile iteration << 12) | (lane that owns the word << 6) | offset in the word
 	uint32_t n_parked = 0;
 	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
-	auto park = [&](uint32_t it, uint32_t p, uint32_t stream, uint64_t word) {
-		if (n_parked < LANE_SLOTS) {
-			lds_st(slot_off + 4u * n_parked, (it << 12) | (lane << 6) | p);
+	auto code_word = [&](uint32_t code, uint32_t &stream) {
+		// `it` -> tile needs a division, but only here on the rare path
+		const uint64_t tile = blockIdx.x + (uint64_t)(code >> 12) * gridDim.x;
+		stream = (uint32_t)(tile / a.tiles_per_stream);
+		return (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+	};
+	auto park = [&](uint32_t code) {
+		if (n_parked < PARK_SLOTS) {
+			lds_st(slot_off + 4u * n_parked, code);
 			n_parked++;
 		} else {
-			verify_lap_any(a, stream, word, p);
+			uint32_t stream;
+			const uint64_t word = code_word(code, stream);
+			verify_lap_any(a, stream, word, code & 63);
 		}
 	};
-	// `it` -> tile needs a division, but only here on the rare path
 	auto drain = [&](uint32_t n) {
 		if (lane < n) {
 			const uint32_t code = lds_ld(ring_off + 4u * ((q_head + lane) & (QRING - 1)));
-			const uint64_t tile = blockIdx.x + (uint64_t)(code >> 12) * gridDim.x;
-			const uint32_t stream = (uint32_t)(tile / a.tiles_per_stream);
-			const uint64_t word = (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+			uint32_t stream;
+			const uint64_t word = code_word(code, stream);
 			verify_lap_any(a, stream, word, code & 63);
 		}
 		q_head += n;
 	};
 	auto compact = [&](bool final) {
-		for (uint32_t k = 0; k < LANE_SLOTS; k++) {
+		for (uint32_t k = 0; k < PARK_SLOTS; k++) {
 			const uint64_t have = __ballot(n_parked > k);
 			if (!have)
 				break;
@@ -299,62 +288,103 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			drain(q_tail - q_head);
 	};
 
-	Cursor cur = {0, blockIdx.x};
-	while (cur.t >= a.tiles_per_stream && cur.stream < a.n_streams) {
-		cur.t -= a.tiles_per_stream;
-		cur.stream++;
+	// tile cursor without divisions: uniform (stream, tile-in-stream) stepped per tile
+	uint32_t stream = 0;
+	uint64_t t = blockIdx.x;
+	while (t >= a.tiles_per_stream && stream < a.n_streams) {
+		t -= a.tiles_per_stream;
+		stream++;
 	}
-	uint64_t lo = 0, hi = 0;
-	if (cur.stream < a.n_streams) {
-		const uint64_t *base = a.words + (uint64_t)cur.stream * a.pitch_words;
-		lo = load_word(base, cur.t * SCAN_THREADS + tid, a.n_words);
-		hi = load_word(base, cur.t * SCAN_THREADS + tid + 1, a.n_words);
-	}
-	for (uint32_t it = 0; cur.stream < a.n_streams; ++it) {
-		const uint32_t stream = cur.stream;
-		const uint64_t word = cur.t * SCAN_THREADS + tid;
-		// software prefetch of the next tile: the loads fly while this tile is processed
-		advance(cur);
-		uint64_t nlo = 0, nhi = 0;
-		if (cur.stream < a.n_streams) {
-			const uint64_t *nb = a.words + (uint64_t)cur.stream * a.pitch_words;
-			nlo = load_word(nb, cur.t * SCAN_THREADS + tid, a.n_words);
-			nhi = load_word(nb, cur.t * SCAN_THREADS + tid + 1, a.n_words);
+	// a tile whose 1024 words + halo word and 65536 offsets are all in range needs no masks
+	auto tile_full = [&](uint64_t tt) {
+		return (tt + 1) * SCAN_THREADS + 1 <= a.n_words && (tt + 1) * (SCAN_THREADS * 64ull) <= a.search_bits;
+	};
+	auto load_pair = [&](uint32_t s, uint64_t tt, uint64_t &lo, uint64_t &hi) {
+		const uint64_t *tp = a.words + (uint64_t)s * a.pitch_words + tt * SCAN_THREADS;   // uniform
+		if (tile_full(tt)) {
+			lo = tp[tid];
+			hi = tp[tid + 1];
+		} else {
+			const uint64_t w = tt * SCAN_THREADS + tid;
+			lo = w < a.n_words ? tp[tid] : 0;
+			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
 		}
+	};
+	uint64_t lo = 0, hi = 0;
+	if (stream < a.n_streams)
+		load_pair(stream, t, lo, hi);
+
+	for (uint32_t it = 0; stream < a.n_streams; ++it) {
+		const uint64_t cur_t = t;
+		// software prefetch of the next tile: the loads fly while this tile is processed
+		t += gridDim.x;
+		while (t >= a.tiles_per_stream) {
+			t -= a.tiles_per_stream;
+			stream++;
+		}
+		uint64_t nlo = 0, nhi = 0;
+		if (stream < a.n_streams)
+			load_pair(stream, t, nlo, nhi);
+
 		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
 		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
 
 		// offsets of this word that lie inside [0, search_bits)
-		const uint64_t first_off = word * 64;
-		const uint64_t valid = first_off >= a.search_bits ? 0ULL
-			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-
+		uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
+		if (!tile_full(cur_t)) {
+			const uint64_t first_off = (cur_t * SCAN_THREADS + tid) * 64;
+			const uint64_t valid = first_off >= a.search_bits ? 0ULL
+				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+			validA = (uint32_t)valid;
+			validB = (uint32_t)(valid >> 32);
+		}
 		uint32_t mA, clsA, mB, clsB;
-		barker32(d1, d2, mA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
-		barker32(d2, d3, mB, clsB);       // offsets 32..63
-		mA &= (uint32_t)valid;
-		mB &= (uint32_t)(valid >> 32);
+		barker32(d1, d2, validA, mA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
+		barker32(d2, d3, validB, mB, clsB);       // offsets 32..63
 
 		if (VARIANT == 1) {      // ablation: pre-filter only
 			if (__popc(mA) + __popc(mB) == 33)
-				park(it, 0, stream, word);
+				park((it << 12) | (lane << 6));
 			mA = mB = 0;
 		}
+
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
-		// survivor of the low half AND one of the high half (two independent LDS chains).
+		// survivor of the low half AND one of the high half.  Reads are issued for both
+		// chains before either result is used, and only by lanes that have a survivor.
 		while (__ballot((mA | mB) != 0)) {
 			const uint32_t pA = lowest_bit(mA), pB = lowest_bit(mB);
-			const uint32_t bitA = probe<VARIANT>(d0, d1, d2, clsA, kdiff, pA, mA ? 1u : 0u);
-			const uint32_t bitB = probe<VARIANT>(d1, d2, d3, clsB, kdiff, pB, mB ? 1u : 0u);
+			const Probe qa = probe_addr(d0, d1, d2, clsA, kdiff, pA);
+			const Probe qb = probe_addr(d1, d2, d3, clsB, kdiff, pB);
+			uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0, wa = 0, wb = 0;
+			if (VARIANT != 2) {
+				if (mA) { a1 = lds_ld(LDS_OFF_TABA + qa.offA); a2 = lds_ld(LDS_OFF_TABB + qa.offB); }
+				if (mB) { b1 = lds_ld(LDS_OFF_TABA + qb.offA); b2 = lds_ld(LDS_OFF_TABB + qb.offB); }
+			}
+			const uint32_t projA = xor3(qa.x, a1, a2), projB = xor3(qb.x, b1, b2);
+			uint32_t bitA, bitB;
+			if (VARIANT == 2 || VARIANT == 3) {       // ablation: no bitmap probe
+				bitA = mA && projA == 0x12345678u;
+				bitB = mB && projB == 0x12345678u;
+			} else {
+				if (mA) wa = lds_ld(LDS_OFF_BITMAP + bitmap_off(projA));
+				if (mB) wb = lds_ld(LDS_OFF_BITMAP + bitmap_off(projB));
+				bitA = (wa >> (projA & 31)) & 1;      // wa == 0 for lanes without a survivor
+				bitB = (wb >> (projB & 31)) & 1;
+				if (VARIANT == 4) {                   // ablation: full probe, no candidates
+					bitA &= projA == 0x12345678u;
+					bitB &= projB == 0x12345678u;
+				}
+			}
 			mA &= mA - 1;
 			mB &= mB - 1;
 			if (bitA | bitB) {
-				if (bitA) park(it, pA & 31, stream, word);
-				if (bitB) park(it, (pB & 31) + 32, stream, word);
+				if (bitA) park((it << 12) | (lane << 6) | (pA & 31));
+				if (bitB) park((it << 12) | (lane << 6) | 32 | (pB & 31));
 			}
 		}
+
 		// wave-uniform: compact (and verify) once enough lanes hold a candidate
-		if (__popcll(__ballot(n_parked != 0)) >= 24 || __ballot(n_parked >= LANE_SLOTS - 1))
+		if (__popcll(__ballot(n_parked != 0)) >= 24 || __ballot(n_parked >= PARK_SLOTS))
 			compact(false);
 		lo = nlo;
 		hi = nhi;
