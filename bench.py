@@ -157,6 +157,15 @@ def main():
         value = world * nbits * args.steps / elapsed / 1e9
         alg_bytes = nbits / 8 + 16 * nhits
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
+        # (profiles/traffic.json says how); only quoted for the workload it was measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if abs(args.gib - 4.0) < 1e-9:
+                traffic = int(tj["bytes_per_launch"])
+        except Exception:
+            traffic = None
         result = {
             "metric": "Gbit/s raw bitstream scanned (LAP_ANY, err<=2)",
             "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
@@ -169,7 +178,7 @@ def main():
                        "symbols_per_gpu": nbits, "hits_per_gpu": nhits,
                        "parallelism": "time-sharded x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "scan_lap_any_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }

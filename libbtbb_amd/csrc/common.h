@@ -24,6 +24,7 @@
 #define TABB_BITS      12                  // window bits 45..56
 #define BITMAP_BITS    19                  // projection width of the candidate bitmap
 #define QRING          256                 // per-wave candidate ring (entries)
+#define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
 #define PARK_SLOTS     4                   // private candidate slots per lane
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a

@@ -289,105 +289,153 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	};
 
 	// tile cursor without divisions: uniform (stream, tile-in-stream) stepped per tile
-	uint32_t stream = 0;
-	uint64_t t = blockIdx.x;
-	while (t >= a.tiles_per_stream && stream < a.n_streams) {
-		t -= a.tiles_per_stream;
-		stream++;
+	struct Cursor { uint32_t stream; uint64_t t; };
+	Cursor cur = {0, blockIdx.x};
+	while (cur.t >= a.tiles_per_stream && cur.stream < a.n_streams) {
+		cur.t -= a.tiles_per_stream;
+		cur.stream++;
 	}
+	auto advance = [&](Cursor &c) {
+		c.t += gridDim.x;
+		while (c.t >= a.tiles_per_stream && c.stream < a.n_streams) {
+			c.t -= a.tiles_per_stream;
+			c.stream++;
+		}
+	};
 	// a tile whose 1024 words + halo word and 65536 offsets are all in range needs no masks
 	auto tile_full = [&](uint64_t tt) {
 		return (tt + 1) * SCAN_THREADS + 1 <= a.n_words && (tt + 1) * (SCAN_THREADS * 64ull) <= a.search_bits;
 	};
-	auto load_pair = [&](uint32_t s, uint64_t tt, uint64_t &lo, uint64_t &hi) {
-		const uint64_t *tp = a.words + (uint64_t)s * a.pitch_words + tt * SCAN_THREADS;   // uniform
-		if (tile_full(tt)) {
+	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
+		lo = hi = 0;
+		if (c.stream >= a.n_streams)
+			return;
+		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + c.t * SCAN_THREADS;   // uniform
+		if (tile_full(c.t)) {
 			lo = tp[tid];
 			hi = tp[tid + 1];
 		} else {
-			const uint64_t w = tt * SCAN_THREADS + tid;
+			const uint64_t w = c.t * SCAN_THREADS + tid;
 			lo = w < a.n_words ? tp[tid] : 0;
 			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
 		}
 	};
-	uint64_t lo = 0, hi = 0;
-	if (stream < a.n_streams)
-		load_pair(stream, t, lo, hi);
 
-	for (uint32_t it = 0; stream < a.n_streams; ++it) {
-		const uint64_t cur_t = t;
-		// software prefetch of the next tile: the loads fly while this tile is processed
-		t += gridDim.x;
-		while (t >= a.tiles_per_stream) {
-			t -= a.tiles_per_stream;
-			stream++;
+	// Each trip of the main loop works on UNROLL tiles at once (independent words in the same
+	// lane): with one workgroup of 16 waves per CU (the tables fill the LDS) this is what keeps
+	// enough independent LDS chains in flight to cover the DS latency.
+	constexpr int UNROLL = SCAN_UNROLL;
+	Cursor tc[UNROLL];
+	uint64_t lo[UNROLL], hi[UNROLL];
+#pragma unroll
+	for (int u = 0; u < UNROLL; u++) {
+		tc[u] = cur;
+		load_pair(cur, lo[u], hi[u]);
+		advance(cur);
+	}
+
+	for (uint32_t it = 0; tc[0].stream < a.n_streams; it += UNROLL) {
+		// software prefetch of the next tiles: the loads fly while these are processed
+		Cursor nc[UNROLL];
+		uint64_t nlo[UNROLL], nhi[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			nc[u] = cur;
+			load_pair(cur, nlo[u], nhi[u]);
+			advance(cur);
 		}
-		uint64_t nlo = 0, nhi = 0;
-		if (stream < a.n_streams)
-			load_pair(stream, t, nlo, nhi);
 
-		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
-		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
-
-		// offsets of this word that lie inside [0, search_bits)
-		uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
-		if (!tile_full(cur_t)) {
-			const uint64_t first_off = (cur_t * SCAN_THREADS + tid) * 64;
-			const uint64_t valid = first_off >= a.search_bits ? 0ULL
-				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-			validA = (uint32_t)valid;
-			validB = (uint32_t)(valid >> 32);
-		}
-		uint32_t mA, clsA, mB, clsB;
-		barker32(d1, d2, validA, mA, clsA);       // offsets 0..31: window bits 57.. live in d1:d2
-		barker32(d2, d3, validB, mB, clsB);       // offsets 32..63
-
-		if (VARIANT == 1) {      // ablation: pre-filter only
-			if (__popc(mA) + __popc(mB) == 33)
-				park((it << 12) | (lane << 6));
-			mA = mB = 0;
+		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
+			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			// offsets of this word that lie inside [0, search_bits)
+			uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
+			if (tc[u].stream >= a.n_streams) {
+				validA = validB = 0;
+			} else if (!tile_full(tc[u].t)) {
+				const uint64_t first_off = (tc[u].t * SCAN_THREADS + tid) * 64;
+				const uint64_t valid = first_off >= a.search_bits ? 0ULL
+					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+				validA = (uint32_t)valid;
+				validB = (uint32_t)(valid >> 32);
+			}
+			barker32(d[u][1], d[u][2], validA, m[u][0], cls[u][0]);    // offsets 0..31: window bits 57.. in d1:d2
+			barker32(d[u][2], d[u][3], validB, m[u][1], cls[u][1]);    // offsets 32..63
+			if (VARIANT == 1) {      // ablation: pre-filter only
+				if (__popc(m[u][0]) + __popc(m[u][1]) == 33)
+					park(((it + u) << 12) | (lane << 6));
+				m[u][0] = m[u][1] = 0;
+			}
 		}
 
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
-		// survivor of the low half AND one of the high half.  Reads are issued for both
-		// chains before either result is used, and only by lanes that have a survivor.
-		while (__ballot((mA | mB) != 0)) {
-			const uint32_t pA = lowest_bit(mA), pB = lowest_bit(mB);
-			const Probe qa = probe_addr(d0, d1, d2, clsA, kdiff, pA);
-			const Probe qb = probe_addr(d1, d2, d3, clsB, kdiff, pB);
-			uint32_t a1 = 0, a2 = 0, b1 = 0, b2 = 0, wa = 0, wb = 0;
-			if (VARIANT != 2) {
-				if (mA) { a1 = lds_ld(LDS_OFF_TABA + qa.offA); a2 = lds_ld(LDS_OFF_TABB + qa.offB); }
-				if (mB) { b1 = lds_ld(LDS_OFF_TABA + qb.offA); b2 = lds_ld(LDS_OFF_TABB + qb.offB); }
-			}
-			const uint32_t projA = xor3(qa.x, a1, a2), projB = xor3(qb.x, b1, b2);
-			uint32_t bitA, bitB;
-			if (VARIANT == 2 || VARIANT == 3) {       // ablation: no bitmap probe
-				bitA = mA && projA == 0x12345678u;
-				bitB = mB && projB == 0x12345678u;
-			} else {
-				if (mA) wa = lds_ld(LDS_OFF_BITMAP + bitmap_off(projA));
-				if (mB) wb = lds_ld(LDS_OFF_BITMAP + bitmap_off(projB));
-				bitA = (wa >> (projA & 31)) & 1;      // wa == 0 for lanes without a survivor
-				bitB = (wb >> (projB & 31)) & 1;
-				if (VARIANT == 4) {                   // ablation: full probe, no candidates
-					bitA &= projA == 0x12345678u;
-					bitB &= projB == 0x12345678u;
+		// survivor of every 32-offset half in flight (2 * UNROLL independent chains).  The LDS
+		// reads of all chains are issued before any result is used, each under the exec mask
+		// of the lanes that really have a survivor there.
+		for (;;) {
+			uint32_t any = 0;
+#pragma unroll
+			for (int u = 0; u < UNROLL; u++)
+				any |= m[u][0] | m[u][1];
+			if (!__ballot(any != 0))
+				break;
+			uint32_t p[UNROLL][2], t1[UNROLL][2], t2[UNROLL][2], bw[UNROLL][2], proj[UNROLL][2];
+			Probe q[UNROLL][2];
+#pragma unroll
+			for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					p[u][h] = lowest_bit(m[u][h]);
+					q[u][h] = probe_addr(d[u][h], d[u][h + 1], d[u][h + 2], cls[u][h], kdiff, p[u][h]);
+					t1[u][h] = t2[u][h] = bw[u][h] = 0;
+					if (VARIANT != 2 && m[u][h]) {
+						t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
+						t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
+					}
 				}
-			}
-			mA &= mA - 1;
-			mB &= mB - 1;
-			if (bitA | bitB) {
-				if (bitA) park((it << 12) | (lane << 6) | (pA & 31));
-				if (bitB) park((it << 12) | (lane << 6) | 32 | (pB & 31));
+			uint32_t anybit = 0, bit[UNROLL][2];
+#pragma unroll
+			for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
+					if (VARIANT != 2 && VARIANT != 3 && m[u][h])
+						bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
+				}
+#pragma unroll
+			for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					if (VARIANT == 2 || VARIANT == 3)          // ablation: no bitmap probe
+						bit[u][h] = m[u][h] && proj[u][h] == 0x12345678u;
+					else
+						bit[u][h] = (bw[u][h] >> (proj[u][h] & 31)) & 1;    // bw == 0 without a survivor
+					if (VARIANT == 4)                          // ablation: full probe, no candidates
+						bit[u][h] &= proj[u][h] == 0x12345678u;
+					anybit |= bit[u][h];
+					m[u][h] &= m[u][h] - 1;
+				}
+			if (anybit) {
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						if (bit[u][h])
+							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31));
 			}
 		}
 
 		// wave-uniform: compact (and verify) once enough lanes hold a candidate
 		if (__popcll(__ballot(n_parked != 0)) >= 24 || __ballot(n_parked >= PARK_SLOTS))
 			compact(false);
-		lo = nlo;
-		hi = nhi;
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			tc[u] = nc[u];
+			lo[u] = nlo[u];
+			hi[u] = nhi[u];
+		}
 	}
 	compact(true);
 }
