@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--gib", type=float, default=4.0, help="packed stream size per GPU in GiB")
     ap.add_argument("--cpu-symbols", type=int, default=1 << 30, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "exercising the N>1 path where ranks share one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,11 +98,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus must match WORLD_SIZE"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import libbtbb_amd as bt
     bt.init(2)
@@ -147,7 +156,7 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     nhits = int(cnt_t.item())
     assert nhits <= cap, "hit buffer overflow"
-    t_el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t_el[0]), float(t_el[1])

@@ -26,6 +26,7 @@
 // LDS; workgroups stride over 64 KiB-bit tiles of the stream(s).  Pure integer work, no
 // MFMA; bound by VALU/LDS issue, not by HBM (see DESIGN.md for the roofline accounting).
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 #define FULL_MASK 0xffffffffffffffffULL
@@ -136,6 +137,8 @@ __device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t strea
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
 typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128_t;
 __device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
 __device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
 __device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
