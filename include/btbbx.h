@@ -136,6 +136,26 @@ int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, uint64_t *d_
 int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_symbols,
 			void *hip_stream);
 
+/* ---- streaming ingest (live captures) ------------------------------ */
+/* Feeds a capture to the GPU chunk by chunk: pinned double buffers, asynchronous host->device
+ * copies overlapped with the scan of the previous chunk, a one-word carry so that access codes
+ * straddling chunk boundaries are found exactly once.  Offsets in the returned hits are global
+ * (symbols since btbbx_stream_open).  Every chunk except the last must be a multiple of 64
+ * symbols.  feed() returns the hits of the chunk fed BEFORE this one (the current one is still
+ * in flight); flush() waits for and returns the rest. */
+typedef struct btbbx_stream btbbx_stream;
+#define BTBBX_FMT_PACKED  0      /* LSB-first packed words (const uint64_t *) */
+#define BTBBX_FMT_SYMBOLS 1      /* one 0/1 symbol per byte (const char *), packed on the GPU */
+btbbx_stream *btbbx_stream_open(uint32_t lap, int max_ac_errors, uint64_t max_chunk_symbols, int format);
+int64_t btbbx_stream_feed(btbbx_stream *s, const void *data, uint64_t n_symbols, btbbx_hit *hits, uint64_t cap);
+/* zero-copy variant: write the next chunk straight into the pinned staging buffer returned by
+ * acquire() (max_chunk_symbols bytes for SYMBOLS, /8 for PACKED), then submit() = feed() minus
+ * the memcpy */
+void *btbbx_stream_acquire(btbbx_stream *s);
+int64_t btbbx_stream_submit(btbbx_stream *s, uint64_t n_symbols, btbbx_hit *hits, uint64_t cap);
+int64_t btbbx_stream_flush(btbbx_stream *s, btbbx_hit *hits, uint64_t cap);
+void btbbx_stream_close(btbbx_stream *s);
+
 /* ---- synthetic traffic (same generator as libbtbb_amd/synth.py) --------------- */
 /* words [first_word, first_word + n_words) of the infinite stream `seed`:
  * iid noise plus one sync word per `stride` symbols (stride >= 512), LAP random or

@@ -254,3 +254,33 @@ def test_large_stream_properties():
         sel = hits[(hits["offset"] >= lo) & (hits["offset"] < hi)]
         got = [(int(h["offset"]) - lo, int(h["lap"]), int(h["ac_errors"])) for h in sel]
         assert got == want
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_streaming_ingest(fmt):
+    """Chunked feed (pinned double buffers, one-word carry): same hits as one scan of the whole
+    capture, access codes straddling chunk boundaries found exactly once, ragged last chunk."""
+    lib = bt.lib()
+    words, sym, _ = stream(107, 3000, stride=512)
+    total = len(sym) - 37                      # ragged end
+    want = _libs.orc_find_all(sym, total - 63, _libs.LAP_ANY, 2)
+    for chunk in (64, 640, 4096, 65536):
+        h = lib.btbbx_stream_open(bt.LAP_ANY, 2, chunk, fmt)
+        assert h, lib.btbbx_last_error()
+        got = []
+        buf = np.zeros(1 << 16, bt.HIT_DTYPE)
+        pos = 0
+        while pos < total:
+            n = min(chunk, total - pos)
+            if fmt == 1:
+                data = np.ascontiguousarray(sym[pos:pos + n])
+            else:
+                data = np.ascontiguousarray(words[pos // 64:(pos + n + 63) // 64])
+            k = bt.check(lib.btbbx_stream_feed(h, data.ctypes.data, n, buf.ctypes.data, len(buf)), "feed")
+            got += as_tuples(buf[:k])
+            pos += n
+        k = bt.check(lib.btbbx_stream_flush(h, buf.ctypes.data, len(buf)), "flush")
+        got += as_tuples(buf[:k])
+        lib.btbbx_stream_close(h)
+        assert got == want, (fmt, chunk, len(got), len(want))
+    assert len(want) > 100
