@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void inject_kernel(SynthArgs a, uint64_t k0, u
 	uint32_t lap = a.fixed_lap >= 0 ? (uint32_t)a.fixed_lap & 0xffffff : (uint32_t)h1 & 0xffffff;
 	uint32_t nerr = (uint32_t)(k % a.err_cycle);
 	uint64_t mask = 0;
-	for (uint32_t j = 0; j < 3; j++)
+	for (uint32_t j = 0; j < 5; j++)
 		if (nerr > j)
 			mask ^= 1ULL << (((h2 >> (8 * j)) & 0xff) % 57);
 	uint64_t sw = a.sw_default;

@@ -283,7 +283,7 @@ def injection_params(seed, k, stride, err_cycle=4):
         lap = (h1 & np.uint64(0xFFFFFF)).astype(np.uint32)
         nerr = (k % np.uint64(err_cycle)).astype(np.int64)
         mask = np.zeros(k.shape, dtype=np.uint64)
-        for j in range(3):
+        for j in range(5):
             e = (h2 >> np.uint64(8 * j)) & np.uint64(0xFF)
             e = e % np.uint64(57)
             mask ^= np.where(nerr > j, np.uint64(1) << e, np.uint64(0))

@@ -177,6 +177,31 @@ def test_init_semantics_first_nonzero_wins():
         orc.orc_init(2)
 
 
+@pytest.mark.parametrize("n_init", [4, 5])
+def test_large_error_tables(n_init):
+    """btbb_init(4) / btbb_init(5): 457 k / 5.0 M error patterns; the LDS bitmap saturates and
+    nearly every survivor takes the exact path -- slow but bit-exact."""
+    lib = bt.lib()
+    orc = _libs.oracle()
+    words, inj = synth.make_stream(108, 1 << 11, stride=512, err_cycle=7)     # 0..5 (+6) bit errors
+    sym = np.ascontiguousarray(synth.unpack_bits(words))
+    n = len(sym) - 63
+    try:
+        lib.btbbx_shutdown()
+        orc.orc_reset_syndrome_map()
+        assert lib.btbb_init(n_init) == 0 and orc.orc_init(n_init) == 0
+        assert lib.btbbx_table_errors() == n_init
+        for me in (2, n_init - 1, n_init, 6):
+            got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, me))
+            assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, me), (n_init, me)
+        assert len(got) > 150
+    finally:
+        lib.btbbx_shutdown()
+        orc.orc_reset_syndrome_map()
+        bt.init(2)
+        orc.orc_init(2)
+
+
 def test_find_ac_drop_in():
     """btbb_find_ac through the C ABI: first match, packet allocation, LAP / ac_errors."""
     lib = bt.lib()
