@@ -125,6 +125,16 @@ int btbb_decode_payload(btbb_packet* pkt);                           /* btbb.h:1
 void btbb_print_packet(const btbb_packet* pkt);                      /* btbb.h:148 */
 int btbb_header_present(const btbb_packet* pkt);                     /* btbb.h:151 */
 
+/* Also exported by the reference library (lib/src/bluetooth_packet.h:114-144), for callers
+ * that link against them: one candidate clock / its CRC verdict, FHS fields, tun format. */
+uint8_t try_clock(int clock, btbb_packet *pkt);                      /* bluetooth_packet.h:132 */
+int crc_check(int clock, btbb_packet *pkt);                          /* bluetooth_packet.h:124 */
+uint32_t lap_from_fhs(btbb_packet *pkt);                             /* bluetooth_packet.h:135 */
+uint8_t uap_from_fhs(btbb_packet *pkt);                              /* bluetooth_packet.h:138 */
+uint16_t nap_from_fhs(btbb_packet *pkt);                             /* bluetooth_packet.h:141 */
+uint32_t clock_from_fhs(btbb_packet *pkt);                           /* bluetooth_packet.h:144 */
+char *tun_format(btbb_packet *pkt);                                  /* bluetooth_packet.h:127 */
+
 btbb_piconet *btbb_piconet_new(void);                                /* btbb.h:163 */
 void btbb_piconet_ref(btbb_piconet *pn);                             /* btbb.h:164 */
 void btbb_piconet_unref(btbb_piconet *pn);                           /* btbb.h:165 */

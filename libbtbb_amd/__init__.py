@@ -141,6 +141,13 @@ SIGNATURES = {
     "btbb_decode_payload": (C.c_int, [_vp]),
     "btbb_print_packet": (None, [_vp]),
     "btbb_header_present": (C.c_int, [_vp]),
+    "try_clock": (C.c_uint8, [C.c_int, _vp]),
+    "crc_check": (C.c_int, [C.c_int, _vp]),
+    "lap_from_fhs": (_u32, [_vp]),
+    "uap_from_fhs": (C.c_uint8, [_vp]),
+    "nap_from_fhs": (C.c_uint16, [_vp]),
+    "clock_from_fhs": (_u32, [_vp]),
+    "tun_format": (_vp, [_vp]),
     "btbb_piconet_new": (_vp, []),
     "btbb_piconet_ref": (None, [_vp]),
     "btbb_piconet_unref": (None, [_vp]),

@@ -262,6 +262,56 @@ int btbb_decode(btbb_packet *pkt)
 	return rv;
 }
 
+/* ---- symbols the reference library also exports (lib/src/bluetooth_packet.h:114-144) ---- */
+
+/* try_clock, bluetooth_packet.c:1178-1195: one candidate clock through the GPU chain */
+uint8_t try_clock(int clock, btbb_packet *pkt)
+{
+	TrialPlan plan = { 1ULL, 0ULL, (uint32_t)clock & 63 };
+	int uap = 0;
+	if (packet_gpu_decode(pkt, DEC_TRIALS, &plan, nullptr, &uap, nullptr))
+		return 0;
+	return (uint8_t)uap;
+}
+
+/* crc_check, bluetooth_packet.c:708-769 */
+int crc_check(int clock, btbb_packet *pkt)
+{
+	TrialPlan plan = { 0ULL, 1ULL, (uint32_t)clock & 63 };
+	int rv = 1;
+	if (packet_gpu_decode(pkt, DEC_TRIALS, &plan, nullptr, nullptr, &rv))
+		return 1;
+	return rv;
+}
+
+/* FHS field extractors, bluetooth_packet.c:1411-1441: read already decoded payload bits */
+uint32_t lap_from_fhs(btbb_packet *pkt) { return bits_of(pkt->payload + 34, 24); }
+uint8_t uap_from_fhs(btbb_packet *pkt) { return (uint8_t)bits_of(pkt->payload + 64, 8); }
+uint16_t nap_from_fhs(btbb_packet *pkt) { return (uint16_t)bits_of(pkt->payload + 72, 16); }
+uint32_t clock_from_fhs(btbb_packet *pkt) { return bits_of(pkt->payload + 115, 26); }
+
+/* tun_format, bluetooth_packet.c:1340-1368: 6 bytes of meta data, 3 of header, payload bytes;
+ * malloc'd, the caller frees */
+char *tun_format(btbb_packet *pkt)
+{
+	int length = 9 + pkt->payload_length;
+	char *out = (char *)malloc((size_t)length);
+	if (!out)
+		return NULL;
+	out[0] = (char)(pkt->clkn & 0xff);
+	out[1] = (char)((pkt->clkn >> 8) & 0xff);
+	out[2] = (char)((pkt->clkn >> 16) & 0xff);
+	out[3] = (char)((pkt->clkn >> 24) & 0xff);
+	out[4] = (char)pkt->channel;
+	out[5] = (char)(btbb_packet_get_flag(pkt, BTBB_CLK27_VALID) | (btbb_packet_get_flag(pkt, BTBB_NAP_VALID) << 1));
+	out[6] = (char)bits_of(pkt->packet_header, 7);
+	out[7] = (char)bits_of(pkt->packet_header + 7, 3);
+	out[8] = (char)bits_of(pkt->packet_header + 10, 8);
+	for (int i = 0; i < pkt->payload_length; i++)
+		out[9 + i] = (char)bits_of(pkt->payload + 8 * i, 8);
+	return out;
+}
+
 } // extern "C"
 
 // ---- GPU round trips for one packet object ---------------------------------------------------

@@ -186,6 +186,41 @@ def test_drop_in_decode(capfd):
     assert ok > 8
 
 
+def test_drop_in_try_clock_crc_check_and_fhs_fields(capfd):
+    """The internal entry points the reference library also exports: try_clock / crc_check one
+    clock at a time on the same packet object (state carried exactly like the oracle), FHS
+    field extractors and tun_format after a decode."""
+    lib, orc = bt.lib(), _libs.oracle()
+    rng = np.random.default_rng(35)
+    for sym, meta in _pkt.random_packets(rng, 24, max_sym_errors=1):
+        d = DropIn(lib, orc, meta["lap"])
+        d.set_data(sym, 7, meta["clk6"] << 1)
+        for clock in (meta["clk6"], (meta["clk6"] + 9) % 64, 63):
+            assert lib.try_clock(clock, d.p) == orc.orc_try_clock(clock, d.o)
+            assert lib.crc_check(clock, d.p) == orc.orc_crc_check(clock, d.o)
+            d.check((meta, clock))
+        d.close()
+    lap, uap = 0x654321, 0x5A
+    fb = synth.fhs_payload(lap, uap, 0xBEEF, 0x2345678, rng)
+    sym = synth.build_packet(lap, uap, 11, synth.TYPE_FHS, fhs_bits=fb)
+    d = DropIn(lib, orc, lap)
+    d.set_data(sym, 3, 11 << 1)
+    lib.btbb_packet_set_uap(d.p, uap)
+    lib.btbb_packet_set_flag(d.p, 4, 1)
+    assert lib.btbb_decode(d.p) == 1000
+    assert lib.lap_from_fhs(d.p) == lap and lib.uap_from_fhs(d.p) == uap
+    assert lib.nap_from_fhs(d.p) == 0xBEEF and lib.clock_from_fhs(d.p) == 0x2345678
+    tun = lib.tun_format(d.p)
+    raw = bytes((C.c_uint8 * (9 + 20)).from_address(tun))
+    assert raw[4] == 3 and raw[8] == lib.btbb_packet_get_hec(d.p)
+    pk = np.zeros(64, np.uint8)
+    lib.btbb_get_payload_packed(d.p, _libs.ptr(pk))
+    assert raw[9:29] == bytes(pk[:20])
+    C.CDLL(None).free(C.c_void_p(tun))
+    d.close()
+    capfd.readouterr()
+
+
 def test_drop_in_uap_from_header(capfd):
     """Piconet UAP / CLK1-6 discovery over packet sequences: return values, piconet state and
     the packet object after each call equal the oracle's."""
