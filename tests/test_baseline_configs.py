@@ -1,0 +1,168 @@
+"""BASELINE.json configs as parity-test cases.
+
+config 0 (CPU plumbing): known-LAP btbb_find_ac over a 1 MiB packed synthetic bitstream
+          (8 388 608 symbols, one ID packet every 4096 symbols with 0/1/2 bit errors),
+          max_ac_errors = 2 -- reference vs oracle on the CPU, and the HIP path under -m gpu.
+config 2: known-LAP full chain (find -> header -> payload -> HEC/CRC) over 79 hop-channel
+          streams -- HIP vs oracle, every packet.
+config 4: 64 whitening seeds x HEC/CRC check over the detected-packet stream.
+(config 1 is bench.py / test_gpu_scan.py::test_large_stream_properties; config 3 is the
+time-sharded multi-GPU run of bench.py --gpus 8, its sharding logic is test_sharding_gloo.py.)
+"""
+import numpy as np
+import pytest
+
+import _libs
+from libbtbb_amd import synth
+
+LAP = 0x9E8B33
+
+
+def config0_stream():
+    words, inj = synth.make_stream(1, 131072, stride=4096, lap=LAP, err_cycle=3)
+    return words, inj
+
+
+def test_config0_known_lap_1mib_cpu():
+    words, inj = config0_stream()
+    sym = np.ascontiguousarray(synth.unpack_bits(words))
+    n = len(sym) - 63
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    got = _libs.orc_find_all(sym, n, LAP, 2)
+    assert len(got) == 2048 == len(inj[0])                 # every injection, no false positive
+    assert [g[0] for g in got] == [int(p) for p in inj[0]]
+    popc = np.unpackbits(inj[3].view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)
+    assert [g[2] for g in got] == popc.tolist()
+    ref = _libs.ref()
+    if ref is not None:
+        ref.btbb_init(2)
+        assert _libs.ref_find_all_native(sym, n, LAP, 2) == got
+
+
+@pytest.mark.gpu
+def test_config0_known_lap_1mib_gpu():
+    import libbtbb_amd as bt
+    bt.init(2)
+    words, inj = config0_stream()
+    sym = np.ascontiguousarray(synth.unpack_bits(words))
+    n = len(sym) - 63
+    hits = bt.scan_words(words, n, LAP, 2)
+    got = [(int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in hits]
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    assert got == _libs.orc_find_all(sym, n, LAP, 2) and len(got) == 2048
+
+
+def _channel_streams(nch, wpc, rng, uap):
+    """79 hop-channel streams with DM1/DH1/DM3/FHS/NULL/DH5 packets of one piconet."""
+    stream = synth.noise_words(4242, 0, nch * wpc).reshape(nch, wpc).copy()
+    truth = {}
+    types = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_FHS, synth.TYPE_NULL, synth.TYPE_DH5]
+    for ch in range(nch):
+        symc = synth.unpack_bits(stream[ch])
+        for k in range(wpc * 64 // 4096):
+            clk6 = int(rng.integers(0, 64))
+            t = types[(k + ch) % len(types)]
+            body = rng.integers(0, 256, int(rng.integers(1, 17)), dtype=np.uint8).tobytes()
+            p = synth.build_packet(LAP, uap, clk6, t, lt_addr=1 + k % 7, flags=k % 8, body=body,
+                                   fhs_bits=synth.fhs_payload(LAP, uap, 0x1234, k, rng))
+            if rng.random() < 0.3:                      # symbol errors behind the access code
+                p[int(rng.integers(64, len(p)))] ^= 1
+            pos = k * 4096 + 100 + int(rng.integers(0, 64))
+            if pos + len(p) + 64 > len(symc):
+                continue
+            symc[pos:pos + len(p)] = p
+            truth[(ch, pos)] = clk6
+        stream[ch] = synth.pack_bits(symc)
+    return stream, truth
+
+
+@pytest.mark.gpu
+def test_config2_full_chain_79_channels_and_config4_trials():
+    import ctypes as C
+    import libbtbb_amd as bt
+    import _pkt
+    bt.init(2)
+    lib = bt.lib()
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    rng = np.random.default_rng(79)
+    uap, nch, wpc = 0x47, 79, 1 << 10
+    stream, truth = _channel_streams(nch, wpc, rng, uap)
+    d_w = bt.DeviceBuffer(stream.nbytes).upload(stream)
+    cap = 1 << 14
+    d_h = bt.DeviceBuffer(cap * 16)
+    d_c = bt.DeviceBuffer(4).zero()
+    nbits = wpc * 64 - 63
+    bt.check(lib.btbbx_scan_device(d_w.ptr, wpc, wpc, nch, nbits, LAP, 2, d_h.ptr, cap, d_c.ptr, None))
+    bt.check(lib.btbbx_sync(None))
+    n = int(d_c.download(np.uint32, 1)[0])
+    hits = d_h.download(bt.HIT_DTYPE, n)
+    lib.btbbx_sort_hits(hits.ctypes.data_as(C.c_void_p), n)
+    d_h.upload(hits)
+    # find: same hit list as the oracle, channel by channel
+    want = []
+    syms = []
+    for ch in range(nch):
+        s = np.ascontiguousarray(synth.unpack_bits(stream[ch]))
+        syms.append(s)
+        want += [(ch,) + h for h in _libs.orc_find_all(s, nbits, LAP, 2)]
+    assert [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in hits] == want
+    assert n >= len(truth) > 1000
+    # gather + decode on the GPU with the true clock of each packet
+    d_p = bt.DeviceBuffer(n * 400)
+    d_l = bt.DeviceBuffer(n * 4)
+    bt.check(lib.btbbx_gather_packets_device(d_w.ptr, wpc, wpc, d_h.ptr, n, 3125, d_p.ptr, d_l.ptr, None))
+    bt.check(lib.btbbx_sync(None))
+    lengths = d_l.download(np.uint32, n)
+    packets = d_p.download(np.uint64, n * 50).reshape(n, 50)
+    pin = np.zeros(n, bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    pin["uap"] = uap
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    for i, h in enumerate(hits):
+        pin["clkn"][i] = truth.get((int(h["stream"]), int(h["offset"])), 0)
+    out = bt.run_decode(packets, pin)
+    ok = 0
+    for i, h in enumerate(hits):
+        s = syms[int(h["stream"])][int(h["offset"]):int(h["offset"]) + 3125]
+        assert len(s) == lengths[i]
+        assert (synth.unpack_bits(packets[i], len(s)) == s).all()
+        p = orc.orc_packet_new()
+        orc.orc_packet_init_found(p, LAP, int(h["ac_errors"]))
+        orc.orc_packet_set_data(p, _libs.ptr(np.ascontiguousarray(s)), len(s), int(h["stream"]), int(pin["clkn"][i]) << 1)
+        p.contents.UAP = uap
+        orc.orc_packet_set_flag(p, 2, 1)
+        orc.orc_packet_set_flag(p, 4, 1)
+        hd = orc.orc_decode_header(p)
+        rv = orc.orc_decode_payload(p) if hd else 0
+        st = _pkt.orc_state(p)
+        o = out[i]
+        assert (int(o["header_rv"]), int(o["payload_rv"])) == (hd, rv), (i, st["packet_type"])
+        if hd:
+            assert (int(o["lt_addr"]), int(o["type"]), int(o["hdr_flags"]), int(o["hec"]), int(o["payload_length"])) == \
+                   (st["packet_lt_addr"], st["packet_type"], st["packet_flags"], st["packet_hec"], st["payload_length"])
+            assert (synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744) == st["payload"]).all()
+            ok += rv in (1, 10, 1000)
+        orc.orc_packet_free(p)
+    assert ok > 0.9 * len(truth)
+    # config 4: the 64-clock table of every detected packet, a sample checked against the oracle
+    pin["flags"] = 1
+    pin["uap"] = 0
+    trials = bt.run_trials(packets, pin)
+    for i in range(0, n, max(1, n // 300)):
+        s = np.ascontiguousarray(syms[int(hits[i]["stream"])][int(hits[i]["offset"]):int(hits[i]["offset"]) + 3125])
+        p = orc.orc_packet_new()
+        orc.orc_packet_init_found(p, LAP, 0)
+        orc.orc_packet_set_data(p, _libs.ptr(s), len(s), 0, 0)
+        for clock in range(64):
+            u = orc.orc_try_clock(clock, p)
+            rv = orc.orc_crc_check(clock, p)
+            t = trials[i, clock]
+            assert (int(t["uap"]), int(t["type"]), int(t["rv"])) == (u, p.contents.packet_type, rv), (i, clock)
+        # the true clock yields the true UAP
+        c = truth.get((int(hits[i]["stream"]), int(hits[i]["offset"])))
+        if c is not None and trials[i, c]["rv"] >= 10:
+            assert int(trials[i, c]["uap"]) == uap
+        orc.orc_packet_free(p)
