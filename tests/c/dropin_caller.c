@@ -1,0 +1,58 @@
+/* A caller written against libbtbb's public API only (what an Ubertooth-style capture loop
+ * does, lib/src/btbb.h:63-198): find access codes in a window of one-symbol-per-byte data,
+ * hand the packet to the piconet logic, decode it.  Compiled as C90 against include/btbb.h and
+ * linked with the drop-in library; run on the GPU box by tests/test_c_dropin.py.
+ * Input file: n symbols (bytes 0/1).  Output: one line per access code. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <btbb.h>
+
+int main(int argc, char **argv)
+{
+	FILE *f;
+	char *syms;
+	long n, off = 0;
+	int r, found = 0;
+	btbb_packet *pkt = NULL;
+	btbb_piconet *pn;
+	unsigned long lap;
+
+	if (argc < 3)
+		return 2;
+	lap = strtoul(argv[2], NULL, 0);
+	f = fopen(argv[1], "rb");
+	if (!f)
+		return 2;
+	fseek(f, 0, SEEK_END);
+	n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	syms = (char *)malloc((size_t)n + 128);
+	if (fread(syms, 1, (size_t)n, f) != (size_t)n)
+		return 2;
+	fclose(f);
+
+	if (btbb_init(2) < 0)
+		return 3;
+	pn = btbb_piconet_new();
+	btbb_init_piconet(pn, (uint32_t)lap);
+	while (off < n - 64) {
+		r = btbb_find_ac(syms + off, (int)(n - 63 - off), LAP_ANY, 2, &pkt);
+		if (r < 0)
+			break;
+		off += r;
+		btbb_packet_set_data(pkt, syms + off, (int)(n - off), 17, (uint32_t)(off / 312));
+		printf("AC offset=%ld lap=%06x err=%u hdr=%d\n", off, (unsigned)btbb_packet_get_lap(pkt),
+		       (unsigned)btbb_packet_get_ac_errors(pkt), btbb_header_present(pkt));
+		if (btbb_packet_get_lap(pkt) == lap)
+			btbb_process_packet(pkt, pn);
+		found++;
+		off += 1;
+	}
+	printf("DONE found=%d uap_valid=%d uap=%02x\n", found, btbb_piconet_get_flag(pn, BTBB_UAP_VALID),
+	       (unsigned)btbb_piconet_get_uap(pn));
+	if (pkt)
+		btbb_packet_unref(pkt);
+	btbb_piconet_unref(pn);
+	free(syms);
+	return 0;
+}
