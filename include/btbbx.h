@@ -135,6 +135,8 @@ int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, uint64_t *d_
 		      void *hip_stream);
 int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_symbols,
 			void *hip_stream);
+/* bytes holding 8 symbols MSB first (first received symbol in bit 7) -> LSB-first words, in place */
+int btbbx_msb_to_lsb_device(uint64_t *d_words, uint64_t n_words, void *hip_stream);
 
 /* ---- streaming ingest (live captures) ------------------------------ */
 /* Feeds a capture to the GPU chunk by chunk: pinned double buffers, asynchronous host->device
@@ -146,6 +148,7 @@ int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_
 typedef struct btbbx_stream btbbx_stream;
 #define BTBBX_FMT_PACKED  0      /* LSB-first packed words (const uint64_t *) */
 #define BTBBX_FMT_SYMBOLS 1      /* one 0/1 symbol per byte (const char *), packed on the GPU */
+#define BTBBX_FMT_PACKED_MSB 2   /* 8 symbols per byte, first symbol in bit 7; converted on the GPU */
 btbbx_stream *btbbx_stream_open(uint32_t lap, int max_ac_errors, uint64_t max_chunk_symbols, int format);
 int64_t btbbx_stream_feed(btbbx_stream *s, const void *data, uint64_t n_symbols, btbbx_hit *hits, uint64_t cap);
 /* zero-copy variant: write the next chunk straight into the pinned staging buffer returned by

@@ -95,6 +95,7 @@ SIGNATURES = {
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
     "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_unpack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
+    "btbbx_msb_to_lsb_device": (C.c_int, [_vp, _u64, _vp]),
     "btbbx_stream_open": (_vp, [_u32, C.c_int, _u64, C.c_int]),
     "btbbx_stream_feed": (C.c_int64, [_vp, _vp, _u64, _vp, _u64]),
     "btbbx_stream_acquire": (_vp, [_vp]),

@@ -634,6 +634,17 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint64_t *words, uint
 	}
 }
 
+// MSB-first packed bytes (8 symbols per byte, first received symbol in bit 7 -- the order a
+// radio front end typically delivers) -> the library's LSB-first words: reverse the bits of
+// every byte in place.  brev64 reverses everything, the byte swap puts the bytes back.
+__global__ __launch_bounds__(256) void bitrev_bytes_kernel(uint64_t *words, uint64_t n_words)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n_words; i += step)
+		words[i] = __builtin_bswap64(__brevll(words[i]));
+}
+
 // ---- launchers ----------------------------------------------------------------------------
 
 static int check_scan_args(uint64_t n_words, uint64_t pitch_words, uint32_t n_streams, uint64_t search_bits)
@@ -760,6 +771,17 @@ extern "C" int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, u
 	if (blocks > 65536) blocks = 65536;
 	hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream,
 			   d_symbols, n_symbols, d_words, n_words);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_msb_to_lsb_device(uint64_t *d_words, uint64_t n_words, void *hip_stream)
+{
+	if (n_words == 0)
+		return BTBBX_OK;
+	uint64_t blocks = (n_words + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(bitrev_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_words, n_words);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }

@@ -65,7 +65,7 @@ extern "C" btbbx_stream *btbbx_stream_open(uint32_t lap, int max_ac_errors, uint
 {
 	if (ctx_require())
 		return nullptr;
-	if (max_chunk_symbols < 64 || (format != BTBBX_FMT_PACKED && format != BTBBX_FMT_SYMBOLS)) {
+	if (max_chunk_symbols < 64 || format < BTBBX_FMT_PACKED || format > BTBBX_FMT_PACKED_MSB) {
 		set_error("btbbx_stream_open: bad argument");
 		return nullptr;
 	}
@@ -174,10 +174,15 @@ extern "C" int64_t btbbx_stream_submit(btbbx_stream *s, uint64_t n_symbols, btbb
 		if (rc)
 			return rc;
 	} else {
-		if (n_symbols & 63)      // clear the unused tail of the last word
+		if ((n_symbols & 63) && s->format == BTBBX_FMT_PACKED)      // clear the unused tail of the last word
 			((uint64_t *)sl.h_in)[chunk_words - 1] &= (1ULL << (n_symbols & 63)) - 1;
 		if (hipMemcpyAsync(sl.d_words + 1, sl.h_in, chunk_words * 8, hipMemcpyHostToDevice, sl.stream) != hipSuccess)
 			return hip_fail(hipGetLastError(), "h2d words");
+		if (s->format == BTBBX_FMT_PACKED_MSB) {
+			int rc = btbbx_msb_to_lsb_device(sl.d_words + 1, chunk_words, sl.stream);
+			if (rc)
+				return rc;
+		}
 	}
 	// carry = last word of the previous chunk (its packing must have finished)
 	if (first) {

@@ -281,7 +281,7 @@ def test_large_stream_properties():
         assert got == want
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("fmt", [0, 1, 2])
 def test_streaming_ingest(fmt):
     """Chunked feed (pinned double buffers, one-word carry): same hits as one scan of the whole
     capture, access codes straddling chunk boundaries found exactly once, ragged last chunk."""
@@ -299,8 +299,11 @@ def test_streaming_ingest(fmt):
             n = min(chunk, total - pos)
             if fmt == 1:
                 data = np.ascontiguousarray(sym[pos:pos + n])
-            else:
+            elif fmt == 0:
                 data = np.ascontiguousarray(words[pos // 64:(pos + n + 63) // 64])
+            else:       # 8 symbols per byte, MSB first
+                pad = np.concatenate([sym[pos:pos + n], np.zeros((-n) % 64, np.uint8)])
+                data = np.ascontiguousarray(np.packbits(pad, bitorder="big"))
             k = bt.check(lib.btbbx_stream_feed(h, data.ctypes.data, n, buf.ctypes.data, len(buf)), "feed")
             got += as_tuples(buf[:k])
             pos += n
