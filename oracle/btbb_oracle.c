@@ -924,8 +924,13 @@ static void channel_seen(orc_piconet *pn, uint8_t ch)   /* :133-141 */
 	}
 }
 
-static void piconet_reset(orc_piconet *pn)   /* :547-572 (hop-reversal buffers are out of scope) */
+void orc_piconet_reset(orc_piconet *pn)   /* :547-572 */
 {
+	if (orc_piconet_get_flag(pn, ORC_HOP_REVERSAL_INIT)) {
+		free(pn->clock_candidates);
+		pn->clock_candidates = NULL;   /* the reference leaves it dangling; never read again before re-init */
+		pn->sequence = NULL;
+	}
 	orc_piconet_set_flag(pn, ORC_GOT_FIRST_PACKET, 0);
 	orc_piconet_set_flag(pn, ORC_HOP_REVERSAL_INIT, 0);
 	orc_piconet_set_flag(pn, ORC_UAP_VALID, 0);
@@ -948,7 +953,7 @@ int orc_uap_from_header(orc_packet *p, orc_piconet *pn)
 		pn->pattern_indices[pn->packets_observed] = (int)(clkn - pn->first_pkt_time);
 		pn->pattern_channels[pn->packets_observed] = p->channel;
 	} else {
-		piconet_reset(pn);
+		orc_piconet_reset(pn);
 		return 0;
 	}
 	pn->packets_observed++;
@@ -996,13 +1001,38 @@ int orc_uap_from_header(orc_packet *p, orc_piconet *pn)
 		return 1;
 	}
 	if (remaining == 0)
-		piconet_reset(pn);
+		orc_piconet_reset(pn);
 	return 0;
 }
 
-/* bluetooth_piconet.c:851-899, non-survey branches.  try_hop (:501-543) is restated
- * up to the point where CLK1-27 hop reversal (out of scope) would
- * start; that point only bumps hop_reversal_requests. */
+/* try_hop, bluetooth_piconet.c:501-543 (prints dropped) */
+static void try_hop(orc_packet *p, orc_piconet *pn)
+{
+	uint8_t filter_uap = pn->UAP;
+
+	orc_decode(p);
+	if (orc_piconet_get_flag(pn, ORC_HOP_REVERSAL_INIT)) {
+		pn->pattern_indices[pn->packets_observed] = (int)(p->clkn - pn->first_pkt_time);
+		pn->pattern_channels[pn->packets_observed] = p->channel;
+		pn->packets_observed++;
+		pn->total_packets_observed++;
+		orc_winnow(pn);
+	} else if (orc_piconet_get_flag(pn, ORC_CLK6_VALID)) {
+		orc_uap_from_header(p, pn);
+	} else if (orc_uap_from_header(p, pn)) {
+		if (filter_uap == pn->UAP) {
+			pn->hop_reversal_requests++;
+			orc_init_hop_reversal(0, pn);
+			orc_winnow(pn);
+		}
+	}
+	if (!orc_piconet_get_flag(pn, ORC_UAP_VALID)) {
+		orc_piconet_set_flag(pn, ORC_UAP_VALID, 1);
+		pn->UAP = filter_uap;
+	}
+}
+
+/* bluetooth_piconet.c:851-899, non-survey branches */
 int orc_process_packet(orc_packet *p, orc_piconet *pn)
 {
 	if (pn)
@@ -1015,20 +1045,7 @@ int orc_process_packet(orc_packet *p, orc_piconet *pn)
 			orc_packet_set_flag(p, ORC_CLK27_VALID, 1);
 			orc_decode(p);
 		} else if (pn->UAP) {
-			uint8_t filter_uap = pn->UAP;
-			orc_decode(p);
-			if (orc_piconet_get_flag(pn, ORC_HOP_REVERSAL_INIT)) {
-				pn->hop_reversal_requests++;
-			} else if (orc_piconet_get_flag(pn, ORC_CLK6_VALID)) {
-				orc_uap_from_header(p, pn);
-			} else if (orc_uap_from_header(p, pn)) {
-				if (filter_uap == pn->UAP)
-					pn->hop_reversal_requests++;
-			}
-			if (!orc_piconet_get_flag(pn, ORC_UAP_VALID)) {
-				orc_piconet_set_flag(pn, ORC_UAP_VALID, 1);
-				pn->UAP = filter_uap;
-			}
+			try_hop(p, pn);
 			if (orc_piconet_get_flag(pn, ORC_CLK6_VALID) && orc_piconet_get_flag(pn, ORC_CLK27_VALID)) {
 				orc_piconet_set_flag(pn, ORC_FOLLOWING, 1);
 				return -1;

@@ -78,7 +78,15 @@ typedef struct orc_piconet {
 	uint8_t pattern_channels[1000];
 	int clk_offset;
 	uint32_t first_pkt_time;
-	int hop_reversal_requests;  /* count of times the (out-of-scope) hop reversal would start */
+	int hop_reversal_requests;  /* count of times try_hop started the hop reversal */
+	/* hop reversal, bluetooth_piconet.h:38-40, 56-85 */
+	int aliased;                /* never set by the reference's public API (always 0) */
+	int a1, b, c1, d1, e;
+	int bank[79];
+	char *sequence;             /* 2^27 channels, owned by the pattern cache */
+	uint32_t *clock_candidates;
+	int num_candidates;
+	int winnowed;
 } orc_piconet;
 
 typedef struct orc_hit {
@@ -152,6 +160,20 @@ void orc_piconet_set_flag(orc_piconet *pn, int flag, int val);
 int orc_piconet_get_flag(const orc_piconet *pn, int flag);
 int orc_uap_from_header(orc_packet *p, orc_piconet *pn);     /* bluetooth_piconet.c:648 */
 int orc_process_packet(orc_packet *p, orc_piconet *pn);      /* :851 (non-survey) */
+void orc_piconet_reset(orc_piconet *pn);                     /* :547-572 */
+
+/* ---- hop sequence and CLK1-27 reversal (btbb_oracle_hop.c) ---- */
+#define ORC_SEQUENCE_LENGTH 134217728u                       /* bluetooth_piconet.h:102 */
+int orc_perm5(int z, int p_high, int p_low);                 /* bluetooth_piconet.c:256 */
+void orc_hop_precalc(orc_piconet *pn);                       /* :171 */
+void orc_hop_address_precalc(int address, orc_piconet *pn);  /* :197 */
+void orc_gen_hops(const orc_piconet *pn, char *sequence);    /* :311 (fills 2^27 bytes) */
+void orc_get_hop_pattern(orc_piconet *pn);                   /* :391 (cache keyed by the low 32 key bits) */
+void orc_hop_cache_clear(void);                              /* test helper: free every cached sequence */
+char orc_single_hop(int clock, const orc_piconet *pn);       /* :415 */
+void orc_piconet_set_afh_map(orc_piconet *pn, const uint8_t *afh_map);   /* :122 */
+int orc_init_hop_reversal(int aliased, orc_piconet *pn);     /* :475 */
+int orc_winnow(orc_piconet *pn);                             /* :614 */
 
 #ifdef __cplusplus
 }

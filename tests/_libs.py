@@ -44,6 +44,9 @@ class OrcPiconet(C.Structure):
         ("total_packets_observed", C.c_int), ("clock6_candidates", C.c_int * 64),
         ("pattern_indices", C.c_int * 1000), ("pattern_channels", C.c_uint8 * 1000),
         ("clk_offset", C.c_int), ("first_pkt_time", C.c_uint32), ("hop_reversal_requests", C.c_int),
+        ("aliased", C.c_int), ("a1", C.c_int), ("b", C.c_int), ("c1", C.c_int), ("d1", C.c_int), ("e", C.c_int),
+        ("bank", C.c_int * 79), ("sequence", C.c_void_p), ("clock_candidates", C.POINTER(C.c_uint32)),
+        ("num_candidates", C.c_int), ("winnowed", C.c_int),
     ]
 
 
@@ -55,8 +58,8 @@ def build_oracle():
 @functools.lru_cache(maxsize=None)
 def oracle():
     path = os.path.join(ORACLE_DIR, "liboracle.so")
-    src = os.path.join(ORACLE_DIR, "btbb_oracle.c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("btbb_oracle.c", "btbb_oracle_hop.c", "btbb_oracle.h")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
         build_oracle()
     lib = C.CDLL(path)
     u8p, cp = C.POINTER(C.c_uint8), C.c_char_p
@@ -101,6 +104,17 @@ def oracle():
         "orc_piconet_get_flag": (C.c_int, [N, C.c_int]),
         "orc_uap_from_header": (C.c_int, [P, N]),
         "orc_process_packet": (C.c_int, [P, N]),
+        "orc_piconet_reset": (None, [N]),
+        "orc_perm5": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+        "orc_hop_precalc": (None, [N]),
+        "orc_hop_address_precalc": (None, [C.c_int, N]),
+        "orc_gen_hops": (None, [N, C.c_void_p]),
+        "orc_get_hop_pattern": (None, [N]),
+        "orc_hop_cache_clear": (None, []),
+        "orc_single_hop": (C.c_char, [C.c_int, N]),
+        "orc_piconet_set_afh_map": (None, [N, C.c_void_p]),
+        "orc_init_hop_reversal": (C.c_int, [C.c_int, N]),
+        "orc_winnow": (C.c_int, [N]),
         "orc_lap_from_fhs": (C.c_uint32, [P]),
         "orc_uap_from_fhs": (C.c_uint8, [P]),
         "orc_nap_from_fhs": (C.c_uint16, [P]),
@@ -183,6 +197,24 @@ def ref():
         "refint_piconet_total_packets_observed": (C.c_int, [vp]),
         "refint_piconet_first_pkt_time": (C.c_uint32, [vp]),
         "refint_piconet_flags": (C.c_uint32, [vp]),
+        "refint_piconet_sequence": (vp, [vp]),
+        "refint_piconet_clock_candidates": (C.POINTER(C.c_uint32), [vp]),
+        "refint_piconet_num_candidates": (C.c_int, [vp]),
+        "refint_piconet_winnowed": (C.c_int, [vp]),
+        "refint_piconet_set_aliased": (None, [vp, C.c_int]),
+        "refint_piconet_hop_params": (None, [vp, C.POINTER(C.c_int)]),
+        "refint_piconet_observe": (None, [vp, C.c_int, C.c_uint8]),
+        "refint_piconet_set_first_pkt_time": (None, [vp, C.c_uint32]),
+        "refint_piconet_set_candidate6": (None, [vp, C.c_int, C.c_int]),
+        "refint_piconet_set_pattern_index": (None, [vp, C.c_int, C.c_int]),
+        "perm5": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+        "single_hop": (C.c_char, [C.c_int, vp]),
+        "get_hop_pattern": (None, [vp]),
+        "btbb_piconet_set_afh_map": (None, [vp, vp]),
+        "btbb_piconet_set_clk_offset": (None, [vp, C.c_int]),
+        "btbb_piconet_set_channel_seen": (C.c_uint8, [vp, C.c_uint8]),
+        "btbb_init_hop_reversal": (C.c_int, [C.c_int, vp]),
+        "btbb_winnow": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
