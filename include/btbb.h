@@ -152,6 +152,7 @@ int btbb_piconet_get_flag(const btbb_piconet *pn, int flag);         /* btbb.h:1
 uint8_t btbb_piconet_set_channel_seen(btbb_piconet *pn, uint8_t channel);    /* btbb.h:182 */
 uint8_t btbb_piconet_clear_channel_seen(btbb_piconet *pn, uint8_t channel);  /* btbb.h:183 */
 uint8_t btbb_piconet_get_channel_seen(btbb_piconet *pn, uint8_t channel);    /* btbb.h:184 */
+void btbb_piconet_set_afh_map(btbb_piconet *pn, uint8_t *afh_map);   /* btbb.h:185 */
 uint8_t *btbb_piconet_get_afh_map(btbb_piconet *pn);                 /* btbb.h:186 */
 
 /* btbb.h:189 -- extract LAP/UAP/CLK information from a received packet */
@@ -161,6 +162,13 @@ int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn);
 void btbb_print_afh_map(btbb_piconet *pn);                           /* btbb.h:195 */
 /* btbb.h:198 -- decode a whole packet */
 int btbb_decode(btbb_packet* pkt);
+
+/* btbb.h:203 -- start the CLK1-27 reversal: the candidate clocks (all CLK1-27 values whose hop
+ * is the channel of the first observed packet) are built on the GPU and stay in HBM; returns
+ * their number.  `aliased` only sets BTBB_IS_ALIASED, exactly as in bluetooth_piconet.c:475-498 */
+int btbb_init_hop_reversal(int aliased, btbb_piconet *pn);
+/* btbb.h:206 -- narrow the candidates by all hops observed since the last call */
+int btbb_winnow(btbb_piconet *pn);
 
 int btbb_init_survey(void);                                          /* btbb.h:208 */
 btbb_piconet *btbb_next_survey_result(void);                         /* btbb.h:210 */

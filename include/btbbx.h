@@ -20,6 +20,8 @@
  *                        lib/src/bluetooth_packet.c:708-769, 1178-1195
  *   btbbx_decode_*    <- btbb_header_present / btbb_decode_header / btbb_decode_payload,
  *                        lib/src/bluetooth_packet.c:1198-1297, 1371-1408
+ *   btbbx_hop_*       <- gen_hops / hop / init_candidates / channel_winnow / btbb_winnow,
+ *                        lib/src/bluetooth_piconet.c:311-362, 443-446, 455-498, 575-645
  */
 #ifndef INCLUDED_BTBBX_H
 #define INCLUDED_BTBBX_H
@@ -183,6 +185,53 @@ int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uin
 /* header_present + decode_header + decode_payload with the clock / UAP in d_in */
 int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 			btbbx_pkt_out *d_out, void *hip_stream);
+
+/* ---- hop selection and CLK1-27 reversal ------------------------- */
+#define BTBBX_SEQUENCE_LENGTH 134217728u   /* values of CLK1-27, bluetooth_piconet.h:102 */
+
+/* the inputs of the hop selection kernel for one piconet (precalc + address_precalc,
+ * bluetooth_piconet.c:171-217) */
+typedef struct btbbx_hop_cfg {
+	uint32_t address;        /* (UAP << 24 | LAP) & 0xfffffff */
+	uint8_t  afh;            /* BTBB_IS_AFH: index the bank modulo used_channels */
+	uint8_t  used_channels;
+	uint8_t  reserved[2];
+	uint8_t  bank[80];       /* frequency register bank; entries past the filled part are 0 */
+} btbbx_hop_cfg;
+
+/* afh_map == NULL: basic hopping over all 79 channels; otherwise the 10-byte AFH channel map */
+void btbbx_hop_cfg_init(btbbx_hop_cfg *cfg, uint32_t address, const uint8_t *afh_map);
+
+/* channels of CLK1-27 values [first, first + count) -- what gen_hops stores in
+ * sequence[first .. first+count); first and count multiples of 64; d_sequence receives count
+ * bytes.  The whole 2^27-entry pattern is 128 MiB. */
+int btbbx_hop_sequence_device(const btbbx_hop_cfg *cfg, uint64_t first, uint64_t count,
+			      uint8_t *d_sequence, void *hip_stream);
+/* hop(clock) for arbitrary CLK1-27 values (taken modulo 2^27) */
+int btbbx_hop_channels_device(const btbbx_hop_cfg *cfg, const uint32_t *d_clocks, uint32_t n,
+			      uint8_t *d_channels, void *hip_stream);
+
+/* CLK1-27 reversal: the candidate list lives in HBM.  open() = init_candidates
+ * (bluetooth_piconet.c:455-472): all clocks congruent clk6 mod 64 whose hop is `channel`
+ * (a value > 127 matches nothing, as the reference compares signed chars);
+ * aliased != 0 compares ((ch + 24) % 25) + 26 instead (:449-452). */
+typedef struct btbbx_hop_reversal btbbx_hop_reversal;
+btbbx_hop_reversal *btbbx_hop_reversal_open(const btbbx_hop_cfg *cfg, uint32_t clk6, uint8_t channel,
+					    int aliased, int *n_candidates);
+/* channel_winnow over n_obs observed hops in order (index offset relative to the first packet,
+ * channel), stopping after the first one that leaves <= 1 candidate (btbb_winnow, :614-645).
+ * *stop = how many observations were applied before that one (n_obs if none did), *count =
+ * candidates left, *cand0 = the first of them.  Returns 0 or a negative BTBBX_E_*. */
+int btbbx_hop_reversal_winnow(btbbx_hop_reversal *h, const int32_t *index_offsets, const uint8_t *channels,
+			      uint32_t n_obs, uint32_t *stop, uint32_t *count, uint32_t *cand0);
+int64_t btbbx_hop_reversal_candidates(btbbx_hop_reversal *h, uint32_t *dst, uint64_t cap);  /* ascending */
+void btbbx_hop_reversal_close(btbbx_hop_reversal *h);
+
+/* piconet introspection for tests and tools: what the reference keeps in struct btbb_piconet
+ * (bluetooth_piconet.h:59-85).  field: 0 num_candidates, 1 winnowed, 2 packets_observed,
+ * 3 total_packets_observed, 4 first_pkt_time, 5 flags, 6 used_channels */
+int64_t btbbx_piconet_state(const void *piconet, int field);
+int64_t btbbx_piconet_candidates(const void *piconet, uint32_t *dst, uint64_t cap);
 
 #ifdef __cplusplus
 }

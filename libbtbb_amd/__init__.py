@@ -106,6 +106,15 @@ SIGNATURES = {
     "btbbx_gather_packets_device": (C.c_int, [_vp, _u64, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_trials_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
+    "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
+    "btbbx_hop_channels_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "btbbx_hop_reversal_open": (_vp, [_vp, _u32, C.c_uint8, C.c_int, C.POINTER(C.c_int)]),
+    "btbbx_hop_reversal_winnow": (C.c_int, [_vp, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "btbbx_hop_reversal_candidates": (C.c_int64, [_vp, _vp, _u64]),
+    "btbbx_hop_reversal_close": (None, [_vp]),
+    "btbbx_piconet_state": (C.c_int64, [_vp, C.c_int]),
+    "btbbx_piconet_candidates": (C.c_int64, [_vp, _vp, _u64]),
     # ---- btbb.h
     "btbb_init": (C.c_int, [C.c_int]),
     "btbb_get_release": (C.c_char_p, []),
@@ -169,6 +178,9 @@ SIGNATURES = {
     "btbb_process_packet": (C.c_int, [_vp, _vp]),
     "btbb_uap_from_header": (C.c_int, [_vp, _vp]),
     "btbb_print_afh_map": (None, [_vp]),
+    "btbb_piconet_set_afh_map": (None, [_vp, _vp]),
+    "btbb_init_hop_reversal": (C.c_int, [C.c_int, _vp]),
+    "btbb_winnow": (C.c_int, [_vp]),
     "btbb_decode": (C.c_int, [_vp]),
     "btbb_init_survey": (C.c_int, []),
     "btbb_next_survey_result": (_vp, []),
@@ -308,3 +320,76 @@ def run_decode(packet_words, pkt_in):
     check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
     check(lib().btbbx_sync(None))
     return d_out.download(PKTOUT_DTYPE, n)
+
+
+# ---- hop selection / CLK1-27 reversal -------------------------------------------------------
+SEQUENCE_LENGTH = 1 << 27
+
+
+class HopCfg(C.Structure):
+    _fields_ = [("address", C.c_uint32), ("afh", C.c_uint8), ("used_channels", C.c_uint8),
+                ("reserved", C.c_uint8 * 2), ("bank", C.c_uint8 * 80)]
+
+
+def hop_cfg(lap, uap, afh_map=None):
+    """Kernel configuration of one piconet; afh_map = 10-byte AFH channel map or None."""
+    cfg = HopCfg()
+    m = None if afh_map is None else np.ascontiguousarray(afh_map, dtype=np.uint8)
+    lib().btbbx_hop_cfg_init(C.byref(cfg), ((uap << 24) | lap) & 0xFFFFFFF, None if m is None else _ptr(m))
+    return cfg
+
+
+def hop_sequence(cfg, first=0, count=SEQUENCE_LENGTH):
+    """Channels of CLK1-27 values [first, first+count) as a numpy uint8 array (generated in HBM)."""
+    buf = DeviceBuffer(count)
+    try:
+        check(lib().btbbx_hop_sequence_device(C.byref(cfg), first, count, buf.ptr, None), "btbbx_hop_sequence_device")
+        check(lib().btbbx_sync(None), "sync")
+        return buf.download(np.uint8, count)
+    finally:
+        buf.free()
+
+
+def hop_channels(cfg, clocks):
+    clocks = np.ascontiguousarray(clocks, dtype=np.uint32)
+    d_in, d_out = DeviceBuffer(clocks.nbytes).upload(clocks), DeviceBuffer(len(clocks))
+    try:
+        check(lib().btbbx_hop_channels_device(C.byref(cfg), d_in.ptr, len(clocks), d_out.ptr, None),
+              "btbbx_hop_channels_device")
+        check(lib().btbbx_sync(None), "sync")
+        return d_out.download(np.uint8, len(clocks))
+    finally:
+        d_in.free()
+        d_out.free()
+
+
+class HopReversal:
+    """Candidate CLK1-27 values of one piconet, held in HBM (btbbx_hop_reversal_*)."""
+
+    def __init__(self, cfg, clk6, channel, aliased=False):
+        n = C.c_int(0)
+        self.h = lib().btbbx_hop_reversal_open(C.byref(cfg), clk6, channel, int(aliased), C.byref(n))
+        if not self.h:
+            raise BtbbError("btbbx_hop_reversal_open: %s" % lib().btbbx_last_error().decode())
+        self.count = n.value
+
+    def winnow(self, offsets, channels):
+        """Apply observed hops in order; returns (stop, count, first candidate)."""
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        ch = np.ascontiguousarray(channels, dtype=np.uint8)
+        stop, count, cand0 = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().btbbx_hop_reversal_winnow(self.h, _ptr(off), _ptr(ch), len(off), C.byref(stop), C.byref(count),
+                                              C.byref(cand0)), "btbbx_hop_reversal_winnow")
+        self.count = count.value
+        return stop.value, count.value, cand0.value
+
+    def candidates(self):
+        out = np.zeros(max(self.count, 1), np.uint32)
+        n = lib().btbbx_hop_reversal_candidates(self.h, _ptr(out), len(out))
+        check(min(n, 0), "btbbx_hop_reversal_candidates")
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            lib().btbbx_hop_reversal_close(self.h)
+            self.h = None

@@ -1,0 +1,535 @@
+// hop.hip -- Bluetooth BR hop selection and CLK1-27 reversal on the GPU.
+//
+// Replaces lib/src/bluetooth_piconet.c:171-362 (precalc, address_precalc, perm5/fast_perm,
+// gen_hops), :443-472 (hop, aliased_channel, init_candidates) and :575-645 (channel_winnow,
+// btbb_winnow).  The reference materialises the whole 2^27-entry pattern (128 MiB, about a
+// second of CPU per address) and then filters candidate clocks by table look-ups.  Here the
+// selection kernel is a pure function evaluated where it is needed:
+//   * hop_sequence_kernel   fills sequence[first .. first+count) for callers that want the
+//                           table (one lane per 64 hops, permutation done bit-sliced over the
+//                           32 values of CLK2-6: a butterfly stage is a conditional swap of
+//                           two bit planes);
+//   * candidates / winnow   evaluate the kernel per candidate clock -- no table at all.
+// Candidate lists stay in HBM in ascending order (as the reference keeps them) through
+// ballot masks + a prefix over mask words + an ordered scatter.
+#include <string.h>
+#include <stdlib.h>
+#include "common.h"
+
+#define HOP_NCHAN   79
+#define HOP_TAB     272          // perm (<32) + e (<128) + f (<79) + 32 = at most 268
+#define HOP_GROUPS  (1u << 21)   // values of CLK7-27 = groups of 64 hops
+#define HOP_MAX_OBS 1024
+
+struct HopArgs {
+	uint32_t a1, b, c1, d1, e;
+	uint32_t mod;                // 79, or used_channels under AFH
+	uint32_t afh;
+	uint8_t bank[80];
+};
+
+// butterfly stage s exchanges wires (hop_u(s), hop_v(s)); spec vol 2 part B 2.6.2.3
+__device__ __host__ constexpr int hop_u(int s) { constexpr int u[14] = {0, 2, 1, 3, 0, 1, 0, 3, 1, 0, 2, 1, 0, 1}; return u[s]; }
+__device__ __host__ constexpr int hop_v(int s) { constexpr int v[14] = {1, 3, 2, 4, 4, 3, 2, 4, 4, 3, 4, 3, 3, 2}; return v[s]; }
+
+__device__ __forceinline__ void hop_build_tab(uint8_t *tab, const HopArgs &h)
+{
+	// every kernel using the table runs 256 lanes per workgroup
+	tab[threadIdx.x] = h.bank[threadIdx.x % h.mod];
+	if (threadIdx.x < HOP_TAB - 256)
+		tab[256 + threadIdx.x] = h.bank[(256 + threadIdx.x) % h.mod];
+	__syncthreads();
+}
+
+// index into tab for CLK1-27 value idx: perm5 output + e + f (+32 for odd clocks)
+__device__ __forceinline__ uint32_t hop_tab_index(const HopArgs &h, uint32_t idx)
+{
+	const uint32_t y1 = idx & 1, x = (idx >> 1) & 31, t = idx >> 6;
+	const uint32_t a = h.a1 ^ ((t >> 14) & 31);
+	const uint32_t c = h.c1 ^ ((t >> 9) & 31) ^ (y1 ? 31u : 0u);
+	const uint32_t ctl = (c << 9) | (h.d1 ^ (t & 511));
+	uint32_t z = ((x + a) & 31) ^ h.b;
+#pragma unroll
+	for (int s = 13; s >= 0; s--) {
+		const uint32_t sw = ((z >> hop_u(s)) ^ (z >> hop_v(s))) & (ctl >> s) & 1;
+		z ^= (sw << hop_u(s)) | (sw << hop_v(s));
+	}
+	uint32_t f = (16u * t) % HOP_NCHAN;
+	if (h.afh)
+		f %= h.mod;                           // gen_hops' f_dash (:355), not single_hop's
+	return z + h.e + f + 32u * y1;
+}
+
+__device__ __forceinline__ int hop_observable(uint32_t ch, int aliased)
+{
+	return aliased ? (int)((ch + 24) % 25) + 26 : (int)ch;
+}
+
+// ---- whole-table generation -----------------------------------------------------------
+// 4 bits of one plane -> bit 0 of four byte lanes
+__device__ __forceinline__ uint32_t spread4(uint32_t plane, int x0)
+{
+	return __umul24((plane >> x0) & 15u, 0x00204081u) & 0x01010101u;
+}
+
+__global__ __launch_bounds__(256) void hop_sequence_kernel(HopArgs h, uint32_t t0, uint32_t nt, uint4 *out)
+{
+	__shared__ uint8_t tab[HOP_TAB];
+	hop_build_tab(tab, h);
+	const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+	if (g >= nt)
+		return;
+	const uint32_t t = t0 + g;
+	const uint32_t a = h.a1 ^ ((t >> 14) & 31);
+	const uint32_t c = h.c1 ^ ((t >> 9) & 31);
+	const uint32_t d = h.d1 ^ (t & 511);
+	uint32_t f = (16u * t) % HOP_NCHAN;
+	if (h.afh)
+		f %= h.mod;
+	const uint32_t k0 = h.e + f;
+
+	// plane w, bit x = bit w of the permutation input ((x + a) mod 32) ^ b
+	const uint32_t zplane[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+	uint32_t in[5];
+#pragma unroll
+	for (int w = 0; w < 5; w++)
+		in[w] = __builtin_rotateright32(zplane[w], a) ^ (0u - ((h.b >> w) & 1u));
+
+	// stage masks: all ones where the control bit is set.  d drives stages 0..8 for both clock
+	// parities; c drives 9..13 and is complemented for odd clocks (y1 = 1)
+	const uint32_t ctl = (c << 9) | d;
+	uint32_t q[2][5];
+#pragma unroll
+	for (int w = 0; w < 5; w++)
+		q[0][w] = q[1][w] = in[w];
+#pragma unroll
+	for (int s = 13; s >= 0; s--) {
+		const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)ctl, s, 1);
+#pragma unroll
+		for (int y1 = 0; y1 < 2; y1++) {
+			const bool flip = y1 && s >= 9;
+			const uint32_t pu = q[y1][flip ? hop_v(s) : hop_u(s)], pv = q[y1][flip ? hop_u(s) : hop_v(s)];
+			// m set: swap; with flip the roles of "swap" and "keep" are exchanged
+			q[y1][hop_u(s)] = (pu & ~m) | (pv & m);
+			q[y1][hop_v(s)] = (pv & ~m) | (pu & m);
+		}
+	}
+	const uint8_t *tab0 = tab + k0, *tab1 = tab + k0 + 32;
+
+	uint4 *dst = out + (size_t)g * 4;
+#pragma unroll
+	for (int part = 0; part < 4; part++) {          // 8 values of x per 16 output bytes
+		uint32_t wd[4];
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			const int x0 = part * 8 + half * 4;
+			uint32_t v0 = 0, v1 = 0;                // perm outputs of x0..x0+3 in byte lanes
+#pragma unroll
+			for (int w = 4; w >= 0; w--) {          // Horner form keeps the multiplier 24-bit
+				v0 = (v0 << 1) | spread4(q[0][w], x0);
+				v1 = (v1 << 1) | spread4(q[1][w], x0);
+			}
+			// sequence order: x0/y0, x0/y1, x0+1/y0, x0+1/y1, ...
+			const uint32_t c00 = tab0[v0 & 0xff], c01 = tab1[v1 & 0xff];
+			const uint32_t c10 = tab0[(v0 >> 8) & 0xff], c11 = tab1[(v1 >> 8) & 0xff];
+			const uint32_t c20 = tab0[(v0 >> 16) & 0xff], c21 = tab1[(v1 >> 16) & 0xff];
+			const uint32_t c30 = tab0[v0 >> 24], c31 = tab1[v1 >> 24];
+			wd[half * 2] = c00 | (c01 << 8) | (c10 << 16) | (c11 << 24);
+			wd[half * 2 + 1] = c20 | (c21 << 8) | (c30 << 16) | (c31 << 24);
+		}
+		dst[part] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+	}
+}
+
+__global__ __launch_bounds__(256) void hop_channels_kernel(HopArgs h, const uint32_t *clocks, uint32_t n, uint8_t *channels)
+{
+	__shared__ uint8_t tab[HOP_TAB];
+	hop_build_tab(tab, h);
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n)
+		channels[i] = tab[hop_tab_index(h, clocks[i] & (BTBBX_SEQUENCE_LENGTH - 1))];
+}
+
+// ---- candidate lists ------------------------------------------------------------------
+// init_candidates: item j is the clock known6 + 64 j; one ballot word per wave
+__global__ __launch_bounds__(256) void hop_candidate_mask_kernel(HopArgs h, uint32_t known6, int channel, int aliased,
+								  uint64_t *masks)
+{
+	__shared__ uint8_t tab[HOP_TAB];
+	hop_build_tab(tab, h);
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;         // grid covers exactly HOP_GROUPS
+	const int ch = hop_observable(tab[hop_tab_index(h, known6 + 64u * j)], aliased);
+	const uint64_t m = __ballot(ch == channel);
+	if ((threadIdx.x & 63) == 0)
+		masks[j >> 6] = m;
+}
+
+// exclusive prefix of popcounts over the mask words; one workgroup
+__global__ __launch_bounds__(1024) void hop_mask_prefix_kernel(const uint64_t *masks, uint32_t nwords, uint32_t *prefix,
+								uint32_t *total)
+{
+	__shared__ uint32_t part[1024];
+	const uint32_t per = (nwords + 1023) / 1024;
+	const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nwords);
+	uint32_t sum = 0;
+	for (uint32_t w = lo; w < hi; w++)
+		sum += __popcll(masks[w]);
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t step = 1; step < 1024; step <<= 1) {         // Hillis-Steele, inclusive
+		uint32_t v = threadIdx.x >= step ? part[threadIdx.x - step] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = part[threadIdx.x] - sum;
+	for (uint32_t w = lo; w < hi; w++) {
+		prefix[w] = run;
+		run += __popcll(masks[w]);
+	}
+	if (threadIdx.x == 1023)
+		*total = part[1023];
+}
+
+// ordered scatter: src == nullptr -> the value of item i is base + 64 i
+__global__ __launch_bounds__(256) void hop_scatter_kernel(const uint64_t *masks, const uint32_t *prefix, uint32_t nwords,
+							   const uint32_t *src, uint32_t base, uint32_t *dst)
+{
+	const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+	if (w >= nwords)
+		return;
+	uint64_t m = masks[w];
+	uint32_t o = prefix[w];
+	while (m) {
+		const uint32_t i = w * 64 + (uint32_t)__builtin_ctzll(m);
+		m &= m - 1;
+		dst[o++] = src ? src[i] : base + 64u * i;
+	}
+}
+
+struct HopObs {                   // one observed hop: clock distance to the first packet, channel
+	int32_t offset;
+	int32_t channel;              // as the reference's `char channel`: > 127 never matches
+};
+
+// per candidate: how many of the observations it agrees with before the first mismatch
+__global__ __launch_bounds__(256) void hop_winnow_kernel(HopArgs h, const uint32_t *cand, uint32_t n, const HopObs *obs,
+							  uint32_t n_obs, int aliased, uint16_t *agree, uint32_t *hist)
+{
+	__shared__ uint8_t tab[HOP_TAB];
+	__shared__ uint32_t lhist[HOP_MAX_OBS + 1];
+	for (uint32_t i = threadIdx.x; i <= n_obs; i += 256)
+		lhist[i] = 0;
+	hop_build_tab(tab, h);
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		const uint32_t c = cand[i];
+		uint32_t k = 0;
+		for (; k < n_obs; k++) {
+			const HopObs o = obs[k];
+			const uint32_t idx = (c + (uint32_t)o.offset) & (BTBBX_SEQUENCE_LENGTH - 1);
+			if (hop_observable(tab[hop_tab_index(h, idx)], aliased) != o.channel)
+				break;
+		}
+		agree[i] = (uint16_t)k;
+		atomicAdd(&lhist[k], 1u);
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k <= n_obs; k += 256)
+		if (lhist[k])
+			atomicAdd(&hist[k], lhist[k]);
+}
+
+struct WinnowVerdict {
+	uint32_t stop;        // observations applied before the one that left <= 1 candidate (n_obs if none)
+	uint32_t count;       // candidates left after that one (or after all)
+	uint32_t keep_above;  // survivors are the candidates with agree > keep_above
+	uint32_t cand0;       // first survivor (filled by the scatter pass)
+};
+
+// hist[k] = candidates whose first mismatch is observation k (k = n_obs: none)
+__global__ __launch_bounds__(1024) void hop_verdict_kernel(const uint32_t *hist, uint32_t n, uint32_t n_obs, WinnowVerdict *v)
+{
+	__shared__ uint32_t cum[1024];
+	__shared__ uint32_t first;
+	const uint32_t k = threadIdx.x;
+	if (k == 0)
+		first = n_obs;
+	cum[k] = k < n_obs ? hist[k] : 0;
+	__syncthreads();
+	for (uint32_t step = 1; step < 1024; step <<= 1) {
+		uint32_t x = k >= step ? cum[k - step] : 0;
+		__syncthreads();
+		cum[k] += x;
+		__syncthreads();
+	}
+	// candidates left after applying observation k = n - cum[k]
+	if (k < n_obs && n - cum[k] <= 1)
+		atomicMin(&first, k);
+	__syncthreads();
+	if (k == 0) {
+		const uint32_t last = first < n_obs ? first : n_obs - 1;
+		v->stop = first;
+		v->keep_above = last;
+		v->count = n - cum[last];
+		v->cand0 = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void hop_agree_mask_kernel(const uint16_t *agree, uint32_t n, const WinnowVerdict *v,
+							      uint64_t *masks)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;         // grid covers ceil(n / 64) whole words
+	const uint64_t m = __ballot(i < n && agree[i] > v->keep_above);
+	if ((threadIdx.x & 63) == 0)
+		masks[i >> 6] = m;
+}
+
+__global__ void hop_first_kernel(const uint32_t *cand, WinnowVerdict *v)
+{
+	if (v->count)
+		v->cand0 = cand[0];
+}
+
+// ---- host side ------------------------------------------------------------------------
+// hop selection needs a GPU but none of the btbb_init() tables
+static int hop_device()
+{
+	if (ctx().ready)
+		return BTBBX_OK;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+		set_error("hop: no usable HIP device");
+		return BTBBX_E_NODEVICE;
+	}
+	return BTBBX_OK;
+}
+
+static bool hip_bad(hipError_t e, const char *what) { return e != hipSuccess && hip_fail(e, what) != 0; }
+
+static int hop_args(const btbbx_hop_cfg *cfg, HopArgs *h)
+{
+	if (!cfg) {
+		set_error("hop: NULL configuration");
+		return BTBBX_E_ARG;
+	}
+	const uint32_t address = cfg->address & 0xfffffff;
+	h->a1 = (address >> 23) & 0x1f;
+	h->b = (address >> 19) & 0x0f;
+	h->d1 = (address >> 10) & 0x1ff;
+	h->c1 = 0;
+	h->e = 0;
+	for (int i = 0; i < 5; i++)
+		h->c1 |= ((address >> (2 * i)) & 1) << i;
+	for (int i = 0; i < 7; i++)
+		h->e |= ((address >> (2 * i + 1)) & 1) << i;
+	h->afh = cfg->afh ? 1 : 0;
+	h->mod = cfg->afh ? cfg->used_channels : HOP_NCHAN;
+	if (h->mod == 0 || h->mod > 80) {
+		set_error("hop: AFH pattern with %u used channels", h->mod);
+		return BTBBX_E_ARG;
+	}
+	memcpy(h->bank, cfg->bank, sizeof(h->bank));
+	return BTBBX_OK;
+}
+
+struct btbbx_hop_reversal {
+	HopArgs h;
+	int aliased;
+	uint32_t n;               // candidates
+	uint32_t *d_cand[2];      // ping-pong lists, HOP_GROUPS entries each
+	int cur;
+	uint64_t *d_masks;        // HOP_GROUPS / 64 words
+	uint32_t *d_prefix;
+	uint16_t *d_agree;
+	uint32_t *d_hist;         // HOP_MAX_OBS + 1
+	HopObs *d_obs;
+	WinnowVerdict *d_verdict;
+	uint32_t *d_total;
+	hipStream_t stream;
+};
+
+extern "C" {
+
+void btbbx_hop_cfg_init(btbbx_hop_cfg *cfg, uint32_t address, const uint8_t *afh_map)
+{
+	memset(cfg, 0, sizeof(*cfg));
+	cfg->address = address & 0xfffffff;
+	int j = 0;
+	for (int i = 0; i < HOP_NCHAN; i++) {                       // precalc, bluetooth_piconet.c:171-194
+		const int chan = (2 * i) % HOP_NCHAN;
+		if (!afh_map)
+			cfg->bank[i] = (uint8_t)chan;
+		else if (afh_map[chan / 8] & (1 << (chan % 8)))
+			cfg->bank[j++] = (uint8_t)chan;
+	}
+	if (afh_map) {
+		cfg->afh = 1;
+		for (int i = 0; i < 10; i++)                        // btbb_piconet_set_afh_map, :122-131
+			cfg->used_channels += (uint8_t)__builtin_popcount(afh_map[i]);
+	} else {
+		cfg->used_channels = HOP_NCHAN;
+	}
+}
+
+int btbbx_hop_sequence_device(const btbbx_hop_cfg *cfg, uint64_t first, uint64_t count, uint8_t *d_sequence,
+			      void *hip_stream)
+{
+	int rc = hop_device();
+	if (rc)
+		return rc;
+	HopArgs h;
+	if ((rc = hop_args(cfg, &h)))
+		return rc;
+	if ((first & 63) || (count & 63) || first + count > BTBBX_SEQUENCE_LENGTH || !d_sequence ||
+	    ((uintptr_t)d_sequence & 15)) {
+		set_error("hop_sequence: range [%llu, +%llu) must be 64-aligned inside 2^27, buffer 16-byte aligned",
+			  (unsigned long long)first, (unsigned long long)count);
+		return BTBBX_E_ARG;
+	}
+	if (!count)
+		return BTBBX_OK;
+	const uint32_t nt = (uint32_t)(count >> 6);
+	hipLaunchKernelGGL(hop_sequence_kernel, dim3((nt + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, h,
+			   (uint32_t)(first >> 6), nt, (uint4 *)d_sequence);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+int btbbx_hop_channels_device(const btbbx_hop_cfg *cfg, const uint32_t *d_clocks, uint32_t n, uint8_t *d_channels,
+			      void *hip_stream)
+{
+	int rc = hop_device();
+	if (rc)
+		return rc;
+	HopArgs h;
+	if ((rc = hop_args(cfg, &h)))
+		return rc;
+	if (!n)
+		return BTBBX_OK;
+	hipLaunchKernelGGL(hop_channels_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, h, d_clocks, n,
+			   d_channels);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+void btbbx_hop_reversal_close(btbbx_hop_reversal *r)
+{
+	if (!r)
+		return;
+	void *bufs[] = {r->d_cand[0], r->d_cand[1], r->d_masks, r->d_prefix, r->d_agree, r->d_hist, r->d_obs,
+			r->d_verdict, r->d_total};
+	for (void *p : bufs)
+		if (p)
+			(void)hipFree(p);
+	if (r->stream)
+		(void)hipStreamDestroy(r->stream);
+	free(r);
+}
+
+static int reversal_compact(btbbx_hop_reversal *r, uint32_t nwords, const uint32_t *src, uint32_t base, uint32_t *dst)
+{
+	hipLaunchKernelGGL(hop_mask_prefix_kernel, dim3(1), dim3(1024), 0, r->stream, r->d_masks, nwords, r->d_prefix,
+			   r->d_total);
+	hipLaunchKernelGGL(hop_scatter_kernel, dim3((nwords + 255) / 256), dim3(256), 0, r->stream, r->d_masks, r->d_prefix,
+			   nwords, src, base, dst);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+btbbx_hop_reversal *btbbx_hop_reversal_open(const btbbx_hop_cfg *cfg, uint32_t clk6, uint8_t channel, int aliased,
+					    int *n_candidates)
+{
+	if (hop_device())
+		return nullptr;
+	btbbx_hop_reversal *r = (btbbx_hop_reversal *)calloc(1, sizeof(*r));
+	if (!r || hop_args(cfg, &r->h)) {
+		free(r);
+		return nullptr;
+	}
+	r->aliased = aliased != 0;
+	hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_cand[0], sizeof(uint32_t) * HOP_GROUPS);
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_cand[1], sizeof(uint32_t) * HOP_GROUPS);
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_masks, sizeof(uint64_t) * (HOP_GROUPS / 64));
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_prefix, sizeof(uint32_t) * (HOP_GROUPS / 64));
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_agree, sizeof(uint16_t) * HOP_GROUPS);
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_hist, sizeof(uint32_t) * (HOP_MAX_OBS + 1));
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_obs, sizeof(HopObs) * HOP_MAX_OBS);
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_verdict, sizeof(WinnowVerdict));
+	if (e == hipSuccess) e = hipMalloc((void **)&r->d_total, sizeof(uint32_t));
+	if (e != hipSuccess) {
+		hip_fail(e, "hop_reversal_open: allocation");
+		btbbx_hop_reversal_close(r);
+		return nullptr;
+	}
+	hipLaunchKernelGGL(hop_candidate_mask_kernel, dim3(HOP_GROUPS / 256), dim3(256), 0, r->stream, r->h, clk6 & 63u,
+			   (int)(int8_t)channel, r->aliased, r->d_masks);
+	uint32_t total = 0;
+	if (reversal_compact(r, HOP_GROUPS / 64, nullptr, clk6 & 63u, r->d_cand[0]) ||
+	    hip_bad(hipMemcpyAsync(&total, r->d_total, sizeof(total), hipMemcpyDeviceToHost, r->stream), "copy") ||
+	    hip_bad(hipStreamSynchronize(r->stream), "hop_reversal_open")) {
+		btbbx_hop_reversal_close(r);
+		return nullptr;
+	}
+	r->n = total;
+	r->cur = 0;
+	if (n_candidates)
+		*n_candidates = (int)total;
+	return r;
+}
+
+int btbbx_hop_reversal_winnow(btbbx_hop_reversal *r, const int32_t *index_offsets, const uint8_t *channels,
+			      uint32_t n_obs, uint32_t *stop, uint32_t *count, uint32_t *cand0)
+{
+	if (!r || (n_obs && (!index_offsets || !channels)) || n_obs > HOP_MAX_OBS) {
+		set_error("hop_reversal_winnow: bad arguments (n_obs %u)", n_obs);
+		return BTBBX_E_ARG;
+	}
+	WinnowVerdict v = {n_obs, r->n, 0, 0};
+	if (n_obs && r->n) {
+		HopObs obs[HOP_MAX_OBS];
+		for (uint32_t k = 0; k < n_obs; k++) {
+			obs[k].offset = index_offsets[k];
+			obs[k].channel = (int)(int8_t)channels[k];
+		}
+		const uint32_t n = r->n, nwords = (n + 63) / 64;
+		uint32_t *src = r->d_cand[r->cur], *dst = r->d_cand[r->cur ^ 1];
+		HIP_TRY(hipMemcpyAsync(r->d_obs, obs, sizeof(HopObs) * n_obs, hipMemcpyHostToDevice, r->stream));
+		HIP_TRY(hipMemsetAsync(r->d_hist, 0, sizeof(uint32_t) * (n_obs + 1), r->stream));
+		hipLaunchKernelGGL(hop_winnow_kernel, dim3((n + 255) / 256), dim3(256), 0, r->stream, r->h, src, n, r->d_obs,
+				   n_obs, r->aliased, r->d_agree, r->d_hist);
+		hipLaunchKernelGGL(hop_verdict_kernel, dim3(1), dim3(1024), 0, r->stream, r->d_hist, n, n_obs, r->d_verdict);
+		hipLaunchKernelGGL(hop_agree_mask_kernel, dim3((nwords * 64 + 255) / 256), dim3(256), 0, r->stream, r->d_agree,
+				   n, r->d_verdict, r->d_masks);
+		int rc = reversal_compact(r, nwords, src, 0, dst);
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(hop_first_kernel, dim3(1), dim3(1), 0, r->stream, dst, r->d_verdict);
+		HIP_TRY(hipMemcpyAsync(&v, r->d_verdict, sizeof(v), hipMemcpyDeviceToHost, r->stream));
+		HIP_TRY(hipStreamSynchronize(r->stream));
+		r->cur ^= 1;
+		r->n = v.count;
+	} else if (r->n) {
+		HIP_TRY(hipMemcpyAsync(&v.cand0, r->d_cand[r->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+		HIP_TRY(hipStreamSynchronize(r->stream));
+	}
+	if (stop) *stop = v.stop;
+	if (count) *count = v.count;
+	if (cand0) *cand0 = v.cand0;
+	return BTBBX_OK;
+}
+
+int64_t btbbx_hop_reversal_candidates(btbbx_hop_reversal *r, uint32_t *dst, uint64_t cap)
+{
+	if (!r)
+		return BTBBX_E_ARG;
+	const uint64_t k = r->n < cap ? r->n : cap;
+	if (k && dst) {
+		HIP_TRY(hipMemcpyAsync(dst, r->d_cand[r->cur], k * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+		HIP_TRY(hipStreamSynchronize(r->stream));
+	}
+	return (int64_t)r->n;
+}
+
+} // extern "C"

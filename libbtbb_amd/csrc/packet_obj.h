@@ -49,6 +49,13 @@ struct btbb_piconet {
 	uint8_t pattern_channels[PN_MAX_PATTERN];
 	int clk_offset;
 	uint32_t first_pkt_time;
+	// CLK1-27 reversal (bluetooth_piconet.h:38-40, 49-69)
+	int aliased;                        // never written through the public API, as in the reference
+	uint8_t bank[80];                   // frequency register bank of the last precalc
+	const struct btbbx_hop_cfg *pattern;// the reference's `sequence`: cached per address, NULL = none
+	struct btbbx_hop_reversal *reversal;// the reference's `clock_candidates`, kept in HBM
+	int num_candidates;
+	int winnowed;
 };
 
 // GPU round trips for one packet object (btbb_api.cpp)

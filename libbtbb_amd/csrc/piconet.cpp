@@ -8,8 +8,10 @@
 // packets of a piconet -- is replayed here on the host from that table, and a second launch
 // replays exactly the executed trials with all packet state written so that the packet
 // object ends up as the reference leaves it.
-// Hop reversal (CLK1-27, :170-645) is outside the hot path; where the reference would start
-// it we print a note and leave BTBB_CLK27_VALID clear.
+// CLK1-27 reversal (:365-413 pattern cache, :475-498 btbb_init_hop_reversal, :501-543 try_hop,
+// :575-645 winnowing) keeps the reference's host state machine; the hop selection itself and
+// the candidate lists live on the GPU (hop.hip), with no 128 MiB pattern table: what the
+// cache remembers per address is the 88-byte kernel configuration.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,6 +22,10 @@
 #include "../../include/btbb.h"
 
 static int survey_mode = 0;
+// pattern cache: like the reference's (whose uthash key length is 4 bytes, bluetooth_piconet.c:400,
+// 407) it is keyed by UAP << 24 | LAP only -- the first pattern made for an address wins, whatever
+// its AFH state was
+static std::unordered_map<uint32_t, btbbx_hop_cfg *> pattern_cache;
 static std::unordered_map<uint32_t, btbb_piconet *> survey_map;
 static std::vector<uint32_t> survey_order;
 
@@ -38,8 +44,10 @@ void btbb_piconet_ref(btbb_piconet *pn) { pn->refcount++; }
 void btbb_piconet_unref(btbb_piconet *pn)
 {
 	pn->refcount--;
-	if (pn->refcount == 0)
+	if (pn->refcount == 0) {
+		btbbx_hop_reversal_close(pn->reversal);
 		free(pn);
+	}
 }
 
 int btbb_init_survey(void)
@@ -123,6 +131,11 @@ void btbb_print_afh_map(btbb_piconet *pn)
 /* bluetooth_piconet.c:547-572 */
 static void piconet_reset(btbb_piconet *pn)
 {
+	if (btbb_piconet_get_flag(pn, BTBB_HOP_REVERSAL_INIT)) {
+		btbbx_hop_reversal_close(pn->reversal);
+		pn->reversal = NULL;
+		pn->pattern = NULL;
+	}
 	btbb_piconet_set_flag(pn, BTBB_GOT_FIRST_PACKET, 0);
 	btbb_piconet_set_flag(pn, BTBB_HOP_REVERSAL_INIT, 0);
 	btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 0);
@@ -259,25 +272,170 @@ btbb_piconet *btbb_next_survey_result(void)
 	return NULL;
 }
 
-/* try_hop, bluetooth_piconet.c:501-543, up to the hop-reversal boundary */
+/* get_hop_pattern + gen_hop_pattern, bluetooth_piconet.c:365-413 */
+static void get_hop_pattern(btbb_piconet *pn)
+{
+	const uint32_t key = ((uint32_t)pn->UAP << 24) | pn->LAP;
+	auto it = pattern_cache.find(key);
+	if (it != pattern_cache.end()) {
+		printf("\nFound hopping sequence in cache.\n");
+		pn->pattern = it->second;
+		return;
+	}
+	printf("\nCalculating complete hopping sequence.\n");
+	const int afh = btbb_piconet_get_flag(pn, BTBB_IS_AFH);
+	int j = 0;
+	for (int i = 0; i < 79; i++) {                 /* precalc, :171-194: the bank persists in the piconet */
+		const int chan = (i * 2) % 79;
+		if (!afh)
+			pn->bank[i] = (uint8_t)chan;
+		else if (btbb_piconet_get_channel_seen(pn, (uint8_t)chan))
+			pn->bank[j++] = (uint8_t)chan;
+	}
+	btbbx_hop_cfg *cfg = (btbbx_hop_cfg *)calloc(1, sizeof(*cfg));
+	cfg->address = key & 0xfffffff;
+	cfg->afh = (uint8_t)afh;
+	cfg->used_channels = pn->used_channels;
+	memcpy(cfg->bank, pn->bank, sizeof(cfg->bank));
+	pattern_cache[key] = cfg;
+	pn->pattern = cfg;
+	printf("Hopping sequence calculated.\n");
+}
+
+void btbb_piconet_set_afh_map(btbb_piconet *pn, uint8_t *afh_map)
+{
+	pn->used_channels = 0;
+	for (int i = 0; i < 10; i++) {
+		pn->afh_map[i] = afh_map[i];
+		pn->used_channels += (uint8_t)__builtin_popcount(afh_map[i]);
+	}
+	if (btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
+		get_hop_pattern(pn);
+}
+
+/* bluetooth_piconet.c:475-498; init_candidates (:455-472) is one GPU pass over the 2^21 clocks
+ * that agree with the known CLK1-6 */
+int btbb_init_hop_reversal(int aliased, btbb_piconet *pn)
+{
+	get_hop_pattern(pn);
+	btbbx_hop_reversal_close(pn->reversal);    /* the reference leaks the previous list */
+	const uint32_t clock = ((uint32_t)pn->clk_offset + pn->first_pkt_time) & 0x3f;
+	int n = 0;
+	pn->reversal = btbbx_hop_reversal_open(pn->pattern, clock, pn->pattern_channels[0], pn->aliased, &n);
+	if (!pn->reversal)
+		fprintf(stderr, "btbb_init_hop_reversal: GPU path failed: %s\n", btbbx_last_error());
+	pn->num_candidates = n;
+	pn->winnowed = 0;
+	btbb_piconet_set_flag(pn, BTBB_HOP_REVERSAL_INIT, 1);
+	btbb_piconet_set_flag(pn, BTBB_CLK27_VALID, 0);
+	btbb_piconet_set_flag(pn, BTBB_IS_ALIASED, aliased);
+	printf("%d initial CLK1-27 candidates\n", pn->num_candidates);
+	return pn->num_candidates;
+}
+
+/* btbb_winnow + channel_winnow, bluetooth_piconet.c:575-645.  All observations not yet used go
+ * to the GPU in one call, which stops where the reference's loop would `break`; the host then
+ * replays the loop's side effects (flags, clk_offset, reset, AFH heuristics) in order. */
+int btbb_winnow(btbb_piconet *pn)
+{
+	int new_count = pn->num_candidates;
+	if (pn->winnowed >= pn->packets_observed || !pn->reversal)
+		return new_count;
+	const uint32_t n_obs = (uint32_t)(pn->packets_observed - pn->winnowed);
+	uint32_t stop = 0, count = 0, cand0 = 0;
+	if (btbbx_hop_reversal_winnow(pn->reversal, pn->pattern_indices + pn->winnowed,
+				      pn->pattern_channels + pn->winnowed, n_obs, &stop, &count, &cand0)) {
+		fprintf(stderr, "btbb_winnow: GPU path failed: %s\n", btbbx_last_error());
+		return new_count;
+	}
+	for (uint32_t k = 0; k < n_obs; k++, pn->winnowed++) {
+		const int w = pn->winnowed;
+		const int index = pn->pattern_indices[w];
+		const uint8_t channel = pn->pattern_channels[w];
+		if (k == stop) {                           /* this hop leaves <= 1 candidate */
+			pn->num_candidates = new_count = (int)count;
+			if (count == 1) {
+				pn->clk_offset = (int)((cand0 << 1) - (pn->first_pkt_time << 1));
+				printf("\nAcquired CLK1-27 = 0x%07x\n", cand0);
+				btbb_piconet_set_flag(pn, BTBB_CLK27_VALID, 1);
+			} else {
+				piconet_reset(pn);
+			}
+			return new_count;                  /* pn->winnowed stays, as after the reference's break */
+		}
+		/* The reference also looks one entry below both arrays when w == 0 (:627-628), i.e. at
+		 * clock6_candidates[63] and at the top byte of pattern_indices[999]; same values here. */
+		const int last_index = w > 0 ? pn->pattern_indices[w - 1] : pn->clock6_candidates[63];
+		const uint8_t last_channel = w > 0 ? pn->pattern_channels[w - 1]
+						   : (uint8_t)((uint32_t)pn->pattern_indices[PN_MAX_PATTERN - 1] >> 24);
+		if (!btbb_piconet_get_flag(pn, BTBB_LOOKS_LIKE_AFH) && index == last_index + 1 &&
+		    channel == last_channel) {
+			btbb_piconet_set_flag(pn, BTBB_LOOKS_LIKE_AFH, 1);
+			printf("Hopping pattern appears to be AFH\n");
+		}
+	}
+	pn->num_candidates = new_count = (int)count;
+	return new_count;
+}
+
+/* try_hop, bluetooth_piconet.c:501-543 */
 static void try_hop(btbb_packet *pkt, btbb_piconet *pn)
 {
 	uint8_t filter_uap = pn->UAP;
 	btbb_decode(pkt);
 	if (btbb_piconet_get_flag(pn, BTBB_HOP_REVERSAL_INIT)) {
-		fprintf(stderr, "btbb: CLK1-27 hop reversal is not part of this build\n");
+		if (pn->packets_observed < PN_MAX_PATTERN) {   /* the reference writes past the arrays here */
+			pn->pattern_indices[pn->packets_observed] = (int)(pkt->clkn - pn->first_pkt_time);
+			pn->pattern_channels[pn->packets_observed] = pkt->channel;
+			pn->packets_observed++;
+			pn->total_packets_observed++;
+		}
+		btbb_winnow(pn);
+		if (btbb_piconet_get_flag(pn, BTBB_CLK27_VALID)) {
+			printf("got CLK1-27\n");
+			printf("clock offset = %d.\n", pn->clk_offset);
+		}
 	} else if (btbb_piconet_get_flag(pn, BTBB_CLK6_VALID)) {
 		btbb_uap_from_header(pkt, pn);
+		if (btbb_piconet_get_flag(pn, BTBB_CLK27_VALID)) {
+			printf("got CLK1-27\n");
+			printf("clock offset = %d.\n", pn->clk_offset);
+		}
 	} else if (btbb_uap_from_header(pkt, pn)) {
-		if (filter_uap == pn->UAP)
-			fprintf(stderr, "btbb: UAP confirmed; CLK1-27 hop reversal is not part of this build\n");
-		else
+		if (filter_uap == pn->UAP) {
+			btbb_init_hop_reversal(0, pn);
+			btbb_winnow(pn);
+		} else {
 			printf("failed to confirm UAP\n");
+		}
 	}
 	if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID)) {
 		btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 1);
 		pn->UAP = filter_uap;
 	}
+}
+
+int64_t btbbx_piconet_state(const void *piconet, int field)
+{
+	const btbb_piconet *pn = (const btbb_piconet *)piconet;
+	switch (field) {
+	case 0: return pn->num_candidates;
+	case 1: return pn->winnowed;
+	case 2: return pn->packets_observed;
+	case 3: return pn->total_packets_observed;
+	case 4: return pn->first_pkt_time;
+	case 5: return pn->flags;
+	case 6: return pn->used_channels;
+	default: return BTBBX_E_ARG;
+	}
+}
+
+int64_t btbbx_piconet_candidates(const void *piconet, uint32_t *dst, uint64_t cap)
+{
+	const btbb_piconet *pn = (const btbb_piconet *)piconet;
+	if (!pn->reversal)
+		return 0;
+	return btbbx_hop_reversal_candidates(pn->reversal, dst, cap);
 }
 
 /* bluetooth_piconet.c:851-899 */

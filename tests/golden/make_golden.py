@@ -13,6 +13,10 @@ source text.  Re-run:  python tests/golden/make_golden.py
                       FEC-1/3 headers): per packet the 64-clock table {try_clock, type,
                       crc_check} and btbb_header_present / btbb_decode_header /
                       btbb_decode_payload results for the true clock
+  hop.json         -- per piconet address (with and without AFH): digests of the whole 2^27-entry
+                      hop pattern gen_hops produces, its first 512 channels, and a CLK1-27
+                      reversal trace (btbb_init_hop_reversal / btbb_winnow: return values,
+                      candidate counts, flags, clk_offset, surviving clocks) for seeded hops
 """
 import ctypes as C
 import json
@@ -37,10 +41,69 @@ SCAN_CASES = [
 ]
 
 
+HOP_CASES = [   # lap, uap, used channels (None = basic hopping), aliased receiver
+    (0x9E8B33, 0x47, None, 0), (0x654321, 0x00, None, 0), (0xABCDEF, 0xE1, 57, 0), (0x2A96EF, 0x25, None, 1),
+]
+
+
+def make_hop(ref):
+    import hashlib
+    import zlib
+    import _hop
+    rng = np.random.default_rng(4242)
+    out = {"_generator": "tests/golden/make_golden.py", "cases": []}
+    for lap, uap, used, alias in HOP_CASES:
+        amap = _hop.afh_map_bytes(rng, used) if used else None
+        r = C.c_void_p(ref.btbb_piconet_new())
+        ref.btbb_init_piconet(r, lap)
+        ref.btbb_piconet_set_uap(r, uap)
+        if amap is not None:
+            ref.btbb_piconet_set_flag(r, _hop.F_IS_AFH, 1)
+            ref.btbb_piconet_set_afh_map(r, _libs.ptr(amap))
+        else:
+            ref.btbb_piconet_set_channel_seen(r, 0)
+            ref.get_hop_pattern(r)
+        seq = _hop.seq_view(ref.refint_piconet_sequence(r))
+        case = dict(lap=lap, uap=uap, afh_map=None if amap is None else amap.tolist(), aliased=alias,
+                    sha256=hashlib.sha256(seq.tobytes()).hexdigest(),
+                    crc32_per_mib=[zlib.crc32(seq[i << 20:(i + 1) << 20].tobytes()) for i in range(128)],
+                    head=seq[:512].tolist())
+        # reversal trace
+        c0, t0 = int(rng.integers(0, _hop.SEQ_LEN)), int(rng.integers(0, 1 << 27))
+        ref.refint_piconet_set_first_pkt_time(r, t0)
+        ref.btbb_piconet_set_clk_offset(r, ((c0 & 63) - (t0 & 63)) & 63)
+        ref.refint_piconet_set_aliased(r, alias)
+        obs = _hop.observations(rng, seq, c0, 12, alias=bool(alias))
+        trace = []
+
+        def snap(rv):
+            n = ref.refint_piconet_num_candidates(r)
+            cand = ref.refint_piconet_clock_candidates(r)
+            hop_init = ref.refint_piconet_flags(r) >> _hop.F_HOP_INIT & 1
+            trace.append(dict(rv=rv, n=n, winnowed=ref.refint_piconet_winnowed(r), flags=ref.refint_piconet_flags(r),
+                              clk_offset=ref.btbb_piconet_get_clk_offset(r),
+                              cand_crc=zlib.crc32(np.array([cand[i] for i in range(n)], "<u4").tobytes()) if hop_init else 0,
+                              cand_head=[cand[i] for i in range(min(n, 8))] if hop_init else []))
+        ref.refint_piconet_observe(r, *obs[0])
+        snap(ref.btbb_init_hop_reversal(alias, r))
+        for idx, ch in obs[1:]:
+            ref.refint_piconet_observe(r, idx, ch)
+            snap(ref.btbb_winnow(r))
+            if trace[-1]["n"] <= 1:
+                break
+        case.update(c0=c0, t0=t0, obs=[list(o) for o in obs[:len(trace)]], trace=trace)
+        out["cases"].append(case)
+    json.dump(out, open(os.path.join(HERE, "hop.json"), "w"), separators=(",", ":"))
+    print("wrote hop.json (%d cases)" % len(out["cases"]))
+
+
 def main():
     ref = _libs.ref()
     assert ref is not None, "needs /root/reference (run in the build container)"
     ref.btbb_init(2)
+    make_hop(ref)
+    if "--hop-only" in sys.argv:
+        return
 
     scan = {"_generator": "tests/golden/make_golden.py", "init_max_ac_errors": 2, "cases": []}
     for case in SCAN_CASES:

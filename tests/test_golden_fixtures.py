@@ -109,3 +109,40 @@ def test_gpu_packets_match_reference_fixture():
             assert (int(o["type"]), int(o["lt_addr"]), int(o["hdr_flags"]), int(o["hec"]),
                     int(o["payload_length"]), int(o["payload_header_length"])) == tuple(int(x) for x in d[3:9]), i
             assert (synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744) == payload[i]).all(), i
+
+
+HOP = json.load(open(os.path.join(HERE, "golden", "hop.json")))
+
+
+@pytest.mark.parametrize("case", HOP["cases"], ids=lambda c: "%06x" % c["lap"])
+def test_oracle_hop_matches_reference_fixture(case):
+    """Whole hop pattern digests and a CLK1-27 reversal trace recorded from the reference."""
+    import ctypes as C
+    import hashlib
+    import zlib
+    import _hop
+    orc = _libs.oracle()
+    amap = None if case["afh_map"] is None else np.array(case["afh_map"], np.uint8)
+    pn, seq = _hop.orc_pattern(orc, case["lap"], case["uap"], amap)
+    assert seq[:512].tolist() == case["head"]
+    assert [zlib.crc32(seq[i << 20:(i + 1) << 20].tobytes()) for i in range(128)] == case["crc32_per_mib"]
+    assert hashlib.sha256(seq.tobytes()).hexdigest() == case["sha256"]
+    c = pn.contents
+    c.first_pkt_time = case["t0"]
+    c.clk_offset = ((case["c0"] & 63) - (case["t0"] & 63)) & 63
+    c.aliased = case["aliased"]
+    for k, ((idx, ch), want) in enumerate(zip(case["obs"], case["trace"])):
+        c.pattern_indices[c.packets_observed] = idx
+        c.pattern_channels[c.packets_observed] = ch
+        c.packets_observed += 1
+        c.total_packets_observed += 1
+        rv = orc.orc_init_hop_reversal(case["aliased"], pn) if k == 0 else orc.orc_winnow(pn)
+        assert (rv, c.num_candidates, c.winnowed, c.flags, c.clk_offset) == \
+            (want["rv"], want["n"], want["winnowed"], want["flags"], want["clk_offset"]), k
+        if c.flags >> _hop.F_HOP_INIT & 1:
+            cand = np.array([c.clock_candidates[i] for i in range(c.num_candidates)], "<u4")
+            assert zlib.crc32(cand.tobytes()) == want["cand_crc"]
+            assert cand[:8].tolist() == want["cand_head"]
+    assert case["trace"][-1]["n"] == 1 and c.clock_candidates[0] == case["c0"]
+    orc.orc_piconet_free(pn)
+    orc.orc_hop_cache_clear()
