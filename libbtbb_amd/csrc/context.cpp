@@ -231,9 +231,12 @@ extern "C" int btbbx_init(int max_ac_errors)
 	return BTBBX_OK;
 }
 
+void hop_pool_release();     // hop.hip
+
 extern "C" void btbbx_shutdown(void)
 {
 	Ctx &c = g_ctx;
+	hop_pool_release();
 	if (c.d_tab_block) (void)hipFree(c.d_tab_block);
 	if (c.d_hslots) (void)hipFree(c.d_hslots);
 	if (c.d_scratch) (void)hipFree(c.d_scratch);

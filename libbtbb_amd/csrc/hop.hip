@@ -14,6 +14,8 @@
 // ballot masks + a prefix over mask words + an ordered scatter.
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 #define HOP_NCHAN   79
@@ -285,6 +287,85 @@ __global__ __launch_bounds__(256) void hop_agree_mask_kernel(const uint16_t *agr
 		masks[i >> 6] = m;
 }
 
+
+// One workgroup does a whole winnowing call for short lists (the common case after the first
+// observed hop): agreement counts, verdict and ordered compaction in a single launch.
+#define HOP_SMALL_N 16384
+__global__ __launch_bounds__(1024) void hop_winnow_small_kernel(HopArgs h, const uint32_t *cand, uint32_t n,
+								 const HopObs *obs, uint32_t n_obs, int aliased,
+								 uint32_t *dst, WinnowVerdict *v)
+{
+	__shared__ uint8_t tab[HOP_TAB];
+	__shared__ uint16_t agree[HOP_SMALL_N];
+	__shared__ uint32_t cum[1024];
+	__shared__ uint32_t wave_cnt[16];
+	__shared__ uint32_t first, base;
+	const uint32_t tid = threadIdx.x;
+	if (tid < 256) {
+		tab[tid] = h.bank[tid % h.mod];
+		if (tid < HOP_TAB - 256)
+			tab[256 + tid] = h.bank[(256 + tid) % h.mod];
+	}
+	cum[tid] = 0;
+	if (tid == 0) {
+		first = n_obs;
+		base = 0;
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += 1024) {
+		const uint32_t c = cand[i];
+		uint32_t k = 0;
+		for (; k < n_obs; k++) {
+			const HopObs o = obs[k];
+			const uint32_t idx = (c + (uint32_t)o.offset) & (BTBBX_SEQUENCE_LENGTH - 1);
+			if (hop_observable(tab[hop_tab_index(h, idx)], aliased) != o.channel)
+				break;
+		}
+		agree[i] = (uint16_t)k;
+		if (k < n_obs)
+			atomicAdd(&cum[k], 1u);                 // first mismatch at observation k
+	}
+	__syncthreads();
+	for (uint32_t step = 1; step < 1024; step <<= 1) {
+		const uint32_t x = tid >= step ? cum[tid - step] : 0;
+		__syncthreads();
+		cum[tid] += x;
+		__syncthreads();
+	}
+	if (tid < n_obs && n - cum[tid] <= 1)
+		atomicMin(&first, tid);
+	__syncthreads();
+	const uint32_t keep = first < n_obs ? first : n_obs - 1;
+	for (uint32_t i0 = 0; i0 < n; i0 += 1024) {                 // ordered compaction, 1024 at a time
+		const uint32_t i = i0 + tid;
+		const bool live = i < n && agree[i] > keep;
+		const uint64_t m = __ballot(live);
+		if ((tid & 63) == 0)
+			wave_cnt[tid >> 6] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t before = base;
+		for (uint32_t w = 0; w < (tid >> 6); w++)
+			before += wave_cnt[w];
+		if (live)
+			dst[before + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1))] = cand[i];
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t all = 0;
+			for (int w = 0; w < 16; w++)
+				all += wave_cnt[w];
+			base += all;
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		v->stop = first;
+		v->keep_above = keep;
+		v->count = n - cum[keep];
+		v->cand0 = 0;
+	}
+}
+
+// cand0 of the verdict, read after the compaction on the same stream
 __global__ void hop_first_kernel(const uint32_t *cand, WinnowVerdict *v)
 {
 	if (v->count)
@@ -333,12 +414,11 @@ static int hop_args(const btbbx_hop_cfg *cfg, HopArgs *h)
 	return BTBBX_OK;
 }
 
-struct btbbx_hop_reversal {
-	HopArgs h;
-	int aliased;
-	uint32_t n;               // candidates
+// Device and pinned buffers of one reversal; recycled through a small pool because a handle is
+// opened per piconet and per restart (hipMalloc/hipHostMalloc cost far more than the kernels).
+struct HopWorkspace {
+	void *d_block;            // one allocation, carved below
 	uint32_t *d_cand[2];      // ping-pong lists, HOP_GROUPS entries each
-	int cur;
 	uint64_t *d_masks;        // HOP_GROUPS / 64 words
 	uint32_t *d_prefix;
 	uint16_t *d_agree;
@@ -346,7 +426,103 @@ struct btbbx_hop_reversal {
 	HopObs *d_obs;
 	WinnowVerdict *d_verdict;
 	uint32_t *d_total;
+	void *h_block;            // pinned: observations going in, verdict / total coming back
+	HopObs *h_obs;
+	WinnowVerdict *h_verdict;
+	uint32_t *h_total;
 	hipStream_t stream;
+};
+
+static std::mutex pool_lock;
+static std::vector<HopWorkspace *> pool;
+#define HOP_POOL_MAX 8
+
+static void workspace_free(HopWorkspace *w)
+{
+	if (!w)
+		return;
+	if (w->d_block)
+		(void)hipFree(w->d_block);
+	if (w->h_block)
+		(void)hipHostFree(w->h_block);
+	if (w->stream)
+		(void)hipStreamDestroy(w->stream);
+	free(w);
+}
+
+static HopWorkspace *workspace_get()
+{
+	{
+		std::lock_guard<std::mutex> g(pool_lock);
+		if (!pool.empty()) {
+			HopWorkspace *w = pool.back();
+			pool.pop_back();
+			return w;
+		}
+	}
+	HopWorkspace *w = (HopWorkspace *)calloc(1, sizeof(*w));
+	if (!w)
+		return nullptr;
+	size_t off = 0;
+	auto carve = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	const size_t o_c0 = carve(sizeof(uint32_t) * HOP_GROUPS), o_c1 = carve(sizeof(uint32_t) * HOP_GROUPS);
+	const size_t o_m = carve(sizeof(uint64_t) * (HOP_GROUPS / 64)), o_p = carve(sizeof(uint32_t) * (HOP_GROUPS / 64));
+	const size_t o_a = carve(sizeof(uint16_t) * HOP_GROUPS), o_h = carve(sizeof(uint32_t) * (HOP_MAX_OBS + 1));
+	const size_t o_o = carve(sizeof(HopObs) * HOP_MAX_OBS), o_v = carve(sizeof(WinnowVerdict)), o_t = carve(sizeof(uint32_t));
+	hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+	if (e == hipSuccess)
+		e = hipMalloc(&w->d_block, off);
+	if (e == hipSuccess)
+		e = hipHostMalloc(&w->h_block, sizeof(HopObs) * HOP_MAX_OBS + 256, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		hip_fail(e, "hop workspace allocation");
+		workspace_free(w);
+		return nullptr;
+	}
+	char *d = (char *)w->d_block, *hp = (char *)w->h_block;
+	w->d_cand[0] = (uint32_t *)(d + o_c0);
+	w->d_cand[1] = (uint32_t *)(d + o_c1);
+	w->d_masks = (uint64_t *)(d + o_m);
+	w->d_prefix = (uint32_t *)(d + o_p);
+	w->d_agree = (uint16_t *)(d + o_a);
+	w->d_hist = (uint32_t *)(d + o_h);
+	w->d_obs = (HopObs *)(d + o_o);
+	w->d_verdict = (WinnowVerdict *)(d + o_v);
+	w->d_total = (uint32_t *)(d + o_t);
+	w->h_obs = (HopObs *)hp;
+	w->h_verdict = (WinnowVerdict *)(hp + sizeof(HopObs) * HOP_MAX_OBS);
+	w->h_total = (uint32_t *)(hp + sizeof(HopObs) * HOP_MAX_OBS + 64);
+	return w;
+}
+
+void hop_pool_release()        // btbbx_shutdown
+{
+	std::lock_guard<std::mutex> g(pool_lock);
+	for (HopWorkspace *w : pool)
+		workspace_free(w);
+	pool.clear();
+}
+
+static void workspace_put(HopWorkspace *w)
+{
+	if (!w)
+		return;
+	{
+		std::lock_guard<std::mutex> g(pool_lock);
+		if (pool.size() < HOP_POOL_MAX) {
+			pool.push_back(w);
+			return;
+		}
+	}
+	workspace_free(w);
+}
+
+struct btbbx_hop_reversal {
+	HopArgs h;
+	int aliased;
+	uint32_t n;               // candidates
+	int cur;                  // which of the two lists is current
+	HopWorkspace *w;
 };
 
 extern "C" {
@@ -417,21 +593,16 @@ void btbbx_hop_reversal_close(btbbx_hop_reversal *r)
 {
 	if (!r)
 		return;
-	void *bufs[] = {r->d_cand[0], r->d_cand[1], r->d_masks, r->d_prefix, r->d_agree, r->d_hist, r->d_obs,
-			r->d_verdict, r->d_total};
-	for (void *p : bufs)
-		if (p)
-			(void)hipFree(p);
-	if (r->stream)
-		(void)hipStreamDestroy(r->stream);
+	workspace_put(r->w);
 	free(r);
 }
 
 static int reversal_compact(btbbx_hop_reversal *r, uint32_t nwords, const uint32_t *src, uint32_t base, uint32_t *dst)
 {
-	hipLaunchKernelGGL(hop_mask_prefix_kernel, dim3(1), dim3(1024), 0, r->stream, r->d_masks, nwords, r->d_prefix,
-			   r->d_total);
-	hipLaunchKernelGGL(hop_scatter_kernel, dim3((nwords + 255) / 256), dim3(256), 0, r->stream, r->d_masks, r->d_prefix,
+	HopWorkspace *w = r->w;
+	hipLaunchKernelGGL(hop_mask_prefix_kernel, dim3(1), dim3(1024), 0, w->stream, w->d_masks, nwords, w->d_prefix,
+			   w->d_total);
+	hipLaunchKernelGGL(hop_scatter_kernel, dim3((nwords + 255) / 256), dim3(256), 0, w->stream, w->d_masks, w->d_prefix,
 			   nwords, src, base, dst);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
@@ -443,39 +614,24 @@ btbbx_hop_reversal *btbbx_hop_reversal_open(const btbbx_hop_cfg *cfg, uint32_t c
 	if (hop_device())
 		return nullptr;
 	btbbx_hop_reversal *r = (btbbx_hop_reversal *)calloc(1, sizeof(*r));
-	if (!r || hop_args(cfg, &r->h)) {
+	if (!r || hop_args(cfg, &r->h) || !(r->w = workspace_get())) {
 		free(r);
 		return nullptr;
 	}
+	HopWorkspace *w = r->w;
 	r->aliased = aliased != 0;
-	hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_cand[0], sizeof(uint32_t) * HOP_GROUPS);
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_cand[1], sizeof(uint32_t) * HOP_GROUPS);
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_masks, sizeof(uint64_t) * (HOP_GROUPS / 64));
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_prefix, sizeof(uint32_t) * (HOP_GROUPS / 64));
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_agree, sizeof(uint16_t) * HOP_GROUPS);
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_hist, sizeof(uint32_t) * (HOP_MAX_OBS + 1));
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_obs, sizeof(HopObs) * HOP_MAX_OBS);
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_verdict, sizeof(WinnowVerdict));
-	if (e == hipSuccess) e = hipMalloc((void **)&r->d_total, sizeof(uint32_t));
-	if (e != hipSuccess) {
-		hip_fail(e, "hop_reversal_open: allocation");
+	hipLaunchKernelGGL(hop_candidate_mask_kernel, dim3(HOP_GROUPS / 256), dim3(256), 0, w->stream, r->h, clk6 & 63u,
+			   (int)(int8_t)channel, r->aliased, w->d_masks);
+	if (reversal_compact(r, HOP_GROUPS / 64, nullptr, clk6 & 63u, w->d_cand[0]) ||
+	    hip_bad(hipMemcpyAsync(w->h_total, w->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream), "copy") ||
+	    hip_bad(hipStreamSynchronize(w->stream), "hop_reversal_open")) {
 		btbbx_hop_reversal_close(r);
 		return nullptr;
 	}
-	hipLaunchKernelGGL(hop_candidate_mask_kernel, dim3(HOP_GROUPS / 256), dim3(256), 0, r->stream, r->h, clk6 & 63u,
-			   (int)(int8_t)channel, r->aliased, r->d_masks);
-	uint32_t total = 0;
-	if (reversal_compact(r, HOP_GROUPS / 64, nullptr, clk6 & 63u, r->d_cand[0]) ||
-	    hip_bad(hipMemcpyAsync(&total, r->d_total, sizeof(total), hipMemcpyDeviceToHost, r->stream), "copy") ||
-	    hip_bad(hipStreamSynchronize(r->stream), "hop_reversal_open")) {
-		btbbx_hop_reversal_close(r);
-		return nullptr;
-	}
-	r->n = total;
+	r->n = *w->h_total;
 	r->cur = 0;
 	if (n_candidates)
-		*n_candidates = (int)total;
+		*n_candidates = (int)r->n;
 	return r;
 }
 
@@ -486,33 +642,42 @@ int btbbx_hop_reversal_winnow(btbbx_hop_reversal *r, const int32_t *index_offset
 		set_error("hop_reversal_winnow: bad arguments (n_obs %u)", n_obs);
 		return BTBBX_E_ARG;
 	}
+	HopWorkspace *w = r->w;
 	WinnowVerdict v = {n_obs, r->n, 0, 0};
 	if (n_obs && r->n) {
-		HopObs obs[HOP_MAX_OBS];
 		for (uint32_t k = 0; k < n_obs; k++) {
-			obs[k].offset = index_offsets[k];
-			obs[k].channel = (int)(int8_t)channels[k];
+			w->h_obs[k].offset = index_offsets[k];
+			w->h_obs[k].channel = (int)(int8_t)channels[k];
 		}
 		const uint32_t n = r->n, nwords = (n + 63) / 64;
-		uint32_t *src = r->d_cand[r->cur], *dst = r->d_cand[r->cur ^ 1];
-		HIP_TRY(hipMemcpyAsync(r->d_obs, obs, sizeof(HopObs) * n_obs, hipMemcpyHostToDevice, r->stream));
-		HIP_TRY(hipMemsetAsync(r->d_hist, 0, sizeof(uint32_t) * (n_obs + 1), r->stream));
-		hipLaunchKernelGGL(hop_winnow_kernel, dim3((n + 255) / 256), dim3(256), 0, r->stream, r->h, src, n, r->d_obs,
-				   n_obs, r->aliased, r->d_agree, r->d_hist);
-		hipLaunchKernelGGL(hop_verdict_kernel, dim3(1), dim3(1024), 0, r->stream, r->d_hist, n, n_obs, r->d_verdict);
-		hipLaunchKernelGGL(hop_agree_mask_kernel, dim3((nwords * 64 + 255) / 256), dim3(256), 0, r->stream, r->d_agree,
-				   n, r->d_verdict, r->d_masks);
-		int rc = reversal_compact(r, nwords, src, 0, dst);
-		if (rc)
-			return rc;
-		hipLaunchKernelGGL(hop_first_kernel, dim3(1), dim3(1), 0, r->stream, dst, r->d_verdict);
-		HIP_TRY(hipMemcpyAsync(&v, r->d_verdict, sizeof(v), hipMemcpyDeviceToHost, r->stream));
-		HIP_TRY(hipStreamSynchronize(r->stream));
+		uint32_t *src = w->d_cand[r->cur], *dst = w->d_cand[r->cur ^ 1];
+		HIP_TRY(hipMemcpyAsync(w->d_obs, w->h_obs, sizeof(HopObs) * n_obs, hipMemcpyHostToDevice, w->stream));
+		if (n <= HOP_SMALL_N) {
+			hipLaunchKernelGGL(hop_winnow_small_kernel, dim3(1), dim3(1024), 0, w->stream, r->h, src, n, w->d_obs,
+					   n_obs, r->aliased, dst, w->d_verdict);
+		} else {
+			HIP_TRY(hipMemsetAsync(w->d_hist, 0, sizeof(uint32_t) * (n_obs + 1), w->stream));
+			hipLaunchKernelGGL(hop_winnow_kernel, dim3((n + 255) / 256), dim3(256), 0, w->stream, r->h, src, n,
+					   w->d_obs, n_obs, r->aliased, w->d_agree, w->d_hist);
+			hipLaunchKernelGGL(hop_verdict_kernel, dim3(1), dim3(1024), 0, w->stream, w->d_hist, n, n_obs,
+					   w->d_verdict);
+			hipLaunchKernelGGL(hop_agree_mask_kernel, dim3((nwords * 64 + 255) / 256), dim3(256), 0, w->stream,
+					   w->d_agree, n, w->d_verdict, w->d_masks);
+			int rc = reversal_compact(r, nwords, src, 0, dst);
+			if (rc)
+				return rc;
+		}
+		hipLaunchKernelGGL(hop_first_kernel, dim3(1), dim3(1), 0, w->stream, dst, w->d_verdict);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(w->h_verdict, w->d_verdict, sizeof(v), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		v = *w->h_verdict;
 		r->cur ^= 1;
 		r->n = v.count;
 	} else if (r->n) {
-		HIP_TRY(hipMemcpyAsync(&v.cand0, r->d_cand[r->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-		HIP_TRY(hipStreamSynchronize(r->stream));
+		HIP_TRY(hipMemcpyAsync(w->h_total, w->d_cand[r->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		v.cand0 = *w->h_total;
 	}
 	if (stop) *stop = v.stop;
 	if (count) *count = v.count;
@@ -526,8 +691,8 @@ int64_t btbbx_hop_reversal_candidates(btbbx_hop_reversal *r, uint32_t *dst, uint
 		return BTBBX_E_ARG;
 	const uint64_t k = r->n < cap ? r->n : cap;
 	if (k && dst) {
-		HIP_TRY(hipMemcpyAsync(dst, r->d_cand[r->cur], k * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-		HIP_TRY(hipStreamSynchronize(r->stream));
+		HIP_TRY(hipMemcpyAsync(dst, r->w->d_cand[r->cur], k * sizeof(uint32_t), hipMemcpyDeviceToHost, r->w->stream));
+		HIP_TRY(hipStreamSynchronize(r->w->stream));
 	}
 	return (int64_t)r->n;
 }
