@@ -23,9 +23,10 @@
 #define TABA_BITS      13                  // window bits 32..44
 #define TABB_BITS      12                  // window bits 45..56
 #define BITMAP_BITS    19                  // projection width of the candidate bitmap
-#define QRING          256                 // per-wave candidate ring (entries)
+#define QRING          128                 // per-wave candidate ring (entries; it never holds more than 127)
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
-#define PARK_SLOTS     4                   // private candidate slots per lane
+#define PARK_SLOTS     2                   // private candidate slots per lane
+#define CAND_BYTES     12                  // a parked candidate: position code + its 64-bit window
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
 // probe needs no address adds.
@@ -35,9 +36,9 @@
 #define LDS_OFF_TABB     0u
 #define LDS_OFF_TABA     (LDS_OFF_TABB + 4u * LDS_TABB_WORDS)
 #define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
-#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING u32
-#define LDS_OFF_PARK     (LDS_OFF_QUEUE + 4u * SCAN_WAVES * QRING)            // 16 x 64 x PARK_SLOTS u32
-#define SCAN_LDS_BYTES   (LDS_OFF_PARK + 4u * SCAN_WAVES * 64u * PARK_SLOTS)
+#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING candidates
+#define LDS_OFF_PARK     (LDS_OFF_QUEUE + CAND_BYTES * SCAN_WAVES * QRING)    // 16 x 64 x PARK_SLOTS candidates
+#define SCAN_LDS_BYTES   (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // = 160 KiB, all of it
 
 // ---- device-side table bundle -----------------------------------------------------
 struct ScanTables {

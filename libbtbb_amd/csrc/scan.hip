@@ -81,12 +81,11 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, 
 
 // The exact acceptance rule of promiscuous_packet_search for one offset that passed the
 // barker filter (bluetooth_packet.c:387-416).
-__device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t stream, uint64_t word, uint32_t p)
+// w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
+// batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
+// HBM traffic).
+__device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t stream, uint64_t offset, uint64_t w)
 {
-	const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
-	uint64_t lo = load_word(base, word, a.n_words);
-	uint64_t hi = load_word(base, word + 1, a.n_words);
-	uint64_t w = p ? (lo >> p) | (hi << (64 - p)) : lo;
 	uint32_t win = (uint32_t)(w >> 57);
 	uint32_t cls = __popc(win ^ BARKER1) <= 1 ? 1u : 0u;
 	uint64_t sw = (w & LOW57) | ((uint64_t)(cls ? BARKER1 : BARKER0) << 57);
@@ -119,7 +118,7 @@ __device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t strea
 		}
 	}
 	if ((int)nerr <= a.max_err)
-		emit_hit(a, stream, word * 64 + p, (uint32_t)(sw >> 34) & 0xffffff, nerr);
+		emit_hit(a, stream, offset, (uint32_t)(sw >> 34) & 0xffffff, nerr);
 }
 
 // ---- LAP_ANY ----------------------------------------------------------------------------
@@ -211,8 +210,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t wave = tid >> 6;
-	const uint32_t slot_off = LDS_OFF_PARK + 4u * (wave * 64 * PARK_SLOTS + lane * PARK_SLOTS);
-	const uint32_t ring_off = LDS_OFF_QUEUE + 4u * wave * QRING;
+	const uint32_t slot_off = LDS_OFF_PARK + CAND_BYTES * (wave * 64 * PARK_SLOTS + lane * PARK_SLOTS);
+	const uint32_t ring_off = LDS_OFF_QUEUE + CAND_BYTES * wave * QRING;
 	const uint32_t kdiff = a.t.kdiff;
 
 	// tables -> LDS, 16 bytes per lane per step, coalesced
@@ -246,22 +245,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		stream = (uint32_t)(tile / a.tiles_per_stream);
 		return (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
 	};
-	auto park = [&](uint32_t code) {
+	auto park = [&](uint32_t code, uint32_t wlo, uint32_t whi) {
 		if (n_parked < PARK_SLOTS) {
-			lds_st(slot_off + 4u * n_parked, code);
+			const uint32_t o = slot_off + CAND_BYTES * n_parked;
+			lds_st(o, code);
+			lds_st(o + 4, wlo);
+			lds_st(o + 8, whi);
 			n_parked++;
 		} else {
 			uint32_t stream;
 			const uint64_t word = code_word(code, stream);
-			verify_lap_any(a, stream, word, code & 63);
+			verify_lap_any(a, stream, word * 64 + (code & 63), ((uint64_t)whi << 32) | wlo);
 		}
 	};
 	auto drain = [&](uint32_t n) {
 		if (lane < n) {
-			const uint32_t code = lds_ld(ring_off + 4u * ((q_head + lane) & (QRING - 1)));
+			const uint32_t o = ring_off + CAND_BYTES * ((q_head + lane) & (QRING - 1));
+			const uint32_t code = lds_ld(o);
+			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
 			uint32_t stream;
 			const uint64_t word = code_word(code, stream);
-			verify_lap_any(a, stream, word, code & 63);
+			verify_lap_any(a, stream, word * 64 + (code & 63), w);
 		}
 		q_head += n;
 	};
@@ -273,7 +277,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			if (n_parked > k) {
 				const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32),
 						__builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
-				lds_st(ring_off + 4u * (slot & (QRING - 1)), lds_ld(slot_off + 4u * k));
+				const uint32_t from = slot_off + CAND_BYTES * k, to = ring_off + CAND_BYTES * (slot & (QRING - 1));
+				lds_st(to, lds_ld(from));
+				lds_st(to + 4, lds_ld(from + 4));
+				lds_st(to + 8, lds_ld(from + 8));
 			}
 			q_tail += __popcll(have);
 			while (q_tail - q_head >= 64)       // keeps the ring below 128 entries
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls[u][1]);    // offsets 32..63
 			if (VARIANT == 1) {      // ablation: pre-filter only
 				if (__popc(m[u][0]) + __popc(m[u][1]) == 33)
-					park(((it + u) << 12) | (lane << 6));
+					park(((it + u) << 12) | (lane << 6), d[u][0], d[u][1]);
 				m[u][0] = m[u][1] = 0;
 			}
 		}
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 					for (int h = 0; h < 2; h++)
-						if (bit[u][h])
-							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31));
+						if (bit[u][h])      // rare: rebuild the window of this offset and keep it with the code
+							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31),
+							     alignbit(d[u][h + 1], d[u][h], p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], p[u][h]));
 			}
 		}
 
