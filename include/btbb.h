@@ -173,6 +173,34 @@ int btbb_winnow(btbb_piconet *pn);
 int btbb_init_survey(void);                                          /* btbb.h:208 */
 btbb_piconet *btbb_next_survey_result(void);                         /* btbb.h:210 */
 
+/* ---- capture files (BR/EDR), btbb.h:212-229, 262-271 ---------------------------------------
+ * Host file I/O over the fields the GPU decode left in the packet.  Return 0 or a negated
+ * result code of lib/src/pcapng.h:163-172 / lib/src/pcap.c:32-37. */
+typedef struct btbb_pcapng_handle btbb_pcapng_handle;
+/* btbb.h:214 -- new PCAPNG file (fails if it exists), one LINKTYPE_BLUETOOTH_BREDR_BB interface */
+int btbb_pcapng_create_file(const char *filename, const char *interface_desc, btbb_pcapng_handle **ph);
+/* btbb.h:216 -- one enhanced packet block; ns = capture time in nanoseconds */
+int btbb_pcapng_append_packet(btbb_pcapng_handle *h, const uint64_t ns,
+			      const int8_t sigdbm, const int8_t noisedbm,
+			      const uint32_t reflap, const uint8_t refuap,
+			      const btbb_packet *pkt);
+/* btbb.h:221 -- interface option 0xd340 */
+int btbb_pcapng_record_bdaddr(btbb_pcapng_handle *h, const uint64_t bdaddr,
+			      const uint8_t uapmask, const uint8_t napvalid);
+/* btbb.h:224 -- interface option 0xd341 */
+int btbb_pcapng_record_btclock(btbb_pcapng_handle *h, const uint64_t bdaddr,
+			       const uint64_t ns, const uint32_t clk, const uint32_t clkmask);
+int btbb_pcapng_close(btbb_pcapng_handle *h);                        /* btbb.h:226 */
+
+typedef struct btbb_pcap_handle btbb_pcap_handle;
+/* btbb.h:264 -- classic PCAP, nanosecond magic, LINKTYPE_BLUETOOTH_BREDR_BB */
+int btbb_pcap_create_file(const char *filename, btbb_pcap_handle **ph);
+int btbb_pcap_append_packet(btbb_pcap_handle *h, const uint64_t ns,      /* btbb.h:266 */
+			    const int8_t sigdbm, const int8_t noisedbm,
+			    const uint32_t reflap, const uint8_t refuap,
+			    const btbb_packet *pkt);
+int btbb_pcap_close(btbb_pcap_handle *h);                            /* btbb.h:270 */
+
 #ifdef __cplusplus
 } // __cplusplus defined.
 #endif

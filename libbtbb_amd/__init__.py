@@ -181,6 +181,14 @@ SIGNATURES = {
     "btbb_piconet_set_afh_map": (None, [_vp, _vp]),
     "btbb_init_hop_reversal": (C.c_int, [C.c_int, _vp]),
     "btbb_winnow": (C.c_int, [_vp]),
+    "btbb_pcapng_create_file": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "btbb_pcapng_append_packet": (C.c_int, [_vp, _u64, C.c_int8, C.c_int8, _u32, C.c_uint8, _vp]),
+    "btbb_pcapng_record_bdaddr": (C.c_int, [_vp, _u64, C.c_uint8, C.c_uint8]),
+    "btbb_pcapng_record_btclock": (C.c_int, [_vp, _u64, _u64, _u32, _u32]),
+    "btbb_pcapng_close": (C.c_int, [_vp]),
+    "btbb_pcap_create_file": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "btbb_pcap_append_packet": (C.c_int, [_vp, _u64, C.c_int8, C.c_int8, _u32, C.c_uint8, _vp]),
+    "btbb_pcap_close": (C.c_int, [_vp]),
     "btbb_decode": (C.c_int, [_vp]),
     "btbb_init_survey": (C.c_int, []),
     "btbb_next_survey_result": (_vp, []),

@@ -17,6 +17,8 @@ source text.  Re-run:  python tests/golden/make_golden.py
                       hop pattern gen_hops produces, its first 512 channels, and a CLK1-27
                       reversal trace (btbb_init_hop_reversal / btbb_winnow: return values,
                       candidate counts, flags, clk_offset, surviving clocks) for seeded hops
+  capture.json     -- the pcap and pcapng files (LINKTYPE_BLUETOOTH_BREDR_BB) the reference writes for
+                      ten seeded packets found, decoded and appended through its public API
 """
 import ctypes as C
 import json
@@ -97,13 +99,90 @@ def make_hop(ref):
     print("wrote hop.json (%d cases)" % len(out["cases"]))
 
 
+CAPTURE_TYPES = [3, 4, 10, 11, 14, 15, 2, 0, 9, 8]     # DM1 DH1 DM3 DH3 DM5 DH5 FHS NULL AUX1 DV
+
+
+def capture_packets():
+    """Seeded packets for the capture-file fixture: (symbols incl. preamble noise, meta)."""
+    rng = np.random.default_rng(909)
+    out = []
+    for i, t in enumerate(CAPTURE_TYPES):
+        lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+        maxlen = {3: 17, 4: 27, 10: 121, 11: 183, 14: 224, 15: 339, 9: 29, 8: 9}.get(t, 0)
+        body = rng.integers(0, 256, maxlen, dtype=np.uint8).tobytes()
+        sym = synth.build_packet(lap, uap, clk6, t, lt_addr=int(rng.integers(1, 8)), flags=int(rng.integers(0, 8)), body=body,
+                                 llid=2, flow=1, voice=rng.integers(0, 256, 10, dtype=np.uint8).tobytes(),
+                                 fhs_bits=synth.fhs_payload(lap, uap, 0x1234, 0x2345678, rng))
+        lead = rng.integers(0, 2, 40 + i, dtype=np.uint8)
+        stream = np.concatenate([lead, sym, rng.integers(0, 2, 80, dtype=np.uint8)])
+        if i % 3 == 1:
+            stream[len(lead) + 5] ^= 1          # one access-code error
+        out.append((np.ascontiguousarray(stream), dict(lap=lap, uap=uap, clk6=clk6, type=t, channel=int(rng.integers(0, 79)),
+                                                       ns=1_600_000_000_000_000_000 + i * 987_654_321,
+                                                       sig=int(rng.integers(-80, -30)), noise=int(rng.integers(-100, -60)),
+                                                       transport=int(rng.integers(0, 4)), modulation=int(rng.integers(0, 3)))))
+    return out
+
+
+def make_capture(ref):
+    import base64
+    import tempfile
+    import _capture
+    vp = C.c_void_p
+    app = [vp, C.c_uint64, C.c_int8, C.c_int8, C.c_uint32, C.c_uint8, vp]
+    for name, res, args in (("btbb_pcapng_create_file", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp)]),
+                            ("btbb_pcapng_append_packet", C.c_int, app), ("btbb_pcapng_close", C.c_int, [vp]),
+                            ("btbb_pcapng_record_bdaddr", C.c_int, [vp, C.c_uint64, C.c_uint8, C.c_uint8]),
+                            ("btbb_pcapng_record_btclock", C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+                            ("btbb_pcap_create_file", C.c_int, [C.c_char_p, C.POINTER(vp)]),
+                            ("btbb_pcap_append_packet", C.c_int, app), ("btbb_pcap_close", C.c_int, [vp]),
+                            ("btbb_packet_set_transport", None, [vp, C.c_uint8]),
+                            ("btbb_packet_set_modulation", None, [vp, C.c_uint8])):
+        f = getattr(ref, name)
+        f.restype, f.argtypes = res, args
+    d = tempfile.mkdtemp()
+    ng, pc = vp(), vp()
+    assert ref.btbb_pcapng_create_file(os.path.join(d, "g.pcapng").encode(), b"golden", C.byref(ng)) == 0
+    assert ref.btbb_pcap_create_file(os.path.join(d, "g.pcap").encode(), C.byref(pc)) == 0
+    metas = []
+    for stream, m in capture_packets():
+        pkt = vp(None)
+        off = ref.btbb_find_ac(_libs.ptr(stream), len(stream) - 64, _libs.LAP_ANY, 1, C.byref(pkt))
+        assert off >= 0 and ref.btbb_packet_get_lap(pkt) == m["lap"], (off, m)
+        ref.btbb_packet_set_data(pkt, C.c_void_p(stream.ctypes.data + off), len(stream) - off, m["channel"], m["clk6"] << 1)
+        ref.btbb_packet_set_uap(pkt, m["uap"])
+        ref.btbb_packet_set_flag(pkt, 4, 1)                 # CLK6 valid
+        ref.btbb_packet_set_transport(pkt, m["transport"])
+        ref.btbb_packet_set_modulation(pkt, m["modulation"])
+        m["decode_rv"] = int(ref.btbb_decode(pkt))
+        m["payload_length"] = int(ref.btbb_packet_get_payload_length(pkt))
+        m["offset"] = int(off)
+        for h, fn in ((ng, ref.btbb_pcapng_append_packet), (pc, ref.btbb_pcap_append_packet)):
+            assert fn(h, m["ns"], m["sig"], m["noise"], m["lap"], m["uap"], pkt) == 0
+        ref.btbb_packet_unref(pkt)
+        metas.append(m)
+    ref.btbb_pcapng_record_bdaddr(ng, 0x0000112233445566, 0xFF, 1)
+    ref.btbb_pcapng_record_btclock(ng, 0x0000112233445566, 42, 0x1234567, 0x0FFFFFFF)
+    ref.btbb_pcapng_close(ng)
+    ref.btbb_pcap_close(pc)
+    out = {"_generator": "tests/golden/make_golden.py (inputs: capture_packets(), seeded)", "packets": metas,
+           "page_size": os.sysconf("SC_PAGESIZE"),
+           "pcapng_normalized_b64": base64.b64encode(_capture.normalize_pcapng(open(os.path.join(d, "g.pcapng"), "rb").read())).decode(),
+           "pcap_b64": base64.b64encode(open(os.path.join(d, "g.pcap"), "rb").read()).decode()}
+    json.dump(out, open(os.path.join(HERE, "capture.json"), "w"), separators=(",", ":"))
+    print("wrote capture.json (%d packets, payload lengths %s)" % (len(metas), [m["payload_length"] for m in metas]))
+
+
 def main():
     ref = _libs.ref()
     assert ref is not None, "needs /root/reference (run in the build container)"
     ref.btbb_init(2)
+    if "--capture-only" in sys.argv:
+        return make_capture(ref)
     make_hop(ref)
     if "--hop-only" in sys.argv:
         return
+    make_capture(ref)
 
     scan = {"_generator": "tests/golden/make_golden.py", "init_max_ac_errors": 2, "cases": []}
     for case in SCAN_CASES:
