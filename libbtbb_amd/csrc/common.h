@@ -50,6 +50,9 @@ struct ScanTables {
 	uint64_t hmask;            // slots - 1
 	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1
 	uint32_t kdiff;            // low 32 bits of kclass[0] ^ kclass[1]
+	uint64_t hi_mask[2];       // window bits (0..56) whose syndrome has bit 32 / bit 33 set
+	const uint32_t *bitmap2;   // second-level filter in global memory (tables for >= 3 errors), or null
+	uint32_t bitmap2_shift;    // index = (low32 * golden) >> shift
 };
 
 // packed hash slot: bits 0..33 syndrome, then five 6-bit error positions (63 = unused),
@@ -80,6 +83,7 @@ struct Ctx {
 	ScanTables scan{};          // device pointers
 	void *d_tab_block = nullptr;
 	void *d_hslots = nullptr;
+	void *d_bitmap2 = nullptr;
 	// packet-chain tables
 	void *d_chain = nullptr;
 	// scratch for the host convenience wrappers and the drop-in API

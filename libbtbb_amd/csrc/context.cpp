@@ -96,6 +96,8 @@ static inline uint32_t hslot_hash(uint64_t key)
 struct MapBuilder {
 	std::vector<uint64_t> slots;
 	std::vector<uint32_t> bitmap;
+	std::vector<uint32_t> bitmap2;   // empty = not used
+	int shift2 = 0;
 	uint64_t mask;
 	int shift;
 	uint64_t count = 0;
@@ -111,6 +113,10 @@ struct MapBuilder {
 		slots[h] = packed;
 		uint32_t proj = (uint32_t)syndrome & ((1u << BITMAP_BITS) - 1);
 		bitmap[proj >> 5] |= 1u << (proj & 31);
+		if (!bitmap2.empty()) {
+			const uint32_t i2 = ((uint32_t)syndrome * 0x9E3779B1u) >> shift2;
+			bitmap2[i2 >> 5] |= 1u << (i2 & 31);
+		}
 		count++;
 	}
 
@@ -147,6 +153,14 @@ static int upload_tables(int max_ac_errors)
 	mb.mask = (1ULL << bits) - 1;
 	mb.shift = 32 - bits;
 	mb.bitmap[0] |= 1u;                     // the zero syndrome (error-free codeword)
+	if (max_ac_errors >= 3) {
+		// With 32 567 (3 errors) .. 5.0 M (5) patterns the 2^19-bit LDS bitmap passes 6 % .. 100 %
+		// of the survivors; a 2^26-bit bitmap over a hash of the low 32 syndrome bits (8 MiB, L2 /
+		// Infinity Cache resident) prunes them before the pattern table is probed.
+		mb.shift2 = 32 - 26;
+		mb.bitmap2.assign(1u << (26 - 5), 0);
+		mb.bitmap2[0] |= 1u;            // hash of syndrome 0
+	}
 	int pos[5];
 	for (int k = 1; k <= max_ac_errors; k++)
 		mb.enumerate(t, 0, pos, 0, 0, k);
@@ -175,6 +189,11 @@ static int upload_tables(int max_ac_errors)
 	size_t off_t = off_m + 4 * LDS_BITMAP_WORDS, total = off_t + sizeof(t.bytetab);
 	if (c.d_tab_block) { (void)hipFree(c.d_tab_block); c.d_tab_block = nullptr; }
 	if (c.d_hslots) { (void)hipFree(c.d_hslots); c.d_hslots = nullptr; }
+	if (c.d_bitmap2) { (void)hipFree(c.d_bitmap2); c.d_bitmap2 = nullptr; }
+	if (!mb.bitmap2.empty()) {
+		HIP_TRY(hipMalloc(&c.d_bitmap2, mb.bitmap2.size() * 4));
+		HIP_TRY(hipMemcpy(c.d_bitmap2, mb.bitmap2.data(), mb.bitmap2.size() * 4, hipMemcpyHostToDevice));
+	}
 	HIP_TRY(hipMalloc(&c.d_tab_block, total));
 	HIP_TRY(hipMalloc(&c.d_hslots, mb.slots.size() * sizeof(uint64_t)));
 	char *base = (char *)c.d_tab_block;
@@ -192,6 +211,13 @@ static int upload_tables(int max_ac_errors)
 	c.scan.kclass[0] = kclass[0];
 	c.scan.kclass[1] = kclass[1];
 	c.scan.kdiff = (uint32_t)(kclass[0] ^ kclass[1]);
+	c.scan.hi_mask[0] = c.scan.hi_mask[1] = 0;
+	for (int j = 0; j < 57; j++) {
+		if ((t.col[j] >> 32) & 1) c.scan.hi_mask[0] |= 1ULL << j;
+		if ((t.col[j] >> 33) & 1) c.scan.hi_mask[1] |= 1ULL << j;
+	}
+	c.scan.bitmap2 = (const uint32_t *)c.d_bitmap2;
+	c.scan.bitmap2_shift = (uint32_t)mb.shift2;
 	c.table_errors = max_ac_errors;
 	return BTBBX_OK;
 }
@@ -239,6 +265,7 @@ extern "C" void btbbx_shutdown(void)
 	hop_pool_release();
 	if (c.d_tab_block) (void)hipFree(c.d_tab_block);
 	if (c.d_hslots) (void)hipFree(c.d_hslots);
+	if (c.d_bitmap2) (void)hipFree(c.d_bitmap2);
 	if (c.d_scratch) (void)hipFree(c.d_scratch);
 	if (c.h_pinned) (void)hipHostFree(c.h_pinned);
 	c = Ctx();

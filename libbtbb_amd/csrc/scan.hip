@@ -81,27 +81,50 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, 
 
 // The exact acceptance rule of promiscuous_packet_search for one offset that passed the
 // barker filter (bluetooth_packet.c:387-416).
+// The kernel has no static __shared__, so the dynamic LDS allocation starts at LDS byte 0
+// and table addresses are plain byte offsets: every DS access below is `base + offset:imm`
+// with the table base folded into the 16-bit immediate.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128_t;
+__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
+__device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
+__device__ __forceinline__ void lds_st16(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u16_t *>(byte_off) = (uint16_t)v; }
+__device__ __forceinline__ void lds_st64(uint32_t byte_off, uint64_t v) { *reinterpret_cast<lds_u64_t *>(byte_off) = v; }
+
 // w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
 // batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
 // HBM traffic).
-__device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t stream, uint64_t offset, uint64_t w)
+__device__ __forceinline__ bool verify_lap_any(const ScanArgs &a, uint64_t w, uint32_t &lap, uint32_t &nerr_out)
 {
 	uint32_t win = (uint32_t)(w >> 57);
 	uint32_t cls = __popc(win ^ BARKER1) <= 1 ? 1u : 0u;
 	uint64_t sw = (w & LOW57) | ((uint64_t)(cls ? BARKER1 : BARKER0) << 57);
-	// syndrome of (sw ^ pn): linear, so bytes 0..6 of w, bit 56, and a class constant
-	uint64_t syn = a.t.kclass[cls];
-	uint64_t low = w & LOW57;
-#pragma unroll
-	for (int b = 0; b < 8; b++)
-		syn ^= a.t.bytetab[b * 256 + ((low >> (8 * b)) & 0xff)];
+	// syndrome of (sw ^ pn): linear in the low 57 window bits plus a class constant.  The low 32
+	// bits come from the LDS tables exactly as in the probe; bits 32 and 33 are two parities.  (The
+	// byte tables in global memory cost eight divergent loads per candidate, which is what bounded
+	// the scan for tables built for three or more errors.)
+	const uint64_t low = w & LOW57;
+	const uint32_t s_lo = (uint32_t)low ^ lds_ld(LDS_OFF_TABA + (((uint32_t)(low >> 32) & ((1u << TABA_BITS) - 1)) << 2))
+			      ^ lds_ld(LDS_OFF_TABB + ((uint32_t)(low >> (32 + TABA_BITS)) << 2)) ^ (cls ? a.t.kdiff : 0u);
+	const uint32_t s_hi = ((uint32_t)(a.t.kclass[cls] >> 32) ^ (__popcll(low & a.t.hi_mask[0]) & 1)
+			       ^ ((__popcll(low & a.t.hi_mask[1]) & 1) << 1)) & 3;
+	const uint64_t syn = ((uint64_t)s_hi << 32) | s_lo;
+	if (a.t.bitmap2) {
+		const uint32_t i2 = (s_lo * 0x9E3779B1u) >> a.t.bitmap2_shift;
+		if (!((a.t.bitmap2[i2 >> 5] >> (i2 & 31)) & 1))
+			return false;
+	}
 	uint32_t nerr = 0;
 	if (syn) {
 		uint64_t h = ((((uint32_t)syn ^ (uint32_t)(syn >> 32)) * 0x9E3779B1u) >> (32 - __popcll(a.t.hmask))) & a.t.hmask;
 		for (;;) {
 			uint64_t slot = a.t.hslots[h];
 			if (slot == HSLOT_EMPTY)
-				return;                               // no pattern -> ac_errors = 0xff -> reject
+				return false;                         // no pattern -> ac_errors = 0xff -> reject
 			if ((slot & 0x3ffffffffULL) == syn) {
 				uint64_t err = 0;
 #pragma unroll
@@ -117,25 +140,12 @@ __device__ __forceinline__ void verify_lap_any(const ScanArgs &a, uint32_t strea
 			h = (h + 1) & a.t.hmask;
 		}
 	}
-	if ((int)nerr <= a.max_err)
-		emit_hit(a, stream, offset, (uint32_t)(sw >> 34) & 0xffffff, nerr);
+	lap = (uint32_t)(sw >> 34) & 0xffffff;
+	nerr_out = nerr;
+	return (int)nerr <= a.max_err;
 }
 
 // ---- LAP_ANY ----------------------------------------------------------------------------
-
-// The kernel has no static __shared__, so the dynamic LDS allocation starts at LDS byte 0
-// and table addresses are plain byte offsets: every DS access below is `base + offset:imm`
-// with the table base folded into the 16-bit immediate.
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
-typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u128_t;
-__device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
-__device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
-__device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
-__device__ __forceinline__ void lds_st16(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u16_t *>(byte_off) = (uint16_t)v; }
-__device__ __forceinline__ void lds_st64(uint32_t byte_off, uint64_t v) { *reinterpret_cast<lds_u64_t *>(byte_off) = v; }
 
 // index of the lowest set bit; 0xffffffff for 0 (v_ffbl_b32), which the callers use as
 // "offset 31 of a lane that has nothing left" -- its result is masked out afterwards
@@ -240,10 +250,67 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	uint32_t n_parked = 0;
 	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
 	auto code_word = [&](uint32_t code, uint32_t &stream) {
-		// `it` -> tile needs a division, but only here on the rare path
-		const uint64_t tile = blockIdx.x + (uint64_t)(code >> 12) * gridDim.x;
-		stream = (uint32_t)(tile / a.tiles_per_stream);
-		return (tile % a.tiles_per_stream) * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+		// `it` -> tile.  The launcher keeps it * gridDim below 2^32 tiles (iterations < 2^20, grid
+		// <= CUs), so this is one 32-bit division and only for multi-stream launches -- the 64-bit
+		// div + mod that used to sit here cost about 2000 cycles per batch of 64 candidates.
+		const uint32_t tile = blockIdx.x + (code >> 12) * gridDim.x;
+		uint32_t t = tile;
+		stream = 0;
+		if (a.n_streams > 1) {
+			stream = tile / (uint32_t)a.tiles_per_stream;
+			t = tile - stream * (uint32_t)a.tiles_per_stream;
+		}
+		return (uint64_t)t * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+	};
+	// Hits of a verified batch are not written one batch at a time: a single counter word in
+	// global memory takes ~140 M atomics/s, which capped the scan as soon as batches became
+	// frequent (tables for >= 3 errors: 750 k batches per GiB).  Each wave keeps up to 64 pending
+	// hit records in registers (one per lane), appends new ones with ds_permute (a lane-to-lane
+	// push through the LDS crossbar, no LDS memory), and reserves + writes 64 at a time.
+	uint32_t pend = 0;                            // wave-uniform
+	uint32_t h_off = 0, h_hi = 0, h_lap = 0;      // lane k < pend: offset low, offset high | stream << 16, lap << 8 | errors
+	auto flush_hits = [&]() {
+		if (pend == 0)
+			return;
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(a.hit_count, pend);
+		base = __builtin_amdgcn_readfirstlane(base);
+		const uint32_t idx = base + lane;
+		if (lane < pend && idx < a.hit_cap) {
+			uint4 rec;
+			rec.x = h_off;
+			rec.y = h_hi & 0xffff;
+			rec.z = h_lap >> 8;
+			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
+			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+		}
+		pend = 0;
+	};
+	auto push_hits = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t lap, uint32_t nerr) {
+		if (a.first || VARIANT == 7) {            // first-match mode (or ablation 7): hits go out one by one
+			if (hit)
+				emit_hit(a, stream, offset, lap, nerr);
+			return;
+		}
+		const uint64_t m = __ballot(hit);
+		if (!m)
+			return;
+		const uint32_t c = (uint32_t)__popcll(m);
+		if (pend + c > 64)
+			flush_hits();
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+		// lanes without a hit push to a lane outside [pend, pend + c), whose result is ignored
+		const int dst = (int)((hit ? pend + rank : (pend ? 0u : c)) << 2);
+		const uint32_t r_off = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)offset);
+		const uint32_t r_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((uint32_t)(offset >> 32) | (stream << 16)));
+		const uint32_t r_lap = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((lap << 8) | nerr));
+		if (lane - pend < c) {
+			h_off = r_off;
+			h_hi = r_hi;
+			h_lap = r_lap;
+		}
+		pend += c;
 	};
 	auto park = [&](uint32_t code, uint32_t wlo, uint32_t whi) {
 		if (n_parked < PARK_SLOTS) {
@@ -252,21 +319,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			lds_st(o + 4, wlo);
 			lds_st(o + 8, whi);
 			n_parked++;
-		} else {
-			uint32_t stream;
+		} else {                                  // all slots taken (adversarial input): verify in place
+			uint32_t stream, lap, nerr;
 			const uint64_t word = code_word(code, stream);
-			verify_lap_any(a, stream, word * 64 + (code & 63), ((uint64_t)whi << 32) | wlo);
+			if (verify_lap_any(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
+				emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
 		}
 	};
 	auto drain = [&](uint32_t n) {
+		bool hit = false;
+		uint32_t stream = 0, lap = 0, nerr = 0;
+		uint64_t offset = 0;
 		if (lane < n) {
 			const uint32_t o = ring_off + CAND_BYTES * ((q_head + lane) & (QRING - 1));
 			const uint32_t code = lds_ld(o);
 			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
-			uint32_t stream;
-			const uint64_t word = code_word(code, stream);
-			verify_lap_any(a, stream, word * 64 + (code & 63), w);
+			offset = code_word(code, stream) * 64 + (code & 63);
+			if (VARIANT != 5)                                  // ablation: park + compact, no verification
+				hit = verify_lap_any(a, w, lap, nerr);
+			else
+				hit = w == 0x123456789abcdefULL;
 		}
+		push_hits(hit, stream, offset, lap, nerr);
 		q_head += n;
 	};
 	auto compact = [&](bool final) {
@@ -442,6 +516,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		}
 	}
 	compact(true);
+	flush_hits();
 }
 
 // ---- known LAP --------------------------------------------------------------------------
@@ -706,7 +781,7 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		a.tiles_per_stream = (search_words + SCAN_THREADS - 1) / SCAN_THREADS;
 		a.n_tiles = a.tiles_per_stream * n_streams;
 		uint64_t grid = a.n_tiles < (uint64_t)c.num_cus ? a.n_tiles : (uint64_t)c.num_cus;
-		if ((a.n_tiles + grid - 1) / grid >= (1u << 20)) {
+		if ((a.n_tiles + grid - 1) / grid >= (1u << 20) || (a.n_tiles >> 32)) {
 			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
 			return BTBBX_E_ARG;
 		}
@@ -730,6 +805,8 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		case 2: LAUNCH_VARIANT(2); break;
 		case 3: LAUNCH_VARIANT(3); break;
 		case 4: LAUNCH_VARIANT(4); break;
+		case 5: LAUNCH_VARIANT(5); break;
+		case 7: LAUNCH_VARIANT(7); break;
 		default: LAUNCH_VARIANT(0); break;
 		}
 	} else {

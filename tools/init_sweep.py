@@ -5,7 +5,8 @@ import libbtbb_amd as bt
 lib=bt.lib()
 nw=1<<27
 out={}
-for n in (0,1,2,3,4,5):
+import os
+for n in [int(x) for x in os.environ.get('SWEEP_N','0,1,2,3,4,5').split(',')]:
     lib.btbbx_shutdown(); bt.init(n)
     hs=C.c_void_p(torch.cuda.current_stream().cuda_stream)
     d=torch.empty(nw,dtype=torch.int64,device='cuda')
