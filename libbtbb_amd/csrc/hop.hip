@@ -6,9 +6,8 @@
 // second of CPU per address) and then filters candidate clocks by table look-ups.  Here the
 // selection kernel is a pure function evaluated where it is needed:
 //   * hop_sequence_kernel   fills sequence[first .. first+count) for callers that want the
-//                           table (one lane per 64 hops, permutation done bit-sliced over the
-//                           32 values of CLK2-6: a butterfly stage is a conditional swap of
-//                           two bit planes);
+//                           table (one lane per 64 hops; the permutation is applied to a
+//                           32-byte window of the bank table held in registers);
 //   * candidates / winnow   evaluate the kernel per candidate clock -- no table at all.
 // Candidate lists stay in HBM in ascending order (as the reference keeps them) through
 // ballot masks + a prefix over mask words + an ordered scatter.
@@ -68,18 +67,143 @@ __device__ __forceinline__ int hop_observable(uint32_t ch, int aliased)
 }
 
 // ---- whole-table generation -----------------------------------------------------------
-// 4 bits of one plane -> bit 0 of four byte lanes
-__device__ __forceinline__ uint32_t spread4(uint32_t plane, int x0)
+// One lane produces the 64 hops of one value of CLK7-27.  For a fixed clock parity the 32 hops
+// over CLK2-6 = x are  bank'[K + perm(in(x))],  in(x) = ((x + a) mod 32) ^ b:  a 32-byte window W
+// of the bank table, indexed through a permutation of x.  The window lives in 8 VGPRs and the
+// permutation is applied to the ARRAY instead of to each index: a butterfly stage that exchanges
+// index bits (u, v) is a conditional exchange of array elements -- whole registers when both bits
+// select the register, byte shuffles with v_perm_b32 when a bit selects the byte -- and the final
+// x -> (x + a) mod 32 is a byte rotation of the array.  About 6 VALU ops per hop and 16 LDS reads
+// per 64 hops; an earlier version evaluated the permutation bit-sliced and transposed the planes
+// (11 ops + 1 LDS read per hop, 48 us per pattern).
+#define HOP_PAD 304               // bank' entries incl. padding so that 8 dwords can be read at any K
+
+__device__ __forceinline__ uint32_t vperm(uint32_t hi, uint32_t lo, uint32_t sel)
 {
-	return __umul24((plane >> x0) & 15u, 0x00204081u) & 0x01010101u;
+	return __builtin_amdgcn_perm(hi, lo, sel);      // selector byte 0..3 -> lo, 4..7 -> hi
+}
+
+__device__ __forceinline__ uint32_t bitsel(uint32_t m, uint32_t one, uint32_t zero)
+{
+	return (one & m) | (zero & ~m);                 // one v_bitop3
+}
+
+// new[z] = old[z with index bits U and V exchanged] where the mask m is all ones, unchanged where
+// it is 0.  Index z of the 32-entry array = register (z >> 2), byte (z & 3).
+template <int U, int V> __device__ __forceinline__ void swap_index_bits(uint32_t (&r)[8], uint32_t m)
+{
+	static_assert(U < V && V < 5, "stage wires");
+	if constexpr (U >= 2) {
+		constexpr int mu = 1 << (U - 2), mv = 1 << (V - 2);
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			if ((i & mu) && !(i & mv)) {
+				const int j = i ^ mu ^ mv;
+				const uint32_t a = r[i], b = r[j];
+				r[i] = bitsel(m, b, a);
+				r[j] = bitsel(m, a, b);
+			}
+	} else if constexpr (V >= 2) {
+		constexpr int mv = 1 << (V - 2);
+		// A = register with index bit V clear, B = its partner.  U = 0: A.bytes{1,3} <-> B.bytes{0,2};
+		// U = 1: A.bytes{2,3} <-> B.bytes{0,1}.  Selectors: identity ^ (m & difference)
+		constexpr uint32_t swa = U == 0 ? 0x06020400u : 0x05040100u, swb = U == 0 ? 0x07030501u : 0x07060302u;
+		const uint32_t sa = 0x03020100u ^ (m & (swa ^ 0x03020100u));
+		const uint32_t sb = 0x07060504u ^ (m & (swb ^ 0x07060504u));
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			if (!(i & mv)) {
+				const uint32_t a = r[i], b = r[i | mv];
+				r[i] = vperm(b, a, sa);
+				r[i | mv] = vperm(b, a, sb);
+			}
+	} else {
+		const uint32_t s = 0x03020100u ^ (m & (0x03010200u ^ 0x03020100u));   // bytes 1 <-> 2
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			r[i] = vperm(r[i], r[i], s);
+	}
+}
+
+__device__ __forceinline__ uint32_t ctl_mask(uint32_t ctl, int k)
+{
+	return (uint32_t)__builtin_amdgcn_sbfe((int)ctl, k, 1);          // 0 or ~0
+}
+
+// the 14 stages in array order (stage 0 first, see the composition note in DESIGN.md 3.6)
+__device__ __forceinline__ void hop_permute_array(uint32_t (&r)[8], uint32_t ctl)
+{
+	swap_index_bits<0, 1>(r, ctl_mask(ctl, 0));
+	swap_index_bits<2, 3>(r, ctl_mask(ctl, 1));
+	swap_index_bits<1, 2>(r, ctl_mask(ctl, 2));
+	swap_index_bits<3, 4>(r, ctl_mask(ctl, 3));
+	swap_index_bits<0, 4>(r, ctl_mask(ctl, 4));
+	swap_index_bits<1, 3>(r, ctl_mask(ctl, 5));
+	swap_index_bits<0, 2>(r, ctl_mask(ctl, 6));
+	swap_index_bits<3, 4>(r, ctl_mask(ctl, 7));
+	swap_index_bits<1, 4>(r, ctl_mask(ctl, 8));
+	swap_index_bits<0, 3>(r, ctl_mask(ctl, 9));
+	swap_index_bits<2, 4>(r, ctl_mask(ctl, 10));
+	swap_index_bits<1, 3>(r, ctl_mask(ctl, 11));
+	swap_index_bits<0, 3>(r, ctl_mask(ctl, 12));
+	swap_index_bits<1, 2>(r, ctl_mask(ctl, 13));
+}
+
+// new[x] = old[((x + a) mod 32) ^ b]; b is the same for every lane of the launch
+__device__ __forceinline__ void hop_input_map(uint32_t (&r)[8], uint32_t a, uint32_t b)
+{
+	// z ^ (b & 3): one byte shuffle with a launch-uniform selector
+	const uint32_t xsel = (b & 1 ? 0x02030001u : 0x03020100u) ^ (b & 2 ? 0x02020202u : 0u);
+#pragma unroll
+	for (int i = 0; i < 8; i++)
+		r[i] = vperm(r[i], r[i], xsel);
+	// z ^ (b & 12): exchange registers
+	const uint32_t m4 = 0u - ((b >> 2) & 1u), m8 = 0u - ((b >> 3) & 1u);
+#pragma unroll
+	for (int i = 0; i < 8; i += 2) {
+		const uint32_t p = r[i], q = r[i + 1];
+		r[i] = bitsel(m4, q, p);
+		r[i + 1] = bitsel(m4, p, q);
+	}
+#pragma unroll
+	for (int i = 0; i < 8; i++)
+		if (!(i & 2)) {
+			const uint32_t p = r[i], q = r[i + 2];
+			r[i] = bitsel(m8, q, p);
+			r[i + 2] = bitsel(m8, p, q);
+		}
+	// rotate by whole registers (a >> 2), then by bytes (a & 3)
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const uint32_t m = ctl_mask(a, 2 + k);
+		uint32_t n[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			n[i] = bitsel(m, r[(i + (1 << k)) & 7], r[i]);
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			r[i] = n[i];
+	}
+	const uint32_t s = a & 3;
+	const uint32_t first = r[0];
+#pragma unroll
+	for (int i = 0; i < 7; i++)
+		r[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], s);
+	r[7] = __builtin_amdgcn_alignbyte(first, r[7], s);
 }
 
 __global__ __launch_bounds__(256) void hop_sequence_kernel(HopArgs h, uint32_t t0, uint32_t nt, uint4 *out)
 {
-	__shared__ uint8_t tab[HOP_TAB];
-	hop_build_tab(tab, h);
+	// four copies of the bank table, copy s shifted by s bytes: any 32-byte window starts on a dword
+	__shared__ uint32_t tabs[4][HOP_PAD / 4];
+	__shared__ uint4 stage[4][64 * 5];
+	for (uint32_t i = threadIdx.x; i < 4 * HOP_PAD; i += 256) {
+		const uint32_t s = i / HOP_PAD, k = i % HOP_PAD, v = k + s;
+		reinterpret_cast<uint8_t *>(tabs[s])[k] = v < HOP_TAB ? h.bank[v % h.mod] : 0;
+	}
+	__syncthreads();
 	const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-	if (g >= nt)
+	if (g - (threadIdx.x & 63) >= nt)               // whole wave out of range
 		return;
 	const uint32_t t = t0 + g;
 	const uint32_t a = h.a1 ^ ((t >> 14) & 31);
@@ -89,57 +213,44 @@ __global__ __launch_bounds__(256) void hop_sequence_kernel(HopArgs h, uint32_t t
 	if (h.afh)
 		f %= h.mod;
 	const uint32_t k0 = h.e + f;
+	const uint32_t *win = &tabs[k0 & 3][k0 >> 2];
 
-	// plane w, bit x = bit w of the permutation input ((x + a) mod 32) ^ b
-	const uint32_t zplane[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
-	uint32_t in[5];
+	uint32_t r0[8], r1[8];
 #pragma unroll
-	for (int w = 0; w < 5; w++)
-		in[w] = __builtin_rotateright32(zplane[w], a) ^ (0u - ((h.b >> w) & 1u));
-
-	// stage masks: all ones where the control bit is set.  d drives stages 0..8 for both clock
-	// parities; c drives 9..13 and is complemented for odd clocks (y1 = 1)
-	const uint32_t ctl = (c << 9) | d;
-	uint32_t q[2][5];
-#pragma unroll
-	for (int w = 0; w < 5; w++)
-		q[0][w] = q[1][w] = in[w];
-#pragma unroll
-	for (int s = 13; s >= 0; s--) {
-		const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)ctl, s, 1);
-#pragma unroll
-		for (int y1 = 0; y1 < 2; y1++) {
-			const bool flip = y1 && s >= 9;
-			const uint32_t pu = q[y1][flip ? hop_v(s) : hop_u(s)], pv = q[y1][flip ? hop_u(s) : hop_v(s)];
-			// m set: swap; with flip the roles of "swap" and "keep" are exchanged
-			q[y1][hop_u(s)] = (pu & ~m) | (pv & m);
-			q[y1][hop_v(s)] = (pv & ~m) | (pu & m);
-		}
+	for (int i = 0; i < 8; i++) {
+		r0[i] = win[i];                         // even clocks: window at K
+		r1[i] = win[i + 8];                     // odd clocks: window at K + 32
 	}
-	const uint8_t *tab0 = tab + k0, *tab1 = tab + k0 + 32;
+	hop_permute_array(r0, (c << 9) | d);
+	hop_permute_array(r1, ((c ^ 31u) << 9) | d);
+	hop_input_map(r0, a, h.b);
+	hop_input_map(r1, a, h.b);
 
-	uint4 *dst = out + (size_t)g * 4;
+	// sequence order: x / even, x / odd, x + 1 / even, ...
+	uint4 v[4];
 #pragma unroll
-	for (int part = 0; part < 4; part++) {          // 8 values of x per 16 output bytes
-		uint32_t wd[4];
+	for (int q = 0; q < 4; q++) {
+		v[q].x = vperm(r1[2 * q], r0[2 * q], 0x05010400u);
+		v[q].y = vperm(r1[2 * q], r0[2 * q], 0x07030602u);
+		v[q].z = vperm(r1[2 * q + 1], r0[2 * q + 1], 0x05010400u);
+		v[q].w = vperm(r1[2 * q + 1], r0[2 * q + 1], 0x07030602u);
+	}
+	// A lane holds 64 consecutive bytes; written directly, one store instruction would touch 64
+	// different 64-byte segments.  Transpose through LDS (80-byte lane pitch against bank
+	// conflicts) so that every store instruction of a wave writes 1 KiB contiguously.
+	uint4 *mine = reinterpret_cast<uint4 *>(stage[threadIdx.x >> 6]);
+	const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-		for (int half = 0; half < 2; half++) {
-			const int x0 = part * 8 + half * 4;
-			uint32_t v0 = 0, v1 = 0;                // perm outputs of x0..x0+3 in byte lanes
+	for (int q = 0; q < 4; q++)
+		mine[lane * 5 + q] = v[q];
+	__builtin_amdgcn_wave_barrier();
+	uint4 *dst = out + (size_t)(g - lane) * 4;       // the wave's 4 KiB
+	const uint32_t wave_n = min(64u, nt - (g - lane)) * 4;   // uint4 items this wave owns
 #pragma unroll
-			for (int w = 4; w >= 0; w--) {          // Horner form keeps the multiplier 24-bit
-				v0 = (v0 << 1) | spread4(q[0][w], x0);
-				v1 = (v1 << 1) | spread4(q[1][w], x0);
-			}
-			// sequence order: x0/y0, x0/y1, x0+1/y0, x0+1/y1, ...
-			const uint32_t c00 = tab0[v0 & 0xff], c01 = tab1[v1 & 0xff];
-			const uint32_t c10 = tab0[(v0 >> 8) & 0xff], c11 = tab1[(v1 >> 8) & 0xff];
-			const uint32_t c20 = tab0[(v0 >> 16) & 0xff], c21 = tab1[(v1 >> 16) & 0xff];
-			const uint32_t c30 = tab0[v0 >> 24], c31 = tab1[v1 >> 24];
-			wd[half * 2] = c00 | (c01 << 8) | (c10 << 16) | (c11 << 24);
-			wd[half * 2 + 1] = c20 | (c21 << 8) | (c30 << 16) | (c31 << 24);
-		}
-		dst[part] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+	for (int j = 0; j < 4; j++) {
+		const uint32_t u = 64 * j + lane;
+		if (u < wave_n)
+			dst[u] = mine[(u >> 2) * 5 + (u & 3)];
 	}
 }
 
