@@ -182,6 +182,14 @@ int btbbx_gather_packets_device(const uint64_t *d_words, uint64_t n_words, uint6
 int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 			btbbx_trial *d_trials, void *hip_stream);
 
+/* The HEC-only half of the brute force: d_table[i * 64 + c] = try_clock(c)'s return value (the UAP
+ * candidate for CLK1-6 = c, bluetooth_packet.c:1178-1195 / uap_from_hec :693-705) in the low byte
+ * and the packet type that clock yields in the high byte; 0 when the header's FEC 1/3 fails.
+ * Reads 8 bytes and writes 128 bytes per packet.  d_in may be NULL (all packets whitened);
+ * d_table 16-byte aligned. */
+int btbbx_uap_table_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+			   uint16_t *d_table, void *hip_stream);
+
 /* header_present + decode_header + decode_payload with the clock / UAP in d_in */
 int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 			btbbx_pkt_out *d_out, void *hip_stream);

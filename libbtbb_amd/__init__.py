@@ -106,6 +106,7 @@ SIGNATURES = {
     "btbbx_gather_packets_device": (C.c_int, [_vp, _u64, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_trials_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "btbbx_uap_table_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
     "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "btbbx_hop_channels_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
@@ -317,6 +318,24 @@ def run_trials(packet_words, pkt_in):
     check(lib().btbbx_trials_device(d_pk.ptr, d_in.ptr, n, d_tr.ptr, None), "btbbx_trials_device")
     check(lib().btbbx_sync(None))
     return d_tr.download(TRIAL_DTYPE, n * 64).reshape(n, 64)
+
+
+def run_uap_table(packet_words, pkt_in=None):
+    """n x 64 uint16: try_clock(c) | type << 8 for every packet and CLK1-6 candidate."""
+    packet_words = np.ascontiguousarray(packet_words, dtype=np.uint64)
+    n = packet_words.shape[0]
+    d_pk = DeviceBuffer(packet_words.nbytes).upload(packet_words)
+    d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in) if pkt_in is not None else None
+    d_out = DeviceBuffer(n * 128)
+    try:
+        check(lib().btbbx_uap_table_device(d_pk.ptr, d_in.ptr if d_in else None, n, d_out.ptr, None), "btbbx_uap_table_device")
+        check(lib().btbbx_sync(None), "sync")
+        return d_out.download(np.uint16, n * 64).reshape(n, 64)
+    finally:
+        d_pk.free()
+        d_out.free()
+        if d_in:
+            d_in.free()
 
 
 def run_decode(packet_words, pkt_in):

@@ -598,6 +598,54 @@ __global__ __launch_bounds__(64) void trials_kernel(const uint64_t *packets, con
 	trials[(uint64_t)pkt * 64 + clock] = t;
 }
 
+// The HEC-only half of the brute force (config 5 of BASELINE.json: "64 whitening seeds x HEC
+// check"): table[p * 64 + c] = try_clock(c)'s return value | packet_type(c) << 8, 0 when the FEC 1/3
+// of the header fails.  uap_from_hec (:693-705) and the type field are GF(2)-linear in the 18
+// header bits, and unwhitening XORs a clock-dependent constant onto them, so
+//     UAP(c) = U(header) ^ U(whitening bits of c),
+// one LFSR run per packet and a 64-entry constant table instead of 64 runs.  The kernel is then
+// pure data movement: 8 useful bytes in (the header symbols 68..121 sit in word 1 of a packed
+// packet), 128 bytes out per packet.  A wave takes 64 packets; lane L first decodes packet L,
+// then the wave writes 8 x 1 KiB: in store j lane L emits the 8 clocks 8 (L & 7).. of packet
+// 8 j + (L >> 3), fetching that packet's value with one lane-to-lane read.
+__global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets, const btbbx_pkt_in *in, uint32_t n,
+							 uint4 *table)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t pkt0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+	if (pkt0 >= n)
+		return;
+	uint32_t ut = 0;                               // U | type << 8 | fec ok << 16 | whitened << 17
+	if (pkt0 + lane < n) {
+		const uint32_t p = pkt0 + lane;
+		uint32_t dis;
+		const uint32_t hdr = fec13((packets[(uint64_t)p * BTBBX_PKT_WORDS + 1] >> 4) & ((1ULL << 54) - 1), 18, dis);
+		const uint32_t wht = in ? (in[p].flags & F_WHITENED) : 1u;
+		ut = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16) | (wht << 17);
+	}
+	uint32_t wc[4] = {0, 0, 0, 0};                 // this lane's 8 clocks, two 16-bit entries per word
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const uint32_t wb = (uint32_t)wh_bits(wh_start(8 * (lane & 7) + k, 0), 18);
+		const uint32_t e = uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8);
+		wc[k >> 1] |= e << (16 * (k & 1));
+	}
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		const uint32_t src = 8 * j + (lane >> 3);
+		const uint32_t v = (uint32_t)__shfl((int)ut, (int)src);
+		const uint32_t both = (v & 0xffff) * 0x10001u;
+		const uint32_t okm = 0u - ((v >> 16) & 1u), whm = 0u - ((v >> 17) & 1u);
+		uint4 o;
+		o.x = (both ^ (wc[0] & whm)) & okm;
+		o.y = (both ^ (wc[1] & whm)) & okm;
+		o.z = (both ^ (wc[2] & whm)) & okm;
+		o.w = (both ^ (wc[3] & whm)) & okm;
+		if (pkt0 + src < n)
+			table[(uint64_t)(pkt0 + src) * 8 + (lane & 7)] = o;
+	}
+}
+
 // mode bits of decode_kernel (packet_obj.h):
 //   DEC_HEADER   btbb_decode_header
 //   DEC_PAYLOAD  btbb_decode_payload (after a successful header when DEC_HEADER is set)
@@ -759,6 +807,24 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 		return BTBBX_OK;
 	hipLaunchKernelGGL(trials_kernel, dim3(n_packets), dim3(64), 0, (hipStream_t)hip_stream,
 			   d_packets, d_in, n_packets, d_trials);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_uap_table_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
+				      uint16_t *d_table, void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!n_packets)
+		return BTBBX_OK;
+	if ((uintptr_t)d_table & 15) {
+		set_error("btbbx_uap_table_device: table must be 16-byte aligned");
+		return BTBBX_E_ARG;
+	}
+	hipLaunchKernelGGL(uap_table_kernel, dim3((n_packets + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
+			   d_packets, d_in, n_packets, (uint4 *)d_table);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }

@@ -264,3 +264,40 @@ def test_drop_in_uap_from_header(capfd):
         orc.orc_piconet_free(on)
     capfd.readouterr()
     assert found >= 7
+
+
+def test_uap_table():
+    """btbbx_uap_table_device (one LFSR run per packet + a constant per clock, by linearity) equals
+    try_clock for all 64 clocks: return value and the packet type it leaves."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(36)
+    pk = _pkt.random_packets(rng, 700)
+    syms = [np.ascontiguousarray(s[:bt.MAX_SYMBOLS]) for s, _ in pk]
+    for k in range(0, len(syms), 9):                    # some headers beyond FEC 1/3's reach
+        if len(syms[k]) > 130:
+            syms[k][68 + rng.integers(0, 54, int(rng.integers(3, 9)))] ^= 1
+    words, lengths = bt.packets_to_words(syms)
+    pin = np.zeros(len(syms), bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    pin["flags"] = 1
+    pin["flags"][::13] = 0                              # a few unwhitened
+    got = bt.run_uap_table(words, pin)
+    assert got.shape == (len(syms), 64)
+    zeros = 0
+    for i, s in enumerate(syms):
+        p = orc.orc_packet_new()
+        orc.orc_packet_init_found(p, 0, 0)
+        orc.orc_packet_set_flag(p, 0, int(pin["flags"][i]) & 1)
+        orc.orc_packet_set_data(p, _libs.ptr(s), len(s), 0, 0)
+        for clock in range(64):
+            p.contents.packet_type = 0
+            u = orc.orc_try_clock(clock, p)
+            want = u | (p.contents.packet_type << 8)
+            assert int(got[i, clock]) == want, (i, clock, hex(int(got[i, clock])), hex(want))
+        zeros += int((got[i] == 0).all())
+        orc.orc_packet_free(p)
+    assert 20 < zeros < 200                             # FEC failures present, but not the rule
+    # no pkt_in means "all whitened"
+    allw = pin[:100].copy()
+    allw["flags"] = 1
+    assert np.array_equal(bt.run_uap_table(words[:100]), bt.run_uap_table(words[:100], allw))
