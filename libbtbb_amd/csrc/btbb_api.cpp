@@ -127,21 +127,33 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 		fprintf(stderr, "btbb_find_ac: %s\n", btbbx_last_error());
 		return -1;
 	}
+	// Device block: symbols | sentinel for the first-match word | packed words.  The sentinel sits
+	// right behind the symbols so that ONE host-to-device copy from pinned staging brings both in;
+	// pack + scan + the 8-byte result copy are queued behind it and the call synchronises once.
 	uint8_t *d_sym = (uint8_t *)block;
-	uint64_t *d_words = (uint64_t *)(block + sym_bytes);
-	uint64_t *d_first = d_words + n_words + 1;
+	uint64_t *d_first = (uint64_t *)(block + sym_bytes);
+	uint64_t *d_words = d_first + 1;
+	char *stage = (char *)ctx_pinned(sym_bytes + 16);
 	uint64_t first = ~0ULL;
 	int rc = BTBBX_OK;
-	if (hipMemcpy(d_sym, stream, n_sym, hipMemcpyHostToDevice) != hipSuccess ||
-	    hipMemcpy(d_first, &first, 8, hipMemcpyHostToDevice) != hipSuccess)
-		rc = BTBBX_E_NODEVICE;
+	if (!stage) {
+		rc = BTBBX_E_NOMEM;
+	} else {
+		memcpy(stage, stream, n_sym);
+		memcpy(stage + sym_bytes, &first, 8);
+		if (hipMemcpyAsync(d_sym, stage, sym_bytes + 8, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+			rc = BTBBX_E_NODEVICE;
+	}
 	if (!rc)
 		rc = btbbx_pack_device(d_sym, n_sym, d_words, nullptr);
 	if (!rc)
 		rc = btbbx_scan_first_device(d_words, n_words, (uint64_t)search_length,
 					     lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, d_first, nullptr);
-	if (!rc && hipMemcpy(&first, d_first, 8, hipMemcpyDeviceToHost) != hipSuccess)
+	if (!rc && (hipMemcpyAsync(stage + sym_bytes + 8, d_first, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+		    hipStreamSynchronize(nullptr) != hipSuccess))
 		rc = BTBBX_E_NODEVICE;
+	if (!rc)
+		memcpy(&first, stage + sym_bytes + 8, 8);
 	if (rc) {
 		fprintf(stderr, "btbb_find_ac: GPU scan failed: %s\n", btbbx_last_error());
 		return -1;
@@ -316,30 +328,50 @@ char *tun_format(btbb_packet *pkt)
 
 // ---- GPU round trips for one packet object ---------------------------------------------------
 
+// One device block and a pinned host mirror with the same layout.  Everything a call sends sits
+// at the front (symbols | pkt_in | pkt_out | payload bits), so one asynchronous copy takes it in,
+// the kernels and the result copy are queued behind it, and each call synchronises exactly once.
+#define PB_SYM     0u          // 3200 symbol bytes
+#define PB_IN      3200u       // btbbx_pkt_in (64 reserved)
+#define PB_OUT     3264u       // btbbx_pkt_out (384)
+#define PB_PAY     3648u       // 2752 payload bit bytes
+#define PB_PKT     6400u       // 50 packed words
+#define PB_TRIALS  6848u       // 64 btbbx_trial
+#define PB_TOTAL   8192u
+static_assert(sizeof(btbbx_pkt_out) <= PB_PAY - PB_OUT, "pkt_out slot");
+
 struct DevPacketBufs {
-	uint8_t *d_sym;        // 3200 bytes
-	uint8_t *d_pay;        // 2752 bytes
-	uint64_t *d_pkt;       // 50 words
+	char *dev;             // device block
+	char *host;            // pinned mirror
+	uint8_t *d_sym;
+	uint8_t *d_pay;
+	uint64_t *d_pkt;
 	btbbx_pkt_in *d_in;
 	btbbx_pkt_out *d_out;
-	btbbx_trial *d_trials; // 64
+	btbbx_trial *d_trials;
 };
 
 static int dev_bufs(DevPacketBufs &b)
 {
-	static void *block = nullptr;
+	static void *block = nullptr, *mirror = nullptr;
 	if (!block) {
-		hipError_t e = hipMalloc(&block, 16384);
+		hipError_t e = hipMalloc(&block, PB_TOTAL);
 		if (e != hipSuccess)
 			return hip_fail(e, "hipMalloc(packet buffers)");
 	}
-	char *p = (char *)block;
-	b.d_sym = (uint8_t *)p;                 p += 3200;
-	b.d_pay = (uint8_t *)p;                 p += 2752;
-	b.d_pkt = (uint64_t *)p;                p += 8 * BTBBX_PKT_WORDS;
-	b.d_in = (btbbx_pkt_in *)p;             p += 64;
-	b.d_out = (btbbx_pkt_out *)p;           p += (sizeof(btbbx_pkt_out) + 63) & ~63u;
-	b.d_trials = (btbbx_trial *)p;
+	if (!mirror) {
+		hipError_t e = hipHostMalloc(&mirror, PB_TOTAL, hipHostMallocDefault);
+		if (e != hipSuccess)
+			return hip_fail(e, "hipHostMalloc(packet buffers)");
+	}
+	b.dev = (char *)block;
+	b.host = (char *)mirror;
+	b.d_sym = (uint8_t *)(b.dev + PB_SYM);
+	b.d_in = (btbbx_pkt_in *)(b.dev + PB_IN);
+	b.d_out = (btbbx_pkt_out *)(b.dev + PB_OUT);
+	b.d_pay = (uint8_t *)(b.dev + PB_PAY);
+	b.d_pkt = (uint64_t *)(b.dev + PB_PKT);
+	b.d_trials = (btbbx_trial *)(b.dev + PB_TRIALS);
 	return BTBBX_OK;
 }
 
@@ -355,14 +387,11 @@ static void fill_in(const btbb_packet *pkt, btbbx_pkt_in &in)
 	in.flow = pkt->payload_flow;
 }
 
-static int upload_symbols(const btbb_packet *pkt, DevPacketBufs &b)
+// stage the whole symbol array: FEC 2/3 may read past pkt->length (stale tail)
+static void stage_symbols(const btbb_packet *pkt, DevPacketBufs &b)
 {
-	// the whole symbol array travels: FEC 2/3 may read past pkt->length (stale tail)
-	static uint8_t staging[3200];
-	memcpy(staging, pkt->symbols, PKT_MAX_SYMBOLS);
-	memset(staging + PKT_MAX_SYMBOLS, 0, sizeof(staging) - PKT_MAX_SYMBOLS);
-	HIP_TRY(hipMemcpy(b.d_sym, staging, sizeof(staging), hipMemcpyHostToDevice));
-	return btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+	memcpy(b.host + PB_SYM, pkt->symbols, PKT_MAX_SYMBOLS);
+	memset(b.host + PB_SYM + PKT_MAX_SYMBOLS, 0, 3200 - PKT_MAX_SYMBOLS);
 }
 
 int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
@@ -372,14 +401,18 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
-	rc = upload_symbols(pkt, b);
-	if (rc) return rc;
+	stage_symbols(pkt, b);
 	btbbx_pkt_in in;
 	fill_in(pkt, in);
-	HIP_TRY(hipMemcpy(b.d_in, &in, sizeof(in), hipMemcpyHostToDevice));
+	memcpy(b.host + PB_IN, &in, sizeof(in));
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_OUT, hipMemcpyHostToDevice, nullptr));
+	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+	if (rc) return rc;
 	rc = btbbx_trials_device(b.d_pkt, b.d_in, 1, b.d_trials, nullptr);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpy(trials64, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	memcpy(trials64, b.host + PB_TRIALS, 64 * sizeof(btbbx_trial));
 	return BTBBX_OK;
 }
 
@@ -391,8 +424,7 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
-	rc = upload_symbols(pkt, b);
-	if (rc) return rc;
+	stage_symbols(pkt, b);
 
 	btbbx_pkt_in in;
 	fill_in(pkt, in);
@@ -406,37 +438,41 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 	out.hdr_flags = pkt->packet_flags;
 	out.hec = pkt->packet_hec;
 	out.payload_header = bits_of(pkt->payload_header, 16);
-	HIP_TRY(hipMemcpy(b.d_in, &in, sizeof(in), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(b.d_out, &out, sizeof(out), hipMemcpyHostToDevice));
+	memcpy(b.host + PB_IN, &in, sizeof(in));
+	memcpy(b.host + PB_OUT, &out, sizeof(out));
 	const bool touches_payload = mode & (DEC_PAYLOAD | DEC_TRIALS);
 	if (touches_payload) {
 		// current payload bits travel too: a decoder only overwrites a prefix
-		static uint8_t staging[2752];
-		memcpy(staging, pkt->payload, PKT_MAX_PAYLOAD_BITS);
-		memset(staging + PKT_MAX_PAYLOAD_BITS, 0, sizeof(staging) - PKT_MAX_PAYLOAD_BITS);
-		HIP_TRY(hipMemcpy(b.d_pay, staging, sizeof(staging), hipMemcpyHostToDevice));
-		rc = btbbx_pack_device(b.d_pay, 2752, (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), nullptr);
+		memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
+		memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
+	}
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, nullptr));
+	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+	if (rc) return rc;
+	uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
+	if (touches_payload) {
+		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, nullptr);
 		if (rc) return rc;
 	}
 	rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, nullptr);
 	if (rc) return rc;
 	if (touches_payload) {
-		rc = btbbx_unpack_device((const uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)),
-					 2752, b.d_pay, nullptr);
+		rc = btbbx_unpack_device(d_out_payload, 2752, b.d_pay, nullptr);
 		if (rc) return rc;
 	}
-	HIP_TRY(hipMemcpy(&out, b.d_out, sizeof(out), hipMemcpyDeviceToHost));
+	// pkt_out and (when touched) the payload bits are adjacent: one copy back
+	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, (touches_payload ? PB_PKT : PB_PAY) - PB_OUT,
+			       hipMemcpyDeviceToHost, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	memcpy(&out, b.host + PB_OUT, sizeof(out));
 	if (header_present) *header_present = out.header_present;
 	if (header_rv) *header_rv = out.header_rv;
 	if (payload_rv) *payload_rv = out.payload_rv;
 	if (mode == 0)
 		return BTBBX_OK;           // btbb_header_present: const, nothing written back
 
-	if (touches_payload) {
-		static uint8_t staging[2752];
-		HIP_TRY(hipMemcpy(staging, b.d_pay, sizeof(staging), hipMemcpyDeviceToHost));
-		memcpy(pkt->payload, staging, PKT_MAX_PAYLOAD_BITS);
-	}
+	if (touches_payload)
+		memcpy(pkt->payload, b.host + PB_PAY, PKT_MAX_PAYLOAD_BITS);
 	pkt->flags = out.flags;
 	pkt->UAP = out.uap;
 	pkt->packet_type = out.type;
