@@ -50,6 +50,11 @@ class OrcPiconet(C.Structure):
     ]
 
 
+def seed(n):
+    """Test seeds are fixed; BTBB_TEST_SEED=k shifts all of them (soak runs on the GPU box)."""
+    return int(n) + 100003 * int(os.environ.get("BTBB_TEST_SEED", "0"))
+
+
 def build_oracle():
     """Compile oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
     subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True, capture_output=True)
