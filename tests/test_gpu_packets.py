@@ -115,7 +115,7 @@ def test_batch_decode():
             bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
             assert (bits == st["payload"]).all(), (ctx, np.nonzero(bits != st["payload"])[0][:8])
             good += r in (10, 1000)
-    assert good > 50
+    assert good > 30
 
 
 class DropIn:
