@@ -38,6 +38,7 @@ struct ScanArgs {
 	uint64_t search_bits;    // offsets [0, search_bits) are tested
 	uint64_t tiles_per_stream;
 	uint64_t n_tiles;
+	uint32_t xcd_tiles;      // LAP_ANY: tiles per XCD share (0 = plain round robin over workgroups)
 	uint32_t n_streams;
 	uint32_t lap;            // known-LAP mode
 	uint64_t syncword;       // known-LAP mode
@@ -224,6 +225,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	const uint32_t ring_off = LDS_OFF_QUEUE + CAND_BYTES * wave * QRING;
 	const uint32_t kdiff = a.t.kdiff;
 
+	// Tile order.  The dispatcher is observed to place workgroup b on XCD b % 8 (not a contract: a
+	// different placement costs L2 sharing, never correctness).  Each XCD gets one contiguous
+	// eighth of the tiles and its 32 workgroups walk it interleaved, so that the halo word of a
+	// tile -- the first word of the next tile -- is found in the L2 the neighbour workgroup just
+	// filled instead of being fetched from HBM a second time by another XCD.
+	uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, n_mine;
+	if (a.xcd_tiles) {
+		const uint32_t xcd = blockIdx.x & 7, lo_t = xcd * a.xcd_tiles;
+		const uint32_t hi_t = min((uint64_t)lo_t + a.xcd_tiles, a.n_tiles);
+		tile_step = gridDim.x >> 3;
+		first_tile = lo_t + (blockIdx.x >> 3);
+		n_mine = first_tile < hi_t ? (hi_t - first_tile + tile_step - 1) / tile_step : 0;
+	} else {
+		n_mine = first_tile < a.n_tiles ? (uint32_t)((a.n_tiles - first_tile + tile_step - 1) / tile_step) : 0;
+	}
+
 	// tables -> LDS, 16 bytes per lane per step, coalesced
 	{
 		char *ldsb = reinterpret_cast<char *>(lds);
@@ -250,10 +267,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	uint32_t n_parked = 0;
 	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
 	auto code_word = [&](uint32_t code, uint32_t &stream) {
-		// `it` -> tile.  The launcher keeps it * gridDim below 2^32 tiles (iterations < 2^20, grid
-		// <= CUs), so this is one 32-bit division and only for multi-stream launches -- the 64-bit
-		// div + mod that used to sit here cost about 2000 cycles per batch of 64 candidates.
-		const uint32_t tile = blockIdx.x + (code >> 12) * gridDim.x;
+		// `it` -> tile.  The launcher keeps tile numbers below 2^32 (iterations < 2^20, grid <= CUs),
+		// so this is one 32-bit division and only for multi-stream launches -- the 64-bit div + mod
+		// that used to sit here cost about 2000 cycles per batch of 64 candidates.
+		const uint32_t tile = first_tile + (code >> 12) * tile_step;
 		uint32_t t = tile;
 		stream = 0;
 		if (a.n_streams > 1) {
@@ -367,13 +384,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 
 	// tile cursor without divisions: uniform (stream, tile-in-stream) stepped per tile
 	struct Cursor { uint32_t stream; uint64_t t; };
-	Cursor cur = {0, blockIdx.x};
-	while (cur.t >= a.tiles_per_stream && cur.stream < a.n_streams) {
-		cur.t -= a.tiles_per_stream;
-		cur.stream++;
+	Cursor cur = {a.n_streams, 0};               // stream == n_streams: nothing (left) to do
+	uint32_t handed = 0;                          // tiles handed out so far
+	if (n_mine) {
+		cur.stream = a.n_streams > 1 ? first_tile / (uint32_t)a.tiles_per_stream : 0;
+		cur.t = first_tile - (uint64_t)cur.stream * a.tiles_per_stream;
 	}
 	auto advance = [&](Cursor &c) {
-		c.t += gridDim.x;
+		if (++handed >= n_mine) {
+			c.stream = a.n_streams;
+			return;
+		}
+		c.t += tile_step;
 		while (c.t >= a.tiles_per_stream && c.stream < a.n_streams) {
 			c.t -= a.tiles_per_stream;
 			c.stream++;
@@ -775,12 +797,14 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	a.hit_cap = hit_cap;
 	a.hit_count = d_hit_count;
 	a.first = d_first;
+	a.xcd_tiles = 0;
 	a.t = c.scan;
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
 		a.tiles_per_stream = (search_words + SCAN_THREADS - 1) / SCAN_THREADS;
 		a.n_tiles = a.tiles_per_stream * n_streams;
 		uint64_t grid = a.n_tiles < (uint64_t)c.num_cus ? a.n_tiles : (uint64_t)c.num_cus;
+		a.xcd_tiles = (grid % 8 == 0 && a.n_tiles >= grid) ? (uint32_t)((a.n_tiles + 7) / 8) : 0;
 		if ((a.n_tiles + grid - 1) / grid >= (1u << 20) || (a.n_tiles >> 32)) {
 			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
 			return BTBBX_E_ARG;
