@@ -38,7 +38,8 @@ def main():
         orc.orc_init(n_init)
         t_part = time.time() + a.seconds / 4
         while time.time() < min(t_end, t_part):
-            nwords = int(rng.integers(2, 1 << 13))
+            # mostly short streams; one in ten spans several hundred tiles (XCD-partitioned tile order)
+            nwords = int(rng.integers(1 << 18, 1 << 20)) if rng.random() < 0.1 else int(rng.integers(2, 1 << 13))
             stride = int(rng.choice([512, 600, 1024, 4096]))
             known = rng.random() < 0.35
             lap = int(rng.integers(0, 1 << 24)) if known else None
