@@ -45,7 +45,6 @@ struct ScanTables {
 	const uint32_t *tabA;      // [8192]   low-32 syndrome of window bits 32..44
 	const uint32_t *tabB;      // [4096]   low-32 syndrome of bits 45..56 ^ class-0 constant
 	const uint32_t *bitmap;    // 2^BITMAP_BITS-bit set: projection of acceptable syndromes
-	const uint64_t *bytetab;   // [8][256] full 34-bit syndrome per window byte
 	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)
 	uint64_t hmask;            // slots - 1
 	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1

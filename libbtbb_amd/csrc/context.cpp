@@ -184,9 +184,9 @@ static int upload_tables(int max_ac_errors)
 		tabB[v] = (uint32_t)s;
 	}
 
-	// one block: tabA | tabB | bitmap | bytetab
+	// one block: tabA | tabB | bitmap
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
-	size_t off_t = off_m + 4 * LDS_BITMAP_WORDS, total = off_t + sizeof(t.bytetab);
+	size_t total = off_m + 4 * LDS_BITMAP_WORDS;
 	if (c.d_tab_block) { (void)hipFree(c.d_tab_block); c.d_tab_block = nullptr; }
 	if (c.d_hslots) { (void)hipFree(c.d_hslots); c.d_hslots = nullptr; }
 	if (c.d_bitmap2) { (void)hipFree(c.d_bitmap2); c.d_bitmap2 = nullptr; }
@@ -200,12 +200,10 @@ static int upload_tables(int max_ac_errors)
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_m, mb.bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(base + off_t, t.bytetab, sizeof(t.bytetab), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(c.d_hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	c.scan.tabA = (const uint32_t *)(base + off_a);
 	c.scan.tabB = (const uint32_t *)(base + off_b);
 	c.scan.bitmap = (const uint32_t *)(base + off_m);
-	c.scan.bytetab = (const uint64_t *)(base + off_t);
 	c.scan.hslots = (const uint64_t *)c.d_hslots;
 	c.scan.hmask = mb.mask;
 	c.scan.kclass[0] = kclass[0];
