@@ -417,14 +417,17 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 }
 
 int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, int *header_present,
-		      int *header_rv, int *payload_rv)
+		      int *header_rv, int *payload_rv, bool symbols_resident)
 {
 	if (!gpu_ready("btbb_decode"))
 		return BTBBX_E_NODEVICE;
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
-	stage_symbols(pkt, b);
+	// symbols_resident: the packed symbols of this very packet are still in d_pkt from the
+	// packet_gpu_trials call just before (btbb_uap_from_header) -- no second upload / pack
+	if (!symbols_resident)
+		stage_symbols(pkt, b);
 
 	btbbx_pkt_in in;
 	fill_in(pkt, in);
@@ -446,9 +449,13 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 		memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
 		memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
 	}
-	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, nullptr));
-	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
-	if (rc) return rc;
+	const uint32_t up_from = symbols_resident ? PB_IN : 0u;
+	HIP_TRY(hipMemcpyAsync(b.dev + up_from, b.host + up_from, (touches_payload ? PB_PKT : PB_PAY) - up_from,
+			       hipMemcpyHostToDevice, nullptr));
+	if (!symbols_resident) {
+		rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+		if (rc) return rc;
+	}
 	uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
 	if (touches_payload) {
 		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, nullptr);

@@ -219,7 +219,7 @@ int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn)
 	}
 
 	// leave the packet object as the executed trials leave it in the reference
-	if (packet_gpu_decode(pkt, DEC_TRIALS, &plan, nullptr, nullptr, nullptr))
+	if (packet_gpu_decode(pkt, DEC_TRIALS, &plan, nullptr, nullptr, nullptr, true))
 		fprintf(stderr, "btbb_uap_from_header: state replay failed: %s\n", btbbx_last_error());
 	if (result >= 0)
 		return result;
