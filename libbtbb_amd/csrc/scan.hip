@@ -494,13 +494,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 						t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
 					}
 				}
-			uint32_t anybit = 0, bit[UNROLL][2];
+			uint32_t anybit = 0, bit[UNROLL][2], i2[UNROLL][2];
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
-					if (VARIANT != 2 && VARIANT != 3 && m[u][h])
+					if (VARIANT == 8) {
+						// tables for >= 4 errors: the LDS bitmap passes more than half of the survivors,
+						// so probe the 2^26-bit bitmap in L2 / Infinity Cache right here instead
+						i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+						if (m[u][h])
+							bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
+					} else if (VARIANT != 2 && VARIANT != 3 && m[u][h])
 						bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
 				}
 #pragma unroll
@@ -509,8 +515,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int h = 0; h < 2; h++) {
 					if (VARIANT == 2 || VARIANT == 3)          // ablation: no bitmap probe
 						bit[u][h] = m[u][h] && proj[u][h] == 0x12345678u;
+					else if (VARIANT == 8)
+						bit[u][h] = (bw[u][h] >> (i2[u][h] & 31)) & 1;
 					else
 						bit[u][h] = (bw[u][h] >> (proj[u][h] & 31)) & 1;    // bw == 0 without a survivor
+					if (VARIANT == 9 && bit[u][h]) {
+						// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
+						const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+						bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
+					}
 					if (VARIANT == 4)                          // ablation: full probe, no candidates
 						bit[u][h] &= proj[u][h] == 0x12345678u;
 					anybit |= bit[u][h];
@@ -820,17 +833,24 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 			const char *v = getenv("BTBBX_SCAN_VARIANT");      // ablation switch for profiling only
 			variant = v ? atoi(v) : 0;
 		}
+		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
+		// 2^26-bit bitmap in L2 inside the survivor loop (after / instead of the LDS one)
+		int run_variant = variant;
+		if (variant == 0 && c.scan.bitmap2 && c.table_errors >= 4)
+			run_variant = c.table_errors == 4 ? 9 : 8;
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
 		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
-		switch (variant) {
+		switch (run_variant) {
 		case 1: LAUNCH_VARIANT(1); break;
 		case 2: LAUNCH_VARIANT(2); break;
 		case 3: LAUNCH_VARIANT(3); break;
 		case 4: LAUNCH_VARIANT(4); break;
 		case 5: LAUNCH_VARIANT(5); break;
 		case 7: LAUNCH_VARIANT(7); break;
+		case 8: LAUNCH_VARIANT(8); break;
+		case 9: LAUNCH_VARIANT(9); break;
 		default: LAUNCH_VARIANT(0); break;
 		}
 	} else {
