@@ -53,8 +53,9 @@ __device__ __forceinline__ uint64_t pk_bits(const uint64_t *w, uint32_t pos, uin
 	return n == 64 ? v : v & ((1ULL << n) - 1);
 }
 
-// n (1..64) whitening bits starting at phase idx (0..126)
-__device__ __forceinline__ uint64_t wh_bits(uint32_t idx, uint32_t n)
+// n (1..64) whitening bits starting at phase idx (0..126), straight from constant memory (used
+// where a kernel needs a handful of them; the decoders below use the LDS copies)
+__device__ __forceinline__ uint64_t wh_bits_const(uint32_t idx, uint32_t n)
 {
 	uint32_t i = idx >> 6, s = idx & 63;
 	uint64_t v = g_chain.whiten2[i] >> s;
@@ -63,19 +64,52 @@ __device__ __forceinline__ uint64_t wh_bits(uint32_t idx, uint32_t n)
 	return n == 64 ? v : v & ((1ULL << n) - 1);
 }
 
-__device__ __forceinline__ uint32_t wh_start(uint32_t clock, uint32_t skip)
+__device__ __forceinline__ uint32_t wh_start_const(uint32_t clock, uint32_t skip)
 {
 	return (g_chain.whiten_idx[clock & 63] + skip) % 127u;
+}
+
+// Per-workgroup LDS copies of the small tables the decoders index with per-lane values inside
+// their inner loops (whitening slice, CRC byte step, FEC 2/3 parity and correction): a DS read
+// instead of a divergent constant-memory load or a 10-step loop.  2.1 KiB, built by
+// chain_lds_init() at kernel start.
+struct ChainLds {
+	uint32_t wh32[128];        // 32 whitening bits from phase idx (idx <= 126)
+	uint16_t crc[256];         // crc_byte(0, x): one byte through the reflected CRC-CCITT register
+	uint8_t  par23[1024];      // FEC 2/3 parity of 10 data bits
+	int8_t   fix23[32];
+	uint8_t  whiten_idx[64];
+};
+__shared__ ChainLds g_lds;
+
+__device__ __forceinline__ uint64_t wh_bits(uint32_t idx, uint32_t n)
+{
+	uint64_t v = g_lds.wh32[idx];
+	if (n > 32) {
+		const uint32_t j = idx + 32;
+		v |= (uint64_t)g_lds.wh32[j >= 127 ? j - 127 : j] << 32;
+	}
+	return n == 64 ? v : v & ((1ULL << n) - 1);
+}
+
+__device__ __forceinline__ uint32_t wh_start(uint32_t clock, uint32_t skip)
+{
+	return (g_lds.whiten_idx[clock & 63] + skip) % 127u;
 }
 
 __device__ __forceinline__ uint32_t rev8(uint32_t b) { return __brev(b) >> 24; }
 
 // one byte through the reflected CRC-CCITT register of crcgen (:681-687)
-__device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t byte)
+__device__ __forceinline__ uint32_t crc_byte_calc(uint32_t crc, uint32_t byte)
 {
 	uint32_t x = (crc ^ byte) & 0xff;
 	x ^= (x << 4) & 0xff;
 	return ((crc >> 8) ^ (x << 8) ^ (x << 3) ^ (x >> 4)) & 0xffff;
+}
+// the same through the LDS table (the register update is linear: crc' = crc >> 8 ^ T[(crc ^ byte) & 0xff])
+__device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t byte)
+{
+	return (crc >> 8) ^ g_lds.crc[(crc ^ byte) & 0xff];
 }
 
 __device__ __forceinline__ uint32_t crc_seed(uint32_t uap) { return rev8(uap & 0xff) << 8; }
@@ -116,18 +150,34 @@ __device__ __forceinline__ uint32_t fec13(uint64_t v, uint32_t n, uint32_t &disa
 __device__ __forceinline__ bool fec23_block(uint32_t blk, uint32_t &data)
 {
 	data = blk & 0x3ff;
-	uint32_t par = 0;
-#pragma unroll
-	for (int i = 0; i < 10; i++)
-		if ((data >> i) & 1)
-			par ^= g_chain.fec23_par[i];
-	uint32_t diff = (blk >> 10) ^ par;
-	int fix = g_chain.fec23_fix[diff & 31];
+	uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
+	int fix = g_lds.fix23[diff & 31];
 	if (fix == -2)
 		return false;
 	if (fix >= 0)
 		data ^= 1u << fix;
 	return true;
+}
+
+// all threads of the workgroup; ends with a barrier
+__device__ void chain_lds_init()
+{
+	for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
+		g_lds.wh32[i] = (uint32_t)wh_bits_const(i < 127 ? i : 0, 32);
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+		g_lds.crc[i] = (uint16_t)crc_byte_calc(0, i);
+	for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+		uint32_t par = 0;
+		for (int b = 0; b < 10; b++)
+			if ((i >> b) & 1)
+				par ^= g_chain.fec23_par[b];
+		g_lds.par23[i] = (uint8_t)par;
+	}
+	for (uint32_t i = threadIdx.x; i < 32; i += blockDim.x)
+		g_lds.fix23[i] = g_chain.fec23_fix[i];
+	for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
+		g_lds.whiten_idx[i] = g_chain.whiten_idx[i];
+	__syncthreads();
 }
 
 // ---- packet state -----------------------------------------------------------------------------
@@ -566,12 +616,13 @@ __device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
 
 // ---- kernels --------------------------------------------------------------------------------
 
-// one wave per packet, one lane per CLK1-6 candidate
-__global__ __launch_bounds__(64) void trials_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
-						     uint32_t n_packets, btbbx_trial *trials)
+// one wave per packet (four packets per workgroup), one lane per CLK1-6 candidate
+__global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+						      uint32_t n_packets, btbbx_trial *trials)
 {
-	uint32_t pkt = blockIdx.x;
-	uint32_t clock = threadIdx.x;
+	chain_lds_init();
+	uint32_t pkt = blockIdx.x * 4 + (threadIdx.x >> 6);
+	uint32_t clock = threadIdx.x & 63;
 	if (pkt >= n_packets)
 		return;
 	const btbbx_pkt_in pi = in[pkt];
@@ -626,7 +677,7 @@ __global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets,
 	uint32_t wc[4] = {0, 0, 0, 0};                 // this lane's 8 clocks, two 16-bit entries per word
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		const uint32_t wb = (uint32_t)wh_bits(wh_start(8 * (lane & 7) + k, 0), 18);
+		const uint32_t wb = (uint32_t)wh_bits_const(wh_start_const(8 * (lane & 7) + k, 0), 18);
 		const uint32_t e = uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8);
 		wc[k >> 1] |= e << (16 * (k & 1));
 	}
@@ -656,6 +707,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode,
 						     TrialPlan plan)
 {
+	chain_lds_init();
 	uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pkt >= n_packets)
 		return;
@@ -805,7 +857,7 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 		return rc;
 	if (!n_packets)
 		return BTBBX_OK;
-	hipLaunchKernelGGL(trials_kernel, dim3(n_packets), dim3(64), 0, (hipStream_t)hip_stream,
+	hipLaunchKernelGGL(trials_kernel, dim3((n_packets + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
 			   d_packets, d_in, n_packets, d_trials);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
