@@ -620,14 +620,19 @@ __device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
 __global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 						      uint32_t n_packets, btbbx_trial *trials)
 {
-	chain_lds_init();
+	// the wave's packet goes to LDS first: all 64 candidate clocks pick bits out of the same 50 words
+	__shared__ uint64_t pkt_lds[4][BTBBX_PKT_WORDS + 2];
 	uint32_t pkt = blockIdx.x * 4 + (threadIdx.x >> 6);
 	uint32_t clock = threadIdx.x & 63;
+	if (clock < BTBBX_PKT_WORDS + 2)
+		pkt_lds[threadIdx.x >> 6][clock] = (pkt < n_packets && clock < BTBBX_PKT_WORDS)
+			? packets[(uint64_t)pkt * BTBBX_PKT_WORDS + clock] : 0;
+	chain_lds_init();
 	if (pkt >= n_packets)
 		return;
 	const btbbx_pkt_in pi = in[pkt];
 	PState s;
-	s.w = packets + (uint64_t)pkt * BTBBX_PKT_WORDS;
+	s.w = pkt_lds[threadIdx.x >> 6];
 	s.length = (int)pi.length;
 	s.flags = pi.flags;
 	s.uap = pi.uap;
