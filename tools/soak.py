@@ -31,12 +31,13 @@ def main():
     lib = bt.lib()
     t_end = time.time() + a.seconds
     done = {"cases": 0, "hits": 0, "by_init": {}}
-    for n_init in (2, 3, 1, 4):
+    inits = (2, 3, 1, 4, 5)
+    for n_init in inits:
         lib.btbbx_shutdown()
         bt.init(n_init)
         orc.orc_reset_syndrome_map()
         orc.orc_init(n_init)
-        t_part = time.time() + a.seconds / 4
+        t_part = time.time() + a.seconds / len(inits)
         while time.time() < min(t_end, t_part):
             # mostly short streams; one in ten spans several hundred tiles (XCD-partitioned tile order)
             nwords = int(rng.integers(1 << 18, 1 << 20)) if rng.random() < 0.1 else int(rng.integers(2, 1 << 13))
