@@ -130,6 +130,9 @@ int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search
 int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
 			   uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
 void btbbx_sort_hits(btbbx_hit *hits, size_t n);
+/* the same order for a hit list still in device memory (the host wrappers and the streaming ingest
+ * sort here before copying out); synchronises hip_stream */
+int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_stream);
 
 /* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
  * ceil(n_symbols / 64), the tail of the last word is zero */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "btbbx_scan_host": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
     "btbbx_scan_symbols": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
+    "btbbx_sort_hits_device": (C.c_int, [_vp, _u32, _vp]),
     "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_unpack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_msb_to_lsb_device": (C.c_int, [_vp, _u64, _vp]),

@@ -256,11 +256,13 @@ extern "C" int btbbx_init(int max_ac_errors)
 }
 
 void hop_pool_release();     // hop.hip
+void sort_scratch_release(); // sort.hip
 
 extern "C" void btbbx_shutdown(void)
 {
 	Ctx &c = g_ctx;
 	hop_pool_release();
+	sort_scratch_release();
 	if (c.d_tab_block) (void)hipFree(c.d_tab_block);
 	if (c.d_hslots) (void)hipFree(c.d_hslots);
 	if (c.d_bitmap2) (void)hipFree(c.d_bitmap2);

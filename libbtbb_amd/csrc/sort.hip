@@ -1,0 +1,69 @@
+// sort.hip -- (stream, offset) order for hit lists while they are still in HBM.
+//
+// The scan kernels append hits unordered; callers of the reference get them in stream order
+// (lib/src/bluetooth_packet.c:444-464 is called on a sliding window).  Sorting 10^6 records on the
+// host costs ~60 ms and used to be most of the PCIe-inclusive time of the ingest paths; on the
+// device it is a few hundred microseconds.  The sort itself is rocPRIM's LSD radix sort (AMD's own
+// primitive library, the plain-library case like a rocBLAS GEMM); this file adds the key
+// extraction and the scratch management.
+#include <string.h>
+#include <mutex>
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+struct __attribute__((aligned(16))) HitRec { uint64_t a, b; };      // a btbbx_hit as an opaque 16-byte value
+
+__global__ __launch_bounds__(256) void hit_keys_kernel(const btbbx_hit *hits, uint32_t n, uint64_t *keys)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n)
+		keys[i] = ((uint64_t)hits[i].stream << 48) | (hits[i].offset & 0xffffffffffffULL);
+}
+
+static std::mutex sort_lock;
+static void *sort_block;            // keys in | keys out | values out | rocPRIM temporary
+static size_t sort_block_bytes;
+
+void sort_scratch_release()         // btbbx_shutdown
+{
+	std::lock_guard<std::mutex> g(sort_lock);
+	if (sort_block)
+		(void)hipFree(sort_block);
+	sort_block = nullptr;
+	sort_block_bytes = 0;
+}
+
+extern "C" int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_stream)
+{
+	if (n < 2)
+		return BTBBX_OK;
+	hipStream_t stream = (hipStream_t)hip_stream;
+	std::lock_guard<std::mutex> g(sort_lock);
+	size_t tmp_bytes = 0;
+	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (HitRec *)nullptr,
+					  (HitRec *)nullptr, (size_t)n, 0u, 64u, stream));
+	const size_t key_bytes = ((size_t)n * 8 + 255) & ~(size_t)255, val_bytes = ((size_t)n * 16 + 255) & ~(size_t)255;
+	const size_t need = 2 * key_bytes + val_bytes + tmp_bytes + 256;
+	if (need > sort_block_bytes) {
+		if (sort_block)
+			(void)hipFree(sort_block);
+		sort_block = nullptr;
+		sort_block_bytes = 0;
+		const size_t want = need + need / 2;
+		hipError_t e = hipMalloc(&sort_block, want);
+		if (e != hipSuccess)
+			return hip_fail(e, "hipMalloc(sort scratch)");
+		sort_block_bytes = want;
+	}
+	char *p = (char *)sort_block;
+	uint64_t *k_in = (uint64_t *)p, *k_out = (uint64_t *)(p + key_bytes);
+	HitRec *v_out = (HitRec *)(p + 2 * key_bytes);
+	void *tmp = p + 2 * key_bytes + val_bytes;
+	hipLaunchKernelGGL(hit_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_hits, n, k_in);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, (HitRec *)d_hits, v_out, (size_t)n, 0u, 64u, stream));
+	HIP_TRY(hipMemcpyAsync(d_hits, v_out, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToDevice, stream));
+	// the scratch is shared: finish before another caller may reuse it
+	HIP_TRY(hipStreamSynchronize(stream));
+	return BTBBX_OK;
+}

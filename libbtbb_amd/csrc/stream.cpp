@@ -112,9 +112,14 @@ static int64_t collect(btbbx_stream *s, Slot &sl, btbbx_hit *hits, uint64_t cap)
 		set_error("btbbx_stream: more than %u hits in one chunk", s->hit_cap);
 		return BTBBX_E_NOMEM;
 	}
-	if (n && hipMemcpy(sl.h_hits, sl.d_hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost) != hipSuccess)
-		return hip_fail(hipGetLastError(), "d2h hits");
-	btbbx_sort_hits(sl.h_hits, n);
+	// order them while they are still in HBM (the next chunk is scanning on the other slot's stream)
+	if (n) {
+		int rc = btbbx_sort_hits_device(sl.d_hits, n, sl.stream);
+		if (rc)
+			return rc;
+		if (hipMemcpy(sl.h_hits, sl.d_hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost) != hipSuccess)
+			return hip_fail(hipGetLastError(), "d2h hits");
+	}
 	uint64_t out = 0;
 	for (uint32_t i = 0; i < n; i++) {
 		btbbx_hit h = sl.h_hits[i];

@@ -75,22 +75,28 @@ def main():
         dt = time.perf_counter() - t0
         lib.btbbx_stream_close(h)
         out[name] = {"symbols": total, "chunk": chunk, "seconds": round(dt, 4), "Gbit_s": round(total / dt / 1e9, 1), "hits": int(nh)}
-        # zero copy: the producer writes into the pinned buffer itself (not timed: stands for the capture DMA)
+        # zero copy: the producer (a capture DMA in real life) writes into the pinned buffers itself.
+        # Pipeline capacity without any producer cost: fill both buffers once (untimed), then keep
+        # submitting them as they are -- wall clock over copy in + scan + device sort + hits out.
         h = lib.btbbx_stream_open(bt.LAP_ANY, 2, chunk, fmt)
-        nh, tsub = 0, 0.0
-        for pos in range(0, total, chunk):
-            a0 = pos // 64 if fmt == 0 else pos
+        nh = 0
+        for k in range(2):
+            a0 = (k * chunk) // 64 if fmt == 0 else k * chunk
             part = src[a0:a0 + per]
             dst = lib.btbbx_stream_acquire(h)
             C.memmove(dst, part.ctypes.data, part.nbytes)
-            t0 = time.perf_counter()
-            nh += bt.check(lib.btbbx_stream_submit(h, min(chunk, total - pos), hits.ctypes.data, len(hits)))
-            tsub += time.perf_counter() - t0
-        t0 = time.perf_counter()
+            nh += bt.check(lib.btbbx_stream_submit(h, chunk, hits.ctypes.data, len(hits)))
         nh += bt.check(lib.btbbx_stream_flush(h, hits.ctypes.data, len(hits)))
-        tsub += time.perf_counter() - t0
+        rounds = 16
+        t0 = time.perf_counter()
+        for k in range(rounds):
+            assert lib.btbbx_stream_acquire(h)
+            nh += bt.check(lib.btbbx_stream_submit(h, chunk, hits.ctypes.data, len(hits)))
+        nh += bt.check(lib.btbbx_stream_flush(h, hits.ctypes.data, len(hits)))
+        dt = time.perf_counter() - t0
         lib.btbbx_stream_close(h)
-        out[name + "_zero_copy"] = {"seconds": round(tsub, 4), "Gbit_s": round(total / tsub / 1e9, 1), "hits": int(nh)}
+        out[name + "_zero_copy"] = {"symbols": rounds * chunk, "seconds": round(dt, 4), "Gbit_s": round(rounds * chunk / dt / 1e9, 1),
+                                    "hits": int(nh), "note": "pre-filled pinned buffers resubmitted, no producer cost"}
 
     # ---- drop-in btbb_find_ac latency on a 64 Ki-symbol window
     small = np.ascontiguousarray(sym[: 65536 + 72])
