@@ -5,6 +5,8 @@
 // chunks.  While chunk k is scanned, chunk k+1 is copied and packed.
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
+#include <vector>
 #include "common.h"
 
 extern "C" int64_t btbbx_stream_submit(btbbx_stream *s, uint64_t n_symbols, btbbx_hit *hits, uint64_t cap);
@@ -99,6 +101,28 @@ extern "C" btbbx_stream *btbbx_stream_open(uint32_t lap, int max_ac_errors, uint
 	return s;
 }
 
+static void staging_copy(void *dst, const void *src, size_t bytes)
+{
+	const size_t piece = 4u << 20;
+	unsigned hw = std::thread::hardware_concurrency();
+	size_t parts = bytes / piece;
+	if (parts > 8) parts = 8;
+	if (hw && parts > hw) parts = hw;
+	if (parts < 2) {
+		memcpy(dst, src, bytes);
+		return;
+	}
+	std::vector<std::thread> pool;
+	const size_t each = ((bytes / parts) + 63) & ~(size_t)63;
+	for (size_t k = 1; k < parts; k++) {
+		const size_t lo = k * each, hi = k + 1 == parts ? bytes : (k + 1) * each;
+		pool.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+	}
+	memcpy(dst, src, each);
+	for (auto &t : pool)
+		t.join();
+}
+
 // wait for a slot's launch and hand its hits out with global offsets
 static int64_t collect(btbbx_stream *s, Slot &sl, btbbx_hit *hits, uint64_t cap)
 {
@@ -152,7 +176,8 @@ extern "C" int64_t btbbx_stream_feed(btbbx_stream *s, const void *data, uint64_t
 		set_error("btbbx_stream_feed: internal: slot still busy");
 		return BTBBX_E_ARG;
 	}
-	memcpy(dst, data, s->format == BTBBX_FMT_SYMBOLS ? n_symbols : ((n_symbols + 63) / 64) * 8);
+	// the staging copy is the slowest stage of feed(): split large chunks over a few host threads
+	staging_copy(dst, data, s->format == BTBBX_FMT_SYMBOLS ? n_symbols : ((n_symbols + 63) / 64) * 8);
 	return btbbx_stream_submit(s, n_symbols, hits, cap);
 }
 
