@@ -312,3 +312,25 @@ def test_streaming_ingest(fmt):
         lib.btbbx_stream_close(h)
         assert got == want, (fmt, chunk, len(got), len(want))
     assert len(want) > 100
+
+
+def test_device_hit_sort():
+    """btbbx_sort_hits_device orders (stream, offset) like the host routine, keeps every record."""
+    lib = bt.lib()
+    rng = np.random.default_rng(7)
+    for n, streams, maxoff in ((1, 1, 10), (2, 2, 100), (777, 3, 1 << 20), (100000, 79, 1 << 33), (2500000, 1, 1 << 40)):
+        h = np.zeros(n, bt.HIT_DTYPE)
+        h["offset"] = rng.integers(0, maxoff, n, dtype=np.uint64)
+        h["stream"] = rng.integers(0, streams, n)
+        h["lap"] = rng.integers(0, 1 << 24, n)
+        h["ac_errors"] = rng.integers(0, 6, n)
+        d = bt.DeviceBuffer(h.nbytes).upload(h)
+        bt.check(lib.btbbx_sort_hits_device(d.ptr, n, None))
+        got = d.download(bt.HIT_DTYPE, n)
+        d.free()
+        host = h.copy()
+        lib.btbbx_sort_hits(host.ctypes.data, n)
+        key = lambda a: (a["stream"].astype(np.uint64) << np.uint64(48)) | a["offset"]
+        assert np.array_equal(key(got), key(host)) and np.all(np.diff(key(got).astype(np.int64)) >= 0)
+        full = ["stream", "offset", "lap", "ac_errors"]
+        assert np.array_equal(np.sort(got, order=full), np.sort(h, order=full))      # a permutation of the input
