@@ -13,6 +13,11 @@
 #include "packet_obj.h"
 #include "../../include/btbb.h"
 
+int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
+			btbbx_trial *d_trials, hipStream_t stream);
+int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, const TrialPlan *plan,
+			hipStream_t stream);
+size_t trials_state_bytes();
 int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 		  btbbx_pkt_out *d_out, uint32_t mode, const TrialPlan *plan, hipStream_t stream);
 
@@ -337,7 +342,8 @@ char *tun_format(btbb_packet *pkt)
 #define PB_PAY     3648u       // 2752 payload bit bytes
 #define PB_PKT     6400u       // 50 packed words
 #define PB_TRIALS  6848u       // 64 btbbx_trial
-#define PB_TOTAL   8192u
+#define PB_STATE   8192u       // 64 per-trial write sets (packet.hip: TrialState)
+#define PB_TOTAL   (8192u + 32768u)
 static_assert(sizeof(btbbx_pkt_out) <= PB_PAY - PB_OUT, "pkt_out slot");
 
 struct DevPacketBufs {
@@ -394,44 +400,9 @@ static void stage_symbols(const btbb_packet *pkt, DevPacketBufs &b)
 	memset(b.host + PB_SYM + PKT_MAX_SYMBOLS, 0, 3200 - PKT_MAX_SYMBOLS);
 }
 
-int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
+// entry state of the decoders as btbbx_pkt_out (what a call may leave untouched)
+static void fill_out(const btbb_packet *pkt, btbbx_pkt_out &out)
 {
-	if (!gpu_ready("btbb_uap_from_header"))
-		return BTBBX_E_NODEVICE;
-	DevPacketBufs b;
-	int rc = dev_bufs(b);
-	if (rc) return rc;
-	stage_symbols(pkt, b);
-	btbbx_pkt_in in;
-	fill_in(pkt, in);
-	memcpy(b.host + PB_IN, &in, sizeof(in));
-	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_OUT, hipMemcpyHostToDevice, nullptr));
-	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
-	if (rc) return rc;
-	rc = btbbx_trials_device(b.d_pkt, b.d_in, 1, b.d_trials, nullptr);
-	if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, nullptr));
-	HIP_TRY(hipStreamSynchronize(nullptr));
-	memcpy(trials64, b.host + PB_TRIALS, 64 * sizeof(btbbx_trial));
-	return BTBBX_OK;
-}
-
-int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, int *header_present,
-		      int *header_rv, int *payload_rv, bool symbols_resident)
-{
-	if (!gpu_ready("btbb_decode"))
-		return BTBBX_E_NODEVICE;
-	DevPacketBufs b;
-	int rc = dev_bufs(b);
-	if (rc) return rc;
-	// symbols_resident: the packed symbols of this very packet are still in d_pkt from the
-	// packet_gpu_trials call just before (btbb_uap_from_header) -- no second upload / pack
-	if (!symbols_resident)
-		stage_symbols(pkt, b);
-
-	btbbx_pkt_in in;
-	fill_in(pkt, in);
-	btbbx_pkt_out out;
 	memset(&out, 0, sizeof(out));
 	out.payload_length = pkt->payload_length;
 	out.payload_header_length = pkt->payload_header_length;
@@ -441,6 +412,97 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 	out.hdr_flags = pkt->packet_flags;
 	out.hec = pkt->packet_hec;
 	out.payload_header = bits_of(pkt->payload_header, 16);
+}
+
+static void apply_out(btbb_packet *pkt, const btbbx_pkt_out &out, bool payload_too, const DevPacketBufs &b)
+{
+	if (payload_too)
+		memcpy(pkt->payload, b.host + PB_PAY, PKT_MAX_PAYLOAD_BITS);
+	pkt->flags = out.flags;
+	pkt->UAP = out.uap;
+	pkt->packet_type = out.type;
+	pkt->packet_lt_addr = out.lt_addr;
+	pkt->packet_flags = out.hdr_flags;
+	pkt->packet_hec = out.hec;
+	for (int i = 0; i < 18; i++)
+		pkt->packet_header[i] = (char)((out.header_packed >> i) & 1);
+	pkt->payload_header_length = out.payload_header_length;
+	for (int i = 0; i < 16; i++)
+		pkt->payload_header[i] = (char)((out.payload_header >> i) & 1);
+	pkt->payload_llid = out.llid;
+	pkt->payload_flow = out.flow;
+	pkt->payload_length = out.payload_length;
+}
+
+// Step 1 of btbb_uap_from_header: all 64 trials, each with its packet writes captured on the
+// device, and the {try_clock, type, crc_check} table back on the host.
+int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
+{
+	if (!gpu_ready("btbb_uap_from_header"))
+		return BTBBX_E_NODEVICE;
+	DevPacketBufs b;
+	int rc = dev_bufs(b);
+	if (rc) return rc;
+	if (trials_state_bytes() > PB_TOTAL - PB_STATE) {
+		set_error("internal: trial state area too small");
+		return BTBBX_E_ARG;
+	}
+	stage_symbols(pkt, b);
+	btbbx_pkt_in in;
+	fill_in(pkt, in);
+	btbbx_pkt_out out;
+	fill_out(pkt, out);
+	memcpy(b.host + PB_IN, &in, sizeof(in));
+	memcpy(b.host + PB_OUT, &out, sizeof(out));
+	memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
+	memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_PKT, hipMemcpyHostToDevice, nullptr));
+	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+	if (rc) return rc;
+	rc = btbbx_pack_device(b.d_pay, 2752, (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), nullptr);
+	if (rc) return rc;
+	rc = launch_trials_state(b.d_pkt, b.d_in, b.d_out, b.dev + PB_STATE, b.d_trials, nullptr);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	memcpy(trials64, b.host + PB_TRIALS, 64 * sizeof(btbbx_trial));
+	return BTBBX_OK;
+}
+
+// Step 2: leave the packet as the trials in `plan` leave it in the reference.
+// Must follow packet_gpu_trials() of the same packet directly: everything it needs is still on
+// the device.
+int packet_gpu_trials_commit(btbb_packet *pkt, const TrialPlan *plan)
+{
+	DevPacketBufs b;
+	int rc = dev_bufs(b);
+	if (rc) return rc;
+	rc = launch_trials_merge(b.dev + PB_STATE, b.d_in, b.d_out, plan, nullptr);
+	if (rc) return rc;
+	rc = btbbx_unpack_device((const uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), 2752, b.d_pay, nullptr);
+	if (rc) return rc;
+	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, PB_PKT - PB_OUT, hipMemcpyDeviceToHost, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	btbbx_pkt_out out;
+	memcpy(&out, b.host + PB_OUT, sizeof(out));
+	apply_out(pkt, out, true, b);
+	return BTBBX_OK;
+}
+
+int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, int *header_present,
+		      int *header_rv, int *payload_rv)
+{
+	if (!gpu_ready("btbb_decode"))
+		return BTBBX_E_NODEVICE;
+	DevPacketBufs b;
+	int rc = dev_bufs(b);
+	if (rc) return rc;
+	stage_symbols(pkt, b);
+
+	btbbx_pkt_in in;
+	fill_in(pkt, in);
+	btbbx_pkt_out out;
+	fill_out(pkt, out);
 	memcpy(b.host + PB_IN, &in, sizeof(in));
 	memcpy(b.host + PB_OUT, &out, sizeof(out));
 	const bool touches_payload = mode & (DEC_PAYLOAD | DEC_TRIALS);
@@ -449,13 +511,9 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 		memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
 		memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
 	}
-	const uint32_t up_from = symbols_resident ? PB_IN : 0u;
-	HIP_TRY(hipMemcpyAsync(b.dev + up_from, b.host + up_from, (touches_payload ? PB_PKT : PB_PAY) - up_from,
-			       hipMemcpyHostToDevice, nullptr));
-	if (!symbols_resident) {
-		rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
-		if (rc) return rc;
-	}
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, nullptr));
+	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+	if (rc) return rc;
 	uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
 	if (touches_payload) {
 		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, nullptr);
@@ -478,21 +536,6 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 	if (mode == 0)
 		return BTBBX_OK;           // btbb_header_present: const, nothing written back
 
-	if (touches_payload)
-		memcpy(pkt->payload, b.host + PB_PAY, PKT_MAX_PAYLOAD_BITS);
-	pkt->flags = out.flags;
-	pkt->UAP = out.uap;
-	pkt->packet_type = out.type;
-	pkt->packet_lt_addr = out.lt_addr;
-	pkt->packet_flags = out.hdr_flags;
-	pkt->packet_hec = out.hec;
-	for (int i = 0; i < 18; i++)
-		pkt->packet_header[i] = (char)((out.header_packed >> i) & 1);
-	pkt->payload_header_length = out.payload_header_length;
-	for (int i = 0; i < 16; i++)
-		pkt->payload_header[i] = (char)((out.payload_header >> i) & 1);
-	pkt->payload_llid = out.llid;
-	pkt->payload_flow = out.flow;
-	pkt->payload_length = out.payload_length;
+	apply_out(pkt, out, touches_payload, b);
 	return BTBBX_OK;
 }

@@ -17,6 +17,7 @@
 // Reference quirks kept: FEC-2/3 reads past pkt->length (DM), EV3/EV5 re-use the first
 // payload byte (:1036, :1122), DV whitening restarts at 18 (:913-937), a failed FEC 1/3
 // leaves UAP/type from the previous trial (:1186-1187).
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "packet_obj.h"
@@ -196,7 +197,14 @@ struct PState {
 	// payload writer
 	uint64_t *out;           // 43 words or nullptr
 	uint32_t written;        // payload bits written (prefix)
+	// which fields a trial assigned (replay_kernel merges 64 trials by "last writer wins")
+	uint32_t dirty;          // D_* bits
+	uint32_t ph_mask;        // payload-header bits assigned
 };
+#define D_UT    1u           // uap, type        (try_clock)
+#define D_PLEN  2u           // payload_length
+#define D_PHL   4u           // payload_header_length
+#define D_LF    8u           // llid, flow
 
 // streams payload bits into the CRC (whole bytes) and, when WRITE, into the output words
 template <bool WRITE>
@@ -261,6 +269,7 @@ __device__ int do_fhs(PState &s, uint32_t clock)
 {
 	int size = s.length - 122;
 	s.plen = 20;
+	s.dirty |= D_PLEN;
 	if (size < 240)
 		return 1;
 	uint64_t corr[3] = {0, 0, 0};
@@ -324,6 +333,8 @@ __device__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int h
 	}
 	uint32_t ph = raw ^ (uint32_t)wh(s, wh_start(clock, 18), hbits);
 	s.ph16 = (s.ph16 & ~((1u << hbits) - 1)) | ph;
+	s.ph_mask |= (1u << hbits) - 1;
+	s.dirty |= D_PLEN | D_LF | D_PHL;
 	if (s.ph_written < hbits) s.ph_written = hbits;
 	int plen = header_bytes == 2 ? (int)((s.ph16 >> 3) & 0x3ff) + 4 : (int)((s.ph16 >> 3) & 0x1f) + 3;
 	int cap;
@@ -448,6 +459,7 @@ __device__ int do_EV35(PState &s, uint32_t clock, int maxlength)
 	}
 	sink.flush();
 	s.plen = L;
+	s.dirty |= D_PLEN;
 	return rv;
 }
 
@@ -496,6 +508,7 @@ __device__ int do_EV4(PState &s, uint32_t clock)
 		s.out[oword] = (s.out[oword] & keep) | oacc;
 	}
 	s.plen = L;
+	s.dirty |= D_PLEN;
 	return rv;
 }
 
@@ -505,8 +518,10 @@ __device__ int do_HV(PState &s, uint32_t clock)
 {
 	int size = s.length - 122;
 	s.phl = 0;
+	s.dirty |= D_PHL;
 	if (size < 240) {
 		s.plen = 0;
+		s.dirty |= D_PLEN;
 		return 1;
 	}
 	uint32_t idx = wh_start(clock, 18);
@@ -520,6 +535,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 		if (!(total < 20))
 			return 0;
 		s.plen = 10;
+		s.dirty |= D_PLEN;
 		s.flags |= F_HAS_PAYLOAD;
 		if (WRITE) {
 			Sink<true> sink(0, s.out);
@@ -534,6 +550,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 		if (!fec23_ok(s.w, 122, 16))
 			return 0;
 		s.plen = 20;
+		s.dirty |= D_PLEN;
 		s.flags |= F_HAS_PAYLOAD;
 		if (WRITE) {
 			Sink<true> sink(0, s.out);
@@ -548,6 +565,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 		}
 	} else if (s.type == 7) {
 		s.plen = 30;
+		s.dirty |= D_PLEN;
 		s.flags |= F_HAS_PAYLOAD;
 		if (WRITE) {
 			Sink<true> sink(0, s.out);
@@ -598,6 +616,7 @@ __device__ __forceinline__ uint32_t do_try_clock(PState &s, uint32_t clock, uint
 	uint32_t clear = hdr ^ (uint32_t)wh(s, wh_start(clock, 0), 18);
 	s.uap = uap_from_hec(clear & 0x3ff, clear >> 10);
 	s.type = (clear >> 3) & 0xf;
+	s.dirty |= D_UT;
 	return s.uap;
 }
 
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, co
 	s.type = pi.type;
 	s.llid = pi.llid;
 	s.flow = pi.flow;
-	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0;
+	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
 	s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
 	s.out = nullptr;
 	s.written = 0;
@@ -705,8 +724,8 @@ __global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets,
 // mode bits of decode_kernel (packet_obj.h):
 //   DEC_HEADER   btbb_decode_header
 //   DEC_PAYLOAD  btbb_decode_payload (after a successful header when DEC_HEADER is set)
-//   DEC_TRIALS   replay, in candidate order and with all state written, the try_clock /
-//                crc_check calls btbb_uap_from_header made (plan says which ones)
+// (DEC_TRIALS -- leave the packet as a set of try_clock / crc_check calls leaves it -- is
+//  replay_kernel / trials_state_kernel + trials_merge_kernel below)
 
 __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode,
@@ -730,6 +749,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 	s.phl = o->payload_header_length;
 	s.ph16 = (uint32_t)o->payload_header;
 	s.ph_written = 0;
+	s.dirty = 0;
+	s.ph_mask = 0;
 	s.lt_addr = o->lt_addr; s.hdr_flags = o->hdr_flags; s.hec = o->hec; s.header18 = o->header_packed;
 	s.out = o->payload;
 	s.written = 0;
@@ -737,17 +758,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 	int header_rv = 0, payload_rv = 0;
 	o->header_present = (uint8_t)do_header_present(s.w, s.length);
 
-	if (mode & DEC_TRIALS) {
-		uint32_t dis;
-		uint32_t hdr = header_fec13(s.w, dis);
-		for (uint32_t count = 0; count < 64; count++) {
-			uint32_t clock = (count + plan.clock_offset) & 63;
-			if ((plan.try_mask >> count) & 1)
-				header_rv = (int)do_try_clock(s, clock, hdr, dis);
-			if ((plan.crc_mask >> count) & 1)
-				payload_rv = do_crc_check<true>(s, clock);
-		}
-	} else {
+	{
 		bool go = true;
 		if (mode & DEC_HEADER) {
 			// btbb_decode_header (:1198-1221)
@@ -804,6 +815,236 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 	o->uap = (uint8_t)s.uap;
 	o->payload_header = s.ph16;
 }
+
+// DEC_TRIALS for one packet, 64 trials at once: lane = candidate count, every lane starts from the
+// entry state and writes into a private payload buffer; what the reference's sequential loop
+// (bluetooth_piconet.c:675-690) leaves in the packet is then "last writer wins" per field and per
+// payload bit, taken in lane order.  Valid because a trial never reads what an earlier trial
+// wrote: try_clock + crc_check(c) depend on the entry UAP / type only when FEC 1/3 fails (then for
+// every clock alike), the payload header merge is bitwise, and EV4's llid / flow read never
+// decides anything (see the identities at the top of this file).
+__global__ __launch_bounds__(64) void replay_kernel(const uint64_t *packet, const btbbx_pkt_in *in, btbbx_pkt_out *o,
+						     TrialPlan plan)
+{
+	__shared__ uint64_t pay[64][44];
+	__shared__ uint32_t wrote[64];
+	chain_lds_init();
+	const uint32_t lane = threadIdx.x;
+	const btbbx_pkt_in pi = in[0];
+	PState s;
+	s.w = packet;
+	s.length = (int)pi.length;
+	s.flags = pi.flags;
+	s.uap = pi.uap;
+	s.type = pi.type;
+	s.llid = pi.llid;
+	s.flow = pi.flow;
+	s.plen = o->payload_length;
+	s.phl = o->payload_header_length;
+	s.ph16 = (uint32_t)o->payload_header;
+	s.ph_written = 0;
+	s.dirty = 0;
+	s.ph_mask = 0;
+	s.lt_addr = o->lt_addr; s.hdr_flags = o->hdr_flags; s.hec = o->hec; s.header18 = o->header_packed;
+	s.out = pay[lane];
+	s.written = 0;
+	for (int j = 0; j < 44; j++)
+		pay[lane][j] = 0;
+	const uint32_t entry_flags = s.flags;
+
+	const bool do_try = (plan.try_mask >> lane) & 1, do_crc = (plan.crc_mask >> lane) & 1;
+	const uint32_t clock = (lane + plan.clock_offset) & 63;
+	uint32_t dis;
+	const uint32_t hdr = header_fec13(s.w, dis);
+	int header_rv = 0, payload_rv = 0;
+	if (do_try)
+		header_rv = (int)do_try_clock(s, clock, hdr, dis);
+	if (do_crc)
+		payload_rv = do_crc_check<true>(s, clock);
+	wrote[lane] = s.written;
+	__syncthreads();
+
+	// scalar fields: the highest lane that assigned them
+	auto last = [&](bool mine) { const uint64_t m = __ballot(mine); return m ? 63 - (int)__builtin_clzll(m) : -1; };
+	const int l_ut = last(s.dirty & D_UT), l_plen = last(s.dirty & D_PLEN), l_phl = last(s.dirty & D_PHL);
+	const int l_lf = last(s.dirty & D_LF), l_ph8 = last(s.ph_mask & 0xff), l_ph16 = last(s.ph_mask & 0xff00);
+	const int l_try = last(do_try), l_crc = last(do_crc);
+	const uint32_t f_uap = l_ut >= 0 ? (uint32_t)__shfl((int)s.uap, l_ut) : pi.uap;
+	const uint32_t f_type = l_ut >= 0 ? (uint32_t)__shfl((int)s.type, l_ut) : pi.type;
+	const int f_plen = l_plen >= 0 ? __shfl(s.plen, l_plen) : o->payload_length;
+	const int f_phl = l_phl >= 0 ? __shfl(s.phl, l_phl) : o->payload_header_length;
+	const uint32_t f_llid = l_lf >= 0 ? (uint32_t)__shfl((int)s.llid, l_lf) : pi.llid;
+	const uint32_t f_flow = l_lf >= 0 ? (uint32_t)__shfl((int)s.flow, l_lf) : pi.flow;
+	uint32_t f_ph = (uint32_t)o->payload_header;
+	if (l_ph8 >= 0)
+		f_ph = (f_ph & ~0xffu) | ((uint32_t)__shfl((int)s.ph16, l_ph8) & 0xffu);
+	if (l_ph16 >= 0)
+		f_ph = (f_ph & ~0xff00u) | ((uint32_t)__shfl((int)s.ph16, l_ph16) & 0xff00u);
+	uint32_t f_flags = s.flags & ~entry_flags;                  // bits this trial added (HAS_PAYLOAD)
+	for (int d = 32; d; d >>= 1)
+		f_flags |= (uint32_t)__shfl_xor((int)f_flags, d);
+	f_flags |= entry_flags;
+	const int f_hrv = l_try >= 0 ? __shfl(header_rv, l_try) : 0;
+	const int f_prv = l_crc >= 0 ? __shfl(payload_rv, l_crc) : 0;
+
+	// payload: word j takes, from the highest lane down, the bits that lane's prefix covers
+	if (lane < 43) {
+		uint64_t word = o->payload[lane], undecided = ~0ULL;
+		for (int k = 63; k >= 0 && undecided; k--) {
+			const uint32_t w = wrote[k];
+			if (w <= 64u * lane)
+				continue;
+			const uint32_t nb = w - 64u * lane;
+			const uint64_t covers = (nb >= 64 ? ~0ULL : ((1ULL << nb) - 1)) & undecided;
+			word = (word & ~covers) | (pay[k][lane] & covers);
+			undecided &= ~covers;
+		}
+		o->payload[lane] = word;
+	}
+	if (lane == 0) {
+		o->header_present = (uint8_t)do_header_present(s.w, s.length);
+		o->header_rv = f_hrv;
+		o->payload_rv = f_prv;
+		o->payload_length = f_plen;
+		o->payload_header_length = f_phl;
+		o->flags = f_flags;
+		o->type = (uint8_t)f_type;
+		o->llid = (uint8_t)f_llid;
+		o->flow = (uint8_t)f_flow;
+		o->uap = (uint8_t)f_uap;
+		o->payload_header = f_ph;
+	}
+}
+
+// The same for btbb_uap_from_header in two steps, so that the 64 trials run once: step 1 runs every
+// trial with its writes captured per lane (TrialState in global memory) and returns the
+// {try_clock, type, crc_check} table; the host then eliminates candidates exactly like the
+// reference and hands back which trials the reference would have executed; step 2 merges those.
+struct TrialState {
+	uint32_t dirty, ph16, ph_mask, flags_added, written;
+	int32_t plen, phl;
+	uint8_t uap, type, llid, flow;
+	uint64_t payload[44];
+};
+
+__global__ __launch_bounds__(64) void trials_state_kernel(const uint64_t *packet, const btbbx_pkt_in *in,
+							   const btbbx_pkt_out *o, TrialState *st, btbbx_trial *trials)
+{
+	chain_lds_init();
+	const uint32_t lane = threadIdx.x;
+	const btbbx_pkt_in pi = in[0];
+	TrialState *me = st + lane;
+	PState s;
+	s.w = packet;
+	s.length = (int)pi.length;
+	s.flags = pi.flags;
+	s.uap = pi.uap;
+	s.type = pi.type;
+	s.llid = pi.llid;
+	s.flow = pi.flow;
+	s.plen = o->payload_length;
+	s.phl = o->payload_header_length;
+	s.ph16 = (uint32_t)o->payload_header;
+	s.ph_written = 0;
+	s.dirty = 0;
+	s.ph_mask = 0;
+	s.lt_addr = o->lt_addr; s.hdr_flags = o->hdr_flags; s.hec = o->hec; s.header18 = o->header_packed;
+	s.out = me->payload;
+	s.written = 0;
+	for (int j = 0; j < 44; j++)
+		me->payload[j] = 0;
+	uint32_t dis;
+	const uint32_t hdr = header_fec13(s.w, dis);
+	const uint32_t uap = do_try_clock(s, lane, hdr, dis);
+	const int rv = do_crc_check<true>(s, lane);
+	btbbx_trial t;
+	t.uap = (uint8_t)uap;
+	t.type = (uint8_t)s.type;
+	t.rv = (int16_t)rv;
+	trials[lane] = t;
+	me->dirty = s.dirty;
+	me->ph16 = s.ph16;
+	me->ph_mask = s.ph_mask;
+	me->flags_added = s.flags & ~pi.flags;
+	me->written = s.written;
+	me->plen = s.plen;
+	me->phl = s.phl;
+	me->uap = (uint8_t)s.uap;
+	me->type = (uint8_t)s.type;
+	me->llid = (uint8_t)s.llid;
+	me->flow = (uint8_t)s.flow;
+}
+
+// lane = candidate count; the trial it stands for ran with clock (count + clock_offset) & 63
+__global__ __launch_bounds__(64) void trials_merge_kernel(const TrialState *st, const btbbx_pkt_in *in, btbbx_pkt_out *o,
+							   TrialPlan plan)
+{
+	__shared__ uint32_t wrote[64];
+	__shared__ uint32_t src_of[64];
+	const uint32_t lane = threadIdx.x;
+	const btbbx_pkt_in pi = in[0];
+	const TrialState *me = st + ((lane + plan.clock_offset) & 63);
+	const bool did_try = (plan.try_mask >> lane) & 1, did_crc = (plan.crc_mask >> lane) & 1;
+	const uint32_t dirty = (did_try ? me->dirty & D_UT : 0u) | (did_crc ? me->dirty & ~D_UT : 0u);
+	const uint32_t ph_mask = did_crc ? me->ph_mask : 0u;
+	wrote[lane] = did_crc ? me->written : 0u;
+	src_of[lane] = (lane + plan.clock_offset) & 63;
+	__syncthreads();
+	auto last = [&](bool mine) { const uint64_t m = __ballot(mine); return m ? 63 - (int)__builtin_clzll(m) : -1; };
+	const int l_ut = last(dirty & D_UT), l_plen = last(dirty & D_PLEN), l_phl = last(dirty & D_PHL);
+	const int l_lf = last(dirty & D_LF), l_ph8 = last(ph_mask & 0xff), l_ph16 = last(ph_mask & 0xff00);
+	uint32_t f_flags = did_crc ? me->flags_added : 0u;
+	for (int d = 32; d; d >>= 1)
+		f_flags |= (uint32_t)__shfl_xor((int)f_flags, d);
+	if (lane < 43) {
+		uint64_t word = o->payload[lane], undecided = ~0ULL;
+		for (int k = 63; k >= 0 && undecided; k--) {
+			const uint32_t w = wrote[k];
+			if (w <= 64u * lane)
+				continue;
+			const uint32_t nb = w - 64u * lane;
+			const uint64_t covers = (nb >= 64 ? ~0ULL : ((1ULL << nb) - 1)) & undecided;
+			word = (word & ~covers) | (st[src_of[k]].payload[lane] & covers);
+			undecided &= ~covers;
+		}
+		o->payload[lane] = word;
+	}
+	if (lane == 0) {
+		auto at = [&](int l) { return st + ((l + plan.clock_offset) & 63); };
+		if (l_ut >= 0) { o->uap = at(l_ut)->uap; o->type = at(l_ut)->type; } else { o->uap = pi.uap; o->type = pi.type; }
+		if (l_plen >= 0) o->payload_length = at(l_plen)->plen;
+		if (l_phl >= 0) o->payload_header_length = at(l_phl)->phl;
+		if (l_lf >= 0) { o->llid = at(l_lf)->llid; o->flow = at(l_lf)->flow; } else { o->llid = pi.llid; o->flow = pi.flow; }
+		uint32_t ph = (uint32_t)o->payload_header;
+		if (l_ph8 >= 0) ph = (ph & ~0xffu) | (at(l_ph8)->ph16 & 0xffu);
+		if (l_ph16 >= 0) ph = (ph & ~0xff00u) | (at(l_ph16)->ph16 & 0xff00u);
+		o->payload_header = ph;
+		o->flags = pi.flags | f_flags;
+		o->header_rv = 0;
+		o->payload_rv = 0;
+	}
+}
+
+int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
+			btbbx_trial *d_trials, hipStream_t stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(trials_state_kernel, dim3(1), dim3(64), 0, stream, d_packet, d_in, d_out, (TrialState *)d_state, d_trials);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, const TrialPlan *plan,
+			hipStream_t stream)
+{
+	hipLaunchKernelGGL(trials_merge_kernel, dim3(1), dim3(64), 0, stream, (const TrialState *)d_state, d_in, d_out, *plan);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+size_t trials_state_bytes() { return 64 * sizeof(TrialState); }
 
 // cut packets out of the packed streams
 __global__ __launch_bounds__(64) void gather_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
@@ -897,6 +1138,15 @@ int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t 
 	TrialPlan p = {0, 0, 0};
 	if (plan)
 		p = *plan;
+	if (mode & DEC_TRIALS) {                 // single try_clock / crc_check calls of the drop-in API
+		if (mode != DEC_TRIALS || n_packets != 1) {
+			set_error("decode: trial replay is a one-packet mode");
+			return BTBBX_E_ARG;
+		}
+		hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(64), 0, stream, d_packets, d_in, d_out, p);
+		HIP_TRY(hipGetLastError());
+		return BTBBX_OK;
+	}
 	hipLaunchKernelGGL(decode_kernel, dim3((n_packets + 63) / 64), dim3(64), 0, stream,
 			   d_packets, d_in, n_packets, d_out, mode, p);
 	HIP_TRY(hipGetLastError());

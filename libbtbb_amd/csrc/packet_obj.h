@@ -68,5 +68,6 @@ struct TrialPlan {            // which of the 64 candidate trials to replay, in 
 	uint32_t clock_offset;    // clock(count) = (count + clock_offset) % 64
 };
 int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, int *header_present,
-		      int *header_rv, int *payload_rv, bool symbols_resident = false);
+		      int *header_rv, int *payload_rv);
 int packet_gpu_trials(const btbb_packet *pkt, struct btbbx_trial *trials64);
+int packet_gpu_trials_commit(btbb_packet *pkt, const TrialPlan *plan);   // directly after packet_gpu_trials

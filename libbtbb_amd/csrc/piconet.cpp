@@ -5,9 +5,9 @@
 // (btbb_uap_from_header), :792-899 (AFH print, survey, btbb_process_packet).  The 64
 // candidate trials (try_clock + crc_check per CLK1-6 value) run as ONE GPU launch
 // (packet.hip: trials_kernel); the candidate elimination -- inherently sequential across the
-// packets of a piconet -- is replayed here on the host from that table, and a second launch
-// replays exactly the executed trials with all packet state written so that the packet
-// object ends up as the reference leaves it.
+// packets of a piconet -- is replayed here on the host from that table, and a second, small
+// launch merges the writes of exactly the executed trials (captured per trial by the first
+// launch) so that the packet object ends up as the reference leaves it.
 // CLK1-27 reversal (:365-413 pattern cache, :475-498 btbb_init_hop_reversal, :501-543 try_hop,
 // :575-645 winnowing) keeps the reference's host state machine; the hop selection itself and
 // the candidate lists live on the GPU (hop.hip), with no 128 MiB pattern table: what the
@@ -219,7 +219,7 @@ int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn)
 	}
 
 	// leave the packet object as the executed trials leave it in the reference
-	if (packet_gpu_decode(pkt, DEC_TRIALS, &plan, nullptr, nullptr, nullptr, true))
+	if (packet_gpu_trials_commit(pkt, &plan))
 		fprintf(stderr, "btbb_uap_from_header: state replay failed: %s\n", btbbx_last_error());
 	if (result >= 0)
 		return result;
