@@ -673,6 +673,41 @@ __global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, co
 	trials[(uint64_t)pkt * 64 + clock] = t;
 }
 
+// Small batches (a handful of packets from a live receiver): one workgroup per (packet, clock),
+// lane 0 runs the trial.  64 x n waves spread over the CUs, none of them serialising different packet
+// types, so the call takes as long as the longest single trial -- the lane-per-clock kernel above is
+// the throughput shape, this one the latency shape.
+__global__ __launch_bounds__(64) void trials_wide_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+							  uint32_t n_packets, btbbx_trial *trials)
+{
+	chain_lds_init();
+	const uint32_t pkt = blockIdx.x >> 6, clock = blockIdx.x & 63;
+	if (threadIdx.x || pkt >= n_packets)
+		return;
+	const btbbx_pkt_in pi = in[pkt];
+	PState s;
+	s.w = packets + (uint64_t)pkt * BTBBX_PKT_WORDS;
+	s.length = (int)pi.length;
+	s.flags = pi.flags;
+	s.uap = pi.uap;
+	s.type = pi.type;
+	s.llid = pi.llid;
+	s.flow = pi.flow;
+	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
+	s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
+	s.out = nullptr;
+	s.written = 0;
+	uint32_t dis;
+	const uint32_t hdr = header_fec13(s.w, dis);
+	const uint32_t uap = do_try_clock(s, clock, hdr, dis);
+	const int rv = do_crc_check<false>(s, clock);
+	btbbx_trial t;
+	t.uap = (uint8_t)uap;
+	t.type = (uint8_t)s.type;
+	t.rv = (int16_t)rv;
+	trials[(uint64_t)pkt * 64 + clock] = t;
+}
+
 // The HEC-only half of the brute force (config 5 of BASELINE.json: "64 whitening seeds x HEC
 // check"): table[p * 64 + c] = try_clock(c)'s return value | packet_type(c) << 8, 0 when the FEC 1/3
 // of the header fails.  uap_from_hec (:693-705) and the type field are GF(2)-linear in the 18
@@ -930,8 +965,13 @@ struct TrialState {
 __global__ __launch_bounds__(64) void trials_state_kernel(const uint64_t *packet, const btbbx_pkt_in *in,
 							   const btbbx_pkt_out *o, TrialState *st, btbbx_trial *trials)
 {
+	// one workgroup per candidate clock: 64 waves on 64 CUs each run ONE trial (no divergence between
+	// packet types inside a wave), so the latency of the call is that of the longest single trial
+	// instead of the sum over all types a 64-lane wave would have to serialise
 	chain_lds_init();
-	const uint32_t lane = threadIdx.x;
+	if (threadIdx.x)
+		return;
+	const uint32_t lane = blockIdx.x;
 	const btbbx_pkt_in pi = in[0];
 	TrialState *me = st + lane;
 	PState s;
@@ -1031,7 +1071,7 @@ int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, cons
 	int rc = ctx_require();
 	if (rc)
 		return rc;
-	hipLaunchKernelGGL(trials_state_kernel, dim3(1), dim3(64), 0, stream, d_packet, d_in, d_out, (TrialState *)d_state, d_trials);
+	hipLaunchKernelGGL(trials_state_kernel, dim3(64), dim3(64), 0, stream, d_packet, d_in, d_out, (TrialState *)d_state, d_trials);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
@@ -1103,8 +1143,12 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 		return rc;
 	if (!n_packets)
 		return BTBBX_OK;
-	hipLaunchKernelGGL(trials_kernel, dim3((n_packets + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
-			   d_packets, d_in, n_packets, d_trials);
+	if (n_packets <= 256)        // latency shape while 64 n waves are only a few rounds over the chip
+		hipLaunchKernelGGL(trials_wide_kernel, dim3(n_packets * 64), dim3(64), 0, (hipStream_t)hip_stream,
+				   d_packets, d_in, n_packets, d_trials);
+	else
+		hipLaunchKernelGGL(trials_kernel, dim3((n_packets + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
+				   d_packets, d_in, n_packets, d_trials);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }

@@ -54,6 +54,9 @@ def test_trial_tables():
     pin["uap"] = rng.integers(0, 256, len(syms))
     pin["flags"][::17] = 0                      # a few unwhitened
     got = bt.run_trials(words, pin)
+    # small batches take the one-workgroup-per-trial kernel: same table
+    for k in (1, 40, 128):
+        assert np.array_equal(bt.run_trials(words[:k], pin[:k]), got[:k]), k
     hist = {}
     for i, s in enumerate(syms):
         want = _oracle_trials(orc, s, int(pin["type"][i]), int(pin["uap"][i]), int(pin["flags"][i]) & 1)

@@ -46,3 +46,16 @@ torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 3
 print("trials: %d packets (all 16 types, random lengths) in %.3f ms = %.1f M packets/s, checksum %d"
       % (n, ms, n / ms / 1e3, int(d_tr.sum().item())))
+
+# small batches: latency shape
+for k in (1, 16, 128, 129, 1024):
+    def small():
+        bt.check(lib.btbbx_trials_device(d_pk.data_ptr(), d_in.data_ptr(), k, d_tr.data_ptr(), hs))
+    small()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(20):
+        small()
+    b.record()
+    torch.cuda.synchronize()
+    print("trials, %4d packets: %.1f us per launch" % (k, a.elapsed_time(b) / 20 * 1e3))
