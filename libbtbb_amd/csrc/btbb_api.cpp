@@ -18,6 +18,8 @@ int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, cons
 int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, const TrialPlan *plan,
 			hipStream_t stream);
 size_t trials_state_bytes();
+int launch_decode_bytes(const uint8_t *d_sym, uint8_t *d_pay, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out,
+			uint32_t mode, bool with_payload, hipStream_t stream);
 int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 		  btbbx_pkt_out *d_out, uint32_t mode, const TrialPlan *plan, hipStream_t stream);
 
@@ -512,17 +514,18 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 		memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
 	}
 	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, nullptr));
-	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
-	if (rc) return rc;
-	uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
-	if (touches_payload) {
+	if (mode & DEC_TRIALS) {                 // single try_clock / crc_check calls (rare): separate steps
+		rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+		if (rc) return rc;
+		uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
 		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, nullptr);
 		if (rc) return rc;
-	}
-	rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, nullptr);
-	if (rc) return rc;
-	if (touches_payload) {
+		rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, nullptr);
+		if (rc) return rc;
 		rc = btbbx_unpack_device(d_out_payload, 2752, b.d_pay, nullptr);
+		if (rc) return rc;
+	} else {                                 // pack + decode + unpack in one launch
+		rc = launch_decode_bytes(b.d_sym, b.d_pay, b.d_in, b.d_out, mode, touches_payload, nullptr);
 		if (rc) return rc;
 	}
 	// pkt_out and (when touched) the payload bits are adjacent: one copy back

@@ -762,18 +762,11 @@ __global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets,
 // (DEC_TRIALS -- leave the packet as a set of try_clock / crc_check calls leaves it -- is
 //  replay_kernel / trials_state_kernel + trials_merge_kernel below)
 
-__global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
-						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode,
-						     TrialPlan plan)
+// header_present + decode_header / decode_payload of one packet (w = its 50 packed words)
+__device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
 {
-	chain_lds_init();
-	uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pkt >= n_packets)
-		return;
-	const btbbx_pkt_in pi = in[pkt];
-	btbbx_pkt_out *o = outs + pkt;
 	PState s;
-	s.w = packets + (uint64_t)pkt * BTBBX_PKT_WORDS;
+	s.w = w;
 	s.length = (int)pi.length;
 	s.flags = pi.flags;
 	s.uap = pi.uap;
@@ -849,6 +842,57 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 	o->flow = (uint8_t)s.flow;
 	o->uap = (uint8_t)s.uap;
 	o->payload_header = s.ph16;
+}
+
+__global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode)
+{
+	chain_lds_init();
+	uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pkt >= n_packets)
+		return;
+	decode_one(packets + (uint64_t)pkt * BTBBX_PKT_WORDS, in[pkt], outs + pkt, mode);
+}
+
+// 64 symbols, one per byte (bit 0 counts), -> one packed word
+__device__ __forceinline__ uint64_t pack64(const uint8_t *sym)
+{
+	uint64_t v = 0;
+	const uint4 *p = reinterpret_cast<const uint4 *>(sym);
+	for (int q = 0; q < 4; q++) {
+		const uint4 x = p[q];
+		const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+		for (int k = 0; k < 4; k++) {
+			const uint32_t b = d[k] & 0x01010101u;
+			v |= (uint64_t)((b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xfu) << (16 * q + 4 * k);
+		}
+	}
+	return v;
+}
+
+// The drop-in's single-packet decode in ONE launch: the symbol bytes and the current payload bit
+// bytes are packed by the workgroup, lane 0 decodes, and the payload bits are unpacked again --
+// instead of pack + pack + decode + unpack launches around a one-lane kernel.
+__global__ __launch_bounds__(64) void decode_bytes_kernel(const uint8_t *sym, uint8_t *pay, const btbbx_pkt_in *in,
+							   btbbx_pkt_out *o, uint32_t mode, int with_payload)
+{
+	__shared__ uint64_t pkt[BTBBX_PKT_WORDS + 2];
+	const uint32_t lane = threadIdx.x;
+	if (lane < BTBBX_PKT_WORDS + 2)
+		pkt[lane] = lane < BTBBX_PKT_WORDS ? pack64(sym + 64 * lane) : 0;      // 3200 staged bytes
+	if (with_payload && lane < 43)
+		o->payload[lane] = pack64(pay + 64 * lane);                            // 2752 staged bytes
+	chain_lds_init();
+	if (lane == 0)
+		decode_one(pkt, in[0], o, mode);
+	__syncthreads();
+	if (with_payload && lane < 43) {
+		const uint64_t v = o->payload[lane];
+		for (int k = 0; k < 64; k += 4) {
+			const uint32_t n = (uint32_t)(v >> k) & 0xf;
+			*reinterpret_cast<uint32_t *>(pay + 64 * lane + k) = (n * 0x00204081u) & 0x01010101u;
+		}
+	}
 }
 
 // DEC_TRIALS for one packet, 64 trials at once: lane = candidate count, every lane starts from the
@@ -1171,6 +1215,18 @@ extern "C" int btbbx_uap_table_device(const uint64_t *d_packets, const btbbx_pkt
 	return BTBBX_OK;
 }
 
+int launch_decode_bytes(const uint8_t *d_sym, uint8_t *d_pay, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out,
+			uint32_t mode, bool with_payload, hipStream_t stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(decode_bytes_kernel, dim3(1), dim3(64), 0, stream, d_sym, d_pay, d_in, d_out, mode,
+			   with_payload ? 1 : 0);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
 int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 		  btbbx_pkt_out *d_out, uint32_t mode, const TrialPlan *plan, hipStream_t stream)
 {
@@ -1192,7 +1248,7 @@ int launch_decode(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t 
 		return BTBBX_OK;
 	}
 	hipLaunchKernelGGL(decode_kernel, dim3((n_packets + 63) / 64), dim3(64), 0, stream,
-			   d_packets, d_in, n_packets, d_out, mode, p);
+			   d_packets, d_in, n_packets, d_out, mode);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
