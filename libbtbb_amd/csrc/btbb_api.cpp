@@ -13,10 +13,10 @@
 #include "packet_obj.h"
 #include "../../include/btbb.h"
 
-int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
+int launch_trials_state(const uint8_t *d_sym, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
 			btbbx_trial *d_trials, hipStream_t stream);
-int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, const TrialPlan *plan,
-			hipStream_t stream);
+int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, uint8_t *d_pay,
+			const TrialPlan *plan, hipStream_t stream);
 size_t trials_state_bytes();
 int launch_decode_bytes(const uint8_t *d_sym, uint8_t *d_pay, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out,
 			uint32_t mode, bool with_payload, hipStream_t stream);
@@ -459,11 +459,7 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 	memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
 	memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
 	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_PKT, hipMemcpyHostToDevice, nullptr));
-	rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
-	if (rc) return rc;
-	rc = btbbx_pack_device(b.d_pay, 2752, (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), nullptr);
-	if (rc) return rc;
-	rc = launch_trials_state(b.d_pkt, b.d_in, b.d_out, b.dev + PB_STATE, b.d_trials, nullptr);
+	rc = launch_trials_state(b.d_sym, b.d_in, b.d_out, b.dev + PB_STATE, b.d_trials, nullptr);
 	if (rc) return rc;
 	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, nullptr));
 	HIP_TRY(hipStreamSynchronize(nullptr));
@@ -479,9 +475,7 @@ int packet_gpu_trials_commit(btbb_packet *pkt, const TrialPlan *plan)
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
-	rc = launch_trials_merge(b.dev + PB_STATE, b.d_in, b.d_out, plan, nullptr);
-	if (rc) return rc;
-	rc = btbbx_unpack_device((const uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload)), 2752, b.d_pay, nullptr);
+	rc = launch_trials_merge(b.dev + PB_STATE, b.d_in, b.d_out, b.d_pay, plan, nullptr);
 	if (rc) return rc;
 	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, PB_PKT - PB_OUT, hipMemcpyDeviceToHost, nullptr));
 	HIP_TRY(hipStreamSynchronize(nullptr));

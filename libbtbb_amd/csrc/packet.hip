@@ -1006,9 +1006,13 @@ struct TrialState {
 	uint64_t payload[44];
 };
 
-__global__ __launch_bounds__(64) void trials_state_kernel(const uint64_t *packet, const btbbx_pkt_in *in,
+__global__ __launch_bounds__(64) void trials_state_kernel(const uint8_t *sym, const btbbx_pkt_in *in,
 							   const btbbx_pkt_out *o, TrialState *st, btbbx_trial *trials)
 {
+	// every workgroup packs the 3200 staged symbol bytes for itself (LDS): no separate pack launch
+	__shared__ uint64_t packet[BTBBX_PKT_WORDS + 2];
+	if (threadIdx.x < BTBBX_PKT_WORDS + 2)
+		packet[threadIdx.x] = threadIdx.x < BTBBX_PKT_WORDS ? pack64(sym + 64 * threadIdx.x) : 0;
 	// one workgroup per candidate clock: 64 waves on 64 CUs each run ONE trial (no divergence between
 	// packet types inside a wave), so the latency of the call is that of the longest single trial
 	// instead of the sum over all types a 64-lane wave would have to serialise
@@ -1061,7 +1065,7 @@ __global__ __launch_bounds__(64) void trials_state_kernel(const uint64_t *packet
 
 // lane = candidate count; the trial it stands for ran with clock (count + clock_offset) & 63
 __global__ __launch_bounds__(64) void trials_merge_kernel(const TrialState *st, const btbbx_pkt_in *in, btbbx_pkt_out *o,
-							   TrialPlan plan)
+							   uint8_t *pay, TrialPlan plan)
 {
 	__shared__ uint32_t wrote[64];
 	__shared__ uint32_t src_of[64];
@@ -1081,7 +1085,8 @@ __global__ __launch_bounds__(64) void trials_merge_kernel(const TrialState *st, 
 	for (int d = 32; d; d >>= 1)
 		f_flags |= (uint32_t)__shfl_xor((int)f_flags, d);
 	if (lane < 43) {
-		uint64_t word = o->payload[lane], undecided = ~0ULL;
+		// entry payload bits come in, and the merged ones go out, one per byte (`pay`, 2752 bytes)
+		uint64_t word = pack64(pay + 64 * lane), undecided = ~0ULL;
 		for (int k = 63; k >= 0 && undecided; k--) {
 			const uint32_t w = wrote[k];
 			if (w <= 64u * lane)
@@ -1092,6 +1097,8 @@ __global__ __launch_bounds__(64) void trials_merge_kernel(const TrialState *st, 
 			undecided &= ~covers;
 		}
 		o->payload[lane] = word;
+		for (int k = 0; k < 64; k += 4)
+			*reinterpret_cast<uint32_t *>(pay + 64 * lane + k) = (((uint32_t)(word >> k) & 0xf) * 0x00204081u) & 0x01010101u;
 	}
 	if (lane == 0) {
 		auto at = [&](int l) { return st + ((l + plan.clock_offset) & 63); };
@@ -1109,21 +1116,22 @@ __global__ __launch_bounds__(64) void trials_merge_kernel(const TrialState *st, 
 	}
 }
 
-int launch_trials_state(const uint64_t *d_packet, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
+int launch_trials_state(const uint8_t *d_sym, const btbbx_pkt_in *d_in, const btbbx_pkt_out *d_out, void *d_state,
 			btbbx_trial *d_trials, hipStream_t stream)
 {
 	int rc = ctx_require();
 	if (rc)
 		return rc;
-	hipLaunchKernelGGL(trials_state_kernel, dim3(64), dim3(64), 0, stream, d_packet, d_in, d_out, (TrialState *)d_state, d_trials);
+	hipLaunchKernelGGL(trials_state_kernel, dim3(64), dim3(64), 0, stream, d_sym, d_in, d_out, (TrialState *)d_state, d_trials);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
 
-int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, const TrialPlan *plan,
-			hipStream_t stream)
+int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt_out *d_out, uint8_t *d_pay,
+			const TrialPlan *plan, hipStream_t stream)
 {
-	hipLaunchKernelGGL(trials_merge_kernel, dim3(1), dim3(64), 0, stream, (const TrialState *)d_state, d_in, d_out, *plan);
+	hipLaunchKernelGGL(trials_merge_kernel, dim3(1), dim3(64), 0, stream, (const TrialState *)d_state, d_in, d_out, d_pay,
+			   *plan);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
