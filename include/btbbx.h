@@ -106,7 +106,7 @@ int btbbx_sync(void *hip_stream);
 /* ---- access-code scan -------------------------------------------------------- */
 /* All pointers are DEVICE pointers.  n_streams packed streams of n_words words each
  * lie pitch_words apart; offsets [0, search_bits) of every stream are tested, which
- * needs search_bits + 63 <= 64 * n_words.  Hits are appended (unordered) to d_hits,
+ * needs search_bits + 63 <= 64 * n_words.  Hits are appended (unordered) to d_hits (16-byte aligned),
  * *d_hit_count counts ALL hits even beyond hit_cap.  The caller zeroes *d_hit_count.
  * Asynchronous on hip_stream (NULL = the null stream). */
 int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,

@@ -851,6 +851,10 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		return rc;
 	if (search_bits == 0)
 		return BTBBX_OK;
+	if ((uintptr_t)d_hits & 15) {
+		set_error("btbbx_scan: the hit buffer must be 16-byte aligned (records are written as one 16-byte store)");
+		return BTBBX_E_ARG;
+	}
 	Ctx &c = ctx();
 	ScanArgs a;
 	a.words = d_words;
