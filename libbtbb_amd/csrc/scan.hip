@@ -86,15 +86,8 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, 
 // and table addresses are plain byte offsets: every DS access below is `base + offset:imm`
 // with the table base folded into the 16-bit immediate.
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
-typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u128_t;
 __device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
 __device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
-__device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
-__device__ __forceinline__ void lds_st16(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u16_t *>(byte_off) = (uint16_t)v; }
-__device__ __forceinline__ void lds_st64(uint32_t byte_off, uint64_t v) { *reinterpret_cast<lds_u64_t *>(byte_off) = v; }
 
 // w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
 // batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
