@@ -16,6 +16,9 @@ int main(int argc, char **argv)
 	btbb_packet *pkt = NULL;
 	btbb_piconet *pn;
 	unsigned long lap;
+	btbb_pcap_handle *pcap = NULL;
+	btbb_pcapng_handle *pcapng = NULL;
+	char path[512];
 
 	if (argc < 3)
 		return 2;
@@ -35,6 +38,14 @@ int main(int argc, char **argv)
 		return 3;
 	pn = btbb_piconet_new();
 	btbb_init_piconet(pn, (uint32_t)lap);
+	if (argc > 3) {              /* capture files: <prefix>.pcap and <prefix>.pcapng */
+		sprintf(path, "%.500s.pcap", argv[3]);
+		if (btbb_pcap_create_file(path, &pcap) != 0)
+			return 4;
+		sprintf(path, "%.500s.pcapng", argv[3]);
+		if (btbb_pcapng_create_file(path, "dropin_caller", &pcapng) != 0)
+			return 4;
+	}
 	while (off < n - 64) {
 		r = btbb_find_ac(syms + off, (int)(n - 63 - off), LAP_ANY, 2, &pkt);
 		if (r < 0)
@@ -45,11 +56,20 @@ int main(int argc, char **argv)
 		       (unsigned)btbb_packet_get_ac_errors(pkt), btbb_header_present(pkt));
 		if (btbb_packet_get_lap(pkt) == lap)
 			btbb_process_packet(pkt, pn);
+		if (pcap) {
+			btbb_pcap_append_packet(pcap, (uint64_t)off * 1000u, -40, -90, (uint32_t)lap, UAP_ANY, pkt);
+			btbb_pcapng_append_packet(pcapng, (uint64_t)off * 1000u, -40, -90, (uint32_t)lap, UAP_ANY, pkt);
+		}
 		found++;
 		off += 1;
 	}
 	printf("DONE found=%d uap_valid=%d uap=%02x\n", found, btbb_piconet_get_flag(pn, BTBB_UAP_VALID),
 	       (unsigned)btbb_piconet_get_uap(pn));
+	if (pcap) {
+		btbb_pcapng_record_bdaddr(pcapng, btbb_piconet_get_bdaddr(pn), 0xff, 0);
+		btbb_pcap_close(pcap);
+		btbb_pcapng_close(pcapng);
+	}
 	if (pkt)
 		btbb_packet_unref(pkt);
 	btbb_piconet_unref(pn);

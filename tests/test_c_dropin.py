@@ -57,7 +57,8 @@ def test_c90_caller_runs_like_the_oracle(tmp_path):
     os.symlink(sys.modules["libbtbb_amd"].LIB_PATH, str(libdir / "libbtbb.so.1"))
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = str(libdir) + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    res = subprocess.run([exe, path, hex(lap)], capture_output=True, text=True, env=env, timeout=300)
+    prefix = str(tmp_path / "cap")
+    res = subprocess.run([exe, path, hex(lap), prefix], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0, res.stderr
     lines = [l for l in res.stdout.splitlines() if l.startswith("AC ")]
     orc = _libs.oracle()
@@ -68,3 +69,16 @@ def test_c90_caller_runs_like_the_oracle(tmp_path):
     assert [g[0] for g in got if g[1] == lap] == placed
     done = [l for l in res.stdout.splitlines() if l.startswith("DONE")][0]
     assert "found=%d" % len(want) in done and "uap_valid=1" in done and "uap=%02x" % uap in done
+    # the capture files it wrote: one record per access code, LINKTYPE_BLUETOOTH_BREDR_BB pseudo header
+    import struct
+    import _capture
+    recs = _capture.pcap_records(open(prefix + ".pcap", "rb").read())
+    assert len(recs) == len(want)
+    for (sec, nsec, rec), (o, l, e) in zip(recs, want):
+        ch, sig, noise, errs = struct.unpack_from("<BbbB", rec, 0)
+        rec_lap, ref = struct.unpack_from("<II", rec, 8)
+        assert (ch, sig, noise, errs, rec_lap) == (17, -40, -90, e, l) and ref == (lap | 0xFF << 24)
+        assert sec * 10**9 + nsec == o * 1000
+    blocks = _capture.pcapng_blocks(_capture.normalize_pcapng(open(prefix + ".pcapng", "rb").read()))
+    assert [b[0] for b in blocks] == [0x0A0D0D0A, 1] + [6] * len(want)
+    assert b"dropin_caller" in blocks[1][1] and struct.pack("<HH", 0xD340, 12) in blocks[1][1]
