@@ -74,3 +74,28 @@ def test_fails_loudly_without_gpu(lib):
     import libbtbb_amd
     with pytest.raises(libbtbb_amd.BtbbError):
         libbtbb_amd.scan_words(np.zeros(64, np.uint64), 1000)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may use oracle/: no product source names it,
+    and the shared object neither links it nor has a CPU implementation of the scan to fall back on."""
+    import libbtbb_amd
+    pkg = os.path.dirname(libbtbb_amd.LIB_PATH)
+    for base, _, files in os.walk(pkg):
+        if os.path.basename(base) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle/" not in text and "orc_" not in text, os.path.join(base, f)
+    needed = subprocess.run(["readelf", "-d", libbtbb_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed and "btbb_ref" not in needed
+    # hop selection and capture files, too, refuse to run without a device instead of computing on the host
+    import torch
+    if not torch.cuda.is_available():
+        import ctypes as C
+        lib_ = libbtbb_amd.lib()
+        cfg = libbtbb_amd.hop_cfg(0x123456, 0x78)
+        n = C.c_int(0)
+        assert not lib_.btbbx_hop_reversal_open(C.byref(cfg), 0, 0, 0, C.byref(n))
+        assert lib_.btbbx_hop_sequence_device(C.byref(cfg), 0, 64, None, None) < 0
