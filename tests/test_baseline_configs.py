@@ -6,8 +6,9 @@ config 0 (CPU plumbing): known-LAP btbb_find_ac over a 1 MiB packed synthetic bi
 config 2: known-LAP full chain (find -> header -> payload -> HEC/CRC) over 79 hop-channel
           streams -- HIP vs oracle, every packet.
 config 4: 64 whitening seeds x HEC/CRC check over the detected-packet stream.
-(config 1 is bench.py / test_gpu_scan.py::test_large_stream_properties; config 3 is the
-time-sharded multi-GPU run of bench.py --gpus 8, its sharding logic is test_sharding_gloo.py.)
+config 1 (4 GiB LAP_ANY) and config 3 as one GPU sees it (79 channels, 8 GiB per GPU) at their
+          full sizes through size-independent properties (bench.py measures config 1; the
+          sharding logic of the 8-GPU run is test_sharding_gloo.py).
 """
 import numpy as np
 import pytest
@@ -166,3 +167,78 @@ def test_config2_full_chain_79_channels_and_config4_trials():
         if c is not None and trials[i, c]["rv"] >= 10:
             assert int(trials[i, c]["uap"]) == uap
         orc.orc_packet_free(p)
+
+
+def _scan_properties(nwords_total, n_streams, seed, sample_slices):
+    """Generate nwords_total words in HBM, scan them as n_streams equal streams (LAP_ANY, <= 2
+    errors) and check size-independent properties: every injected sync word with <= 2 bit errors
+    that lies inside one stream's search range is reported once with its LAP and error count,
+    no offset twice, chance matches within theory, sampled slices equal to the oracle."""
+    import torch
+    import libbtbb_amd as bt
+    lib = bt.lib()
+    stride = 4096
+    pitch = nwords_total // n_streams
+    search_bits = pitch * 64 - 63
+    t = torch.empty(nwords_total + 8, dtype=torch.int64, device="cuda")
+    bt.check(lib.btbbx_synth_device(t.data_ptr(), 0, nwords_total, seed, stride, -1, 4, None))
+    cap = nwords_total * 64 // stride + (1 << 16)
+    hits_t = torch.zeros(cap * 2, dtype=torch.int64, device="cuda")
+    cnt_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bt.check(lib.btbbx_scan_device(t.data_ptr(), pitch, pitch, n_streams, search_bits, bt.LAP_ANY, 2,
+                                   hits_t.data_ptr(), cap, cnt_t.data_ptr(), None))
+    torch.cuda.synchronize()
+    cnt = int(cnt_t.item())
+    assert cnt <= cap
+    bt.check(lib.btbbx_sort_hits_device(hits_t.data_ptr(), cnt, None))
+    hits = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:cnt]
+    glob = hits["stream"].astype(np.uint64) * np.uint64(pitch * 64) + hits["offset"]       # offset in the whole buffer
+    assert (np.diff(glob.astype(np.int64)) > 0).all()                                       # sorted, no duplicates
+    assert (hits["offset"] < search_bits).all() and (hits["stream"] < n_streams).all()
+    k = np.arange(nwords_total * 64 // stride, dtype=np.uint64)
+    pos, laps, nerr, mask = synth.injection_params(seed, k, stride, 4)
+    popc = np.unpackbits(mask.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)
+    inside = (pos % np.uint64(pitch * 64)) < np.uint64(search_bits)                         # window fits its stream
+    ok = (popc <= 2) & inside & (pos + np.uint64(64) <= np.uint64(nwords_total * 64))
+    idx = np.searchsorted(glob, pos[ok])
+    assert (idx < cnt).all() and (glob[idx] == pos[ok]).all()
+    assert (hits["lap"][idx] == laps[ok]).all()
+    assert (hits["ac_errors"][idx] == popc[ok]).all()
+    extra = cnt - int(ok.sum())
+    expected_chance = 1.25e-8 * nwords_total * 64
+    assert 0 <= extra < 3 * expected_chance + 100, (extra, expected_chance)
+    orc = _libs.oracle()
+    orc.orc_reset_syndrome_map()
+    orc.orc_init(2)
+    for s, first in sample_slices:
+        nw = 16384
+        base = s * pitch + first
+        sl = t[base:base + nw].cpu().numpy().view(np.uint64)
+        sym = np.ascontiguousarray(synth.unpack_bits(sl))
+        want = _libs.orc_find_all(sym, nw * 64 - 63, _libs.LAP_ANY, 2)
+        lo, hi = first * 64, first * 64 + nw * 64 - 63
+        sel = hits[(hits["stream"] == s) & (hits["offset"] >= lo) & (hits["offset"] < hi)]
+        got = [(int(h["offset"]) - lo, int(h["lap"]), int(h["ac_errors"])) for h in sel]
+        assert got == want, (s, first)
+    return cnt
+
+
+@pytest.mark.gpu
+def test_config1_full_size_4gib_properties():
+    """BASELINE config 1 at its full size: 4 GiB packed single-channel stream, LAP_ANY, <= 2 errors."""
+    import libbtbb_amd as bt
+    bt.init(2)
+    nwords = 1 << 29
+    cnt = _scan_properties(nwords, 1, 20260926, [(0, 777), (0, nwords - 20000), (0, 123456789 % (nwords - 20000))])
+    assert cnt > 6_000_000
+
+
+@pytest.mark.gpu
+def test_config3_per_gpu_shard_79_channels_8gib_properties():
+    """BASELINE config 3 as one GPU sees it: 79 channel streams, 8 GiB of packed bitstream in HBM
+    (64 GiB over 8 GPUs), one launch."""
+    import libbtbb_amd as bt
+    bt.init(2)
+    pitch = (8 << 30) // 8 // 79                # words per channel
+    cnt = _scan_properties(pitch * 79, 79, 99, [(0, 5), (40, pitch // 2), (78, pitch - 16400)])
+    assert cnt > 12_000_000
