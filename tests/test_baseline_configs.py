@@ -242,3 +242,68 @@ def test_config3_per_gpu_shard_79_channels_8gib_properties():
     pitch = (8 << 30) // 8 // 79                # words per channel
     cnt = _scan_properties(pitch * 79, 79, 99, [(0, 5), (40, pitch // 2), (78, pitch - 16400)])
     assert cnt > 12_000_000
+
+
+@pytest.mark.gpu
+def test_config4_full_size_million_packets():
+    """BASELINE config 4 at its size (N ~ 10^6 detected packets): the 64-clock trial table and the
+    HEC-only UAP table for 2048 distinct packets tiled 512 times -- every copy equals the first, the
+    first equals the oracle on a sample, the two tables agree on try_clock, and for CRC-bearing
+    packets the true clock yields the true UAP with the CRC satisfied."""
+    import ctypes as C
+    import torch
+    import libbtbb_amd as bt
+    import _pkt
+    bt.init(2)
+    lib = bt.lib()
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    rng = np.random.default_rng(404)
+    base, metas = [], []
+    for i in range(2048):
+        lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+        t = [synth.TYPE_DM1, synth.TYPE_DH1, 10, 11, 14, 15, synth.TYPE_NULL, 2][i % 8]
+        body = rng.integers(0, 256, int(rng.integers(1, 17)), dtype=np.uint8).tobytes()
+        sym = synth.build_packet(lap, uap, clk6, t, lt_addr=1, body=body, fhs_bits=synth.fhs_payload(lap, uap, 1, 2, rng))
+        base.append(np.ascontiguousarray(np.concatenate([sym, rng.integers(0, 2, 30, dtype=np.uint8)])[:bt.MAX_SYMBOLS]))
+        metas.append((uap, clk6, t))
+    words, lengths = bt.packets_to_words(base)
+    reps = 512
+    n = len(base) * reps
+    assert n >= 1_000_000
+    pin = np.zeros(len(base), bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    pin["flags"] = 1
+    d_pk = torch.from_numpy(np.tile(words.view(np.int64), (reps, 1))).cuda()
+    d_in = torch.from_numpy(np.tile(pin, reps).view(np.uint8)).cuda()
+    d_tr = torch.zeros(n * 64, dtype=torch.int32, device="cuda")
+    d_tab = torch.zeros(n * 32, dtype=torch.int32, device="cuda")
+    hs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bt.check(lib.btbbx_trials_device(d_pk.data_ptr(), d_in.data_ptr(), n, d_tr.data_ptr(), hs))
+    bt.check(lib.btbbx_uap_table_device(d_pk.data_ptr(), d_in.data_ptr(), n, d_tab.data_ptr(), hs))
+    torch.cuda.synchronize()
+    tr = d_tr.view(reps, len(base) * 64)
+    tab = d_tab.view(reps, len(base) * 32)
+    assert bool((tr == tr[0]).all()) and bool((tab == tab[0]).all())          # every tiled copy identical
+    trials = tr[0].cpu().numpy().view(bt.TRIAL_DTYPE).reshape(len(base), 64)
+    table = tab[0].cpu().numpy().view(np.uint16).reshape(len(base), 64)
+    # try_clock agrees between the two kernels (return value; the type wherever FEC 1/3 held)
+    assert np.array_equal(table & 0xFF, trials["uap"])
+    solved = 0
+    for i, (uap, clk6, t) in enumerate(metas):
+        if t in (synth.TYPE_DM1, synth.TYPE_DH1, 10, 11, 14, 15, 2):
+            assert int(trials[i, clk6]["uap"]) == uap and int(trials[i, clk6]["rv"]) in (10, 1000), (i, t)
+            solved += 1
+    assert solved == 2048 * 7 // 8
+    for i in range(0, len(base), 64):                                          # oracle on a sample
+        p = orc.orc_packet_new()
+        orc.orc_packet_init_found(p, 0, 0)
+        orc.orc_packet_set_data(p, _libs.ptr(base[i]), len(base[i]), 0, 0)
+        for clock in range(64):
+            p.contents.packet_type = 0
+            p.contents.UAP = 0
+            u = orc.orc_try_clock(clock, p)
+            rv = orc.orc_crc_check(clock, p)
+            tt = trials[i, clock]
+            assert (int(tt["uap"]), int(tt["type"]), int(tt["rv"])) == (u, p.contents.packet_type, rv), (i, clock)
+        orc.orc_packet_free(p)
