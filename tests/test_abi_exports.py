@@ -99,3 +99,14 @@ def test_product_never_touches_the_oracle():
         n = C.c_int(0)
         assert not lib_.btbbx_hop_reversal_open(C.byref(cfg), 0, 0, 0, C.byref(n))
         assert lib_.btbbx_hop_sequence_device(C.byref(cfg), 0, 64, None, None) < 0
+
+
+def test_headers_are_valid_c90_and_cxx(tmp_path):
+    """Both public headers compile stand-alone as pedantic C90 and as C++ (plain C ABI, no torch types)."""
+    src = tmp_path / "h.c"
+    src.write_text("#include <btbb.h>\n#include <btbbx.h>\nint main(void) { return 0; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c90", "-pedantic", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")], check=True)
+    text = open(os.path.join(inc, "btbbx.h")).read() + open(os.path.join(inc, "btbb.h")).read()
+    assert "torch" not in text and "hip/" not in text
