@@ -785,6 +785,13 @@ int btbbx_hop_reversal_winnow(btbbx_hop_reversal *r, const int32_t *index_offset
 		v = *w->h_verdict;
 		r->cur ^= 1;
 		r->n = v.count;
+	} else if (n_obs) {
+		// An empty list (channel never produced by this pattern, e.g. >= 79 or outside the AFH bank):
+		// the reference's channel_winnow still runs for the first unused observation, finds no
+		// candidate and resets the piconet (bluetooth_piconet.c:596-601, 614-620) -- so the walk
+		// stops at observation 0 with nothing left.
+		v.stop = 0;
+		v.count = 0;
 	} else if (r->n) {
 		HIP_TRY(hipMemcpyAsync(w->h_total, w->d_cand[r->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));

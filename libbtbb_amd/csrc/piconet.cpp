@@ -128,120 +128,149 @@ void btbb_print_afh_map(btbb_piconet *pn)
 
 } // extern "C"
 
-/* bluetooth_piconet.c:547-572 */
+// Back to "nothing known but the LAP" (bluetooth_piconet.c:547-572): everything the discovery
+// stages established is dropped, the AFH guess of the last attempt becomes the next attempt's mode.
 static void piconet_reset(btbb_piconet *pn)
 {
-	if (btbb_piconet_get_flag(pn, BTBB_HOP_REVERSAL_INIT)) {
+	const uint32_t discovered = (1u << BTBB_GOT_FIRST_PACKET) | (1u << BTBB_HOP_REVERSAL_INIT) | (1u << BTBB_UAP_VALID) |
+				    (1u << BTBB_CLK6_VALID) | (1u << BTBB_CLK27_VALID);
+	if (pn->flags & (1u << BTBB_HOP_REVERSAL_INIT)) {
 		btbbx_hop_reversal_close(pn->reversal);
 		pn->reversal = NULL;
 		pn->pattern = NULL;
 	}
-	btbb_piconet_set_flag(pn, BTBB_GOT_FIRST_PACKET, 0);
-	btbb_piconet_set_flag(pn, BTBB_HOP_REVERSAL_INIT, 0);
-	btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 0);
-	btbb_piconet_set_flag(pn, BTBB_CLK6_VALID, 0);
-	btbb_piconet_set_flag(pn, BTBB_CLK27_VALID, 0);
+	pn->flags &= ~(discovered | (1u << BTBB_IS_AFH));
+	if (pn->flags & (1u << BTBB_LOOKS_LIKE_AFH))
+		pn->flags |= 1u << BTBB_IS_AFH;
 	pn->packets_observed = 0;
-	btbb_piconet_set_flag(pn, BTBB_IS_AFH, btbb_piconet_get_flag(pn, BTBB_LOOKS_LIKE_AFH));
+}
+
+// ---- UAP / CLK1-6 discovery (bluetooth_piconet.c:648-750) -------------------------------------
+//
+// The reference walks the 64 candidate values of "CLK1-6 of the first packet" one after the other,
+// running try_clock / crc_check for each.  Here the GPU has already produced all 64 results
+// (trial[clock] = {UAP, type, crc_check verdict}), and nothing a candidate does depends on an
+// earlier candidate except the early exit at the first confirmed CRC.  So the elimination is
+// written as set arithmetic over 64-bit candidate sets, one bit per candidate:
+//
+//   live    candidates still standing (all of them for the first packet of a piconet)
+//   checked live candidates whose CRC the reference would have computed (UAP agrees with the one
+//           remembered for that candidate; all of them for the first packet)
+//   proven  checked candidates, consistent with a known piconet UAP, whose CRC verdict is a pass
+//   kept    the same with an inconclusive verdict (1 or 2)
+//
+// The lowest member of `proven` ends the walk: candidates above it are left untouched.
+
+struct CandidateSets {
+	uint64_t live, checked, proven, kept;
+	uint8_t uap[64];                              // UAP each candidate implies for this packet
+};
+
+static inline uint64_t below(int bit) { return bit >= 64 ? ~0ULL : (1ULL << bit) - 1; }
+
+static CandidateSets classify_candidates(const btbb_piconet *pn, const btbbx_trial *trial, uint32_t rot)
+{
+	const bool opening = !btbb_piconet_get_flag(pn, BTBB_GOT_FIRST_PACKET);
+	const bool uap_known = btbb_piconet_get_flag(pn, BTBB_UAP_VALID) != 0;
+	CandidateSets s = {};
+	for (int c = 0; c < 64; c++) {
+		const btbbx_trial &t = trial[(c + rot) & 63];
+		const uint64_t me = 1ULL << c;
+		s.uap[c] = t.uap;
+		if (!opening && pn->clock6_candidates[c] < 0)
+			continue;
+		s.live |= me;
+		if (!opening && t.uap != pn->clock6_candidates[c])
+			continue;
+		s.checked |= me;
+		if (uap_known && t.uap != pn->UAP)
+			continue;                             // CRC was computed, verdict overruled
+		if (t.rv == 1 || t.rv == 2)
+			s.kept |= me;
+		else if (t.rv != 0)
+			s.proven |= me;
+	}
+	return s;
+}
+
+// record one observed hop; false = pattern memory exhausted
+static bool remember_hop(btbb_piconet *pn, const btbb_packet *pkt)
+{
+	if (!btbb_piconet_get_flag(pn, BTBB_GOT_FIRST_PACKET))
+		pn->first_pkt_time = pkt->clkn;
+	btbb_piconet_set_channel_seen(pn, pkt->channel);
+	const int slot = pn->packets_observed;
+	if (slot >= PN_MAX_PATTERN)
+		return false;
+	pn->pattern_indices[slot] = (int)(pkt->clkn - pn->first_pkt_time);
+	pn->pattern_channels[slot] = pkt->channel;
+	pn->packets_observed = slot + 1;
+	pn->total_packets_observed++;
+	return true;
+}
+
+// candidate `count` is the CLK1-6 of the first packet: the piconet's UAP and clock offset follow
+static void settle_clock6(btbb_piconet *pn, int count, uint8_t uap, const char *prefix)
+{
+	pn->clk_offset = (count - (int)(pn->first_pkt_time & 0x3f)) & 0x3f;
+	if (btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
+		printf("%sCLK6 = 0x%x found after %d total packets.\n", prefix, pn->clk_offset, pn->total_packets_observed);
+	else
+		printf("%sUAP = 0x%x found after %d total packets.\n", prefix, uap, pn->total_packets_observed);
+	pn->UAP = uap;
+	pn->flags |= (1u << BTBB_CLK6_VALID) | (1u << BTBB_UAP_VALID);
+	pn->total_packets_observed = 0;
 }
 
 extern "C" {
 
-/* bluetooth_piconet.c:648-750 */
 int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn)
 {
-	const uint32_t clkn = pkt->clkn;
-	int remaining = 0, first_clock = 0, result = -1;
-
-	if (!btbb_piconet_get_flag(pn, BTBB_GOT_FIRST_PACKET))
-		pn->first_pkt_time = clkn;
-	btbb_piconet_set_channel_seen(pn, pkt->channel);
-	if (pn->packets_observed < PN_MAX_PATTERN) {
-		pn->pattern_indices[pn->packets_observed] = (int)(clkn - pn->first_pkt_time);
-		pn->pattern_channels[pn->packets_observed] = pkt->channel;
-	} else {
+	if (!remember_hop(pn, pkt)) {
 		printf("Oops. More hops than we can remember.\n");
 		piconet_reset(pn);
 		return 0;
 	}
-	pn->packets_observed++;
-	pn->total_packets_observed++;
 
-	// all 64 CLK1-6 candidates in one launch: trial[c] = {try_clock(c), type, crc_check(c)}
-	btbbx_trial trial[64];
+	btbbx_trial trial[64];                        // one launch: trial[clock] for every CLK1-6 value
 	if (packet_gpu_trials(pkt, trial)) {
 		fprintf(stderr, "btbb_uap_from_header: GPU path failed: %s\n", btbbx_last_error());
 		return 0;
 	}
+	const uint32_t rot = (pkt->clkn - pn->first_pkt_time) & 63;
+	const CandidateSets s = classify_candidates(pn, trial, rot);
 
-	TrialPlan plan = {0, 0, (uint32_t)((clkn - pn->first_pkt_time) & 63)};
-	const int first = !btbb_piconet_get_flag(pn, BTBB_GOT_FIRST_PACKET);
-	for (int count = 0; count < 64 && result < 0; count++) {
-		if (pn->clock6_candidates[count] > -1 || first) {
-			const uint32_t clock = ((uint32_t)count + clkn - pn->first_pkt_time) % 64;
-			const btbbx_trial &t = trial[clock];
-			const uint8_t UAP = t.uap;
-			int crc_chk = -1;
-			plan.try_mask |= 1ULL << count;
-			if (first || UAP == pn->clock6_candidates[count]) {
-				crc_chk = t.rv;
-				plan.crc_mask |= 1ULL << count;
-			}
-			if (btbb_piconet_get_flag(pn, BTBB_UAP_VALID) && UAP != pn->UAP)
-				crc_chk = -1;
-			switch (crc_chk) {
-			case -1:
-			case 0:
-				pn->clock6_candidates[count] = -1;
-				break;
-			case 1:
-			case 2:
-				pn->clock6_candidates[count] = UAP;
-				first_clock = count;
-				remaining++;
-				break;
-			default:
-				pn->clk_offset = (count - (int)(pn->first_pkt_time & 0x3f)) & 0x3f;
-				if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
-					printf("Correct CRC! UAP = 0x%x found after %d total packets.\n",
-					       UAP, pn->total_packets_observed);
-				else
-					printf("Correct CRC! CLK6 = 0x%x found after %d total packets.\n",
-					       pn->clk_offset, pn->total_packets_observed);
-				pn->UAP = UAP;
-				btbb_piconet_set_flag(pn, BTBB_CLK6_VALID, 1);
-				btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 1);
-				pn->total_packets_observed = 0;
-				result = 1;
-				break;
-			}
-		}
+	// the walk covers everything below (and including) the first proven candidate
+	const int winner = s.proven ? __builtin_ctzll(s.proven) : 64;
+	const uint64_t walked = s.live & (below(winner) | (winner < 64 ? 1ULL << winner : 0));
+	const uint64_t survivors = s.kept & below(winner);
+	for (uint64_t w = walked & below(winner); w; w &= w - 1) {
+		const int c = __builtin_ctzll(w);
+		pn->clock6_candidates[c] = ((survivors >> c) & 1) ? (int)s.uap[c] : -1;
 	}
 
-	// leave the packet object as the executed trials leave it in the reference
+	// the packet object ends up as the trials that really ran would have left it
+	const TrialPlan plan = {walked, s.checked & walked, rot};
 	if (packet_gpu_trials_commit(pkt, &plan))
 		fprintf(stderr, "btbb_uap_from_header: state replay failed: %s\n", btbbx_last_error());
-	if (result >= 0)
-		return result;
 
-	btbb_piconet_set_flag(pn, BTBB_GOT_FIRST_PACKET, 1);
-	if (remaining == 1) {
-		pn->clk_offset = (first_clock - (int)(pn->first_pkt_time & 0x3f)) & 0x3f;
-		if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
-			printf("UAP = 0x%x found after %d total packets.\n",
-			       pn->clock6_candidates[first_clock], pn->total_packets_observed);
-		else
-			printf("CLK6 = 0x%x found after %d total packets.\n",
-			       pn->clk_offset, pn->total_packets_observed);
-		pn->UAP = (uint8_t)pn->clock6_candidates[first_clock];
-		btbb_piconet_set_flag(pn, BTBB_CLK6_VALID, 1);
-		btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 1);
-		pn->total_packets_observed = 0;
+	if (winner < 64) {
+		settle_clock6(pn, winner, s.uap[winner], "Correct CRC! ");
 		return 1;
 	}
-	if (remaining == 0)
+	btbb_piconet_set_flag(pn, BTBB_GOT_FIRST_PACKET, 1);
+	switch (__builtin_popcountll(survivors)) {
+	case 1: {
+		const int only = __builtin_ctzll(survivors);
+		settle_clock6(pn, only, s.uap[only], "");
+		return 1;
+	}
+	case 0:
 		piconet_reset(pn);
-	return 0;
+		return 0;
+	default:
+		return 0;
+	}
 }
 
 /* bluetooth_piconet.c:817-849 */
@@ -378,42 +407,121 @@ int btbb_winnow(btbb_piconet *pn)
 	return new_count;
 }
 
-/* try_hop, bluetooth_piconet.c:501-543 */
-static void try_hop(btbb_packet *pkt, btbb_piconet *pn)
+} // extern "C"
+
+// ---- packet dispatch (bluetooth_piconet.c:501-543 try_hop, :851-899 btbb_process_packet) --------
+//
+// What happens to a packet depends only on how far the discovery of its piconet has come.  The
+// stage is computed first, then one handler per stage runs; the handlers return what
+// btbb_process_packet returns.
+enum Stage {
+	STAGE_IGNORE,        // no piconet, no LAP, or no header in the packet
+	STAGE_FOLLOWING,     // UAP and full clock known: decode and print
+	STAGE_WINNOWING,     // UAP and CLK1-6 known, CLK1-27 candidates are being eliminated by observed hops
+	STAGE_CLK6_KNOWN,    // UAP and CLK1-6 known, hop reversal not opened
+	STAGE_CONFIRM_UAP,   // a UAP is assumed, CLK1-6 not yet found with it
+	STAGE_FIND_UAP,      // only the LAP is known
+	STAGE_COUNT
+};
+
+static Stage stage_of(btbb_packet *pkt, const btbb_piconet *pn)
 {
-	uint8_t filter_uap = pn->UAP;
-	btbb_decode(pkt);
-	if (btbb_piconet_get_flag(pn, BTBB_HOP_REVERSAL_INIT)) {
-		if (pn->packets_observed < PN_MAX_PATTERN) {   /* the reference writes past the arrays here */
-			pn->pattern_indices[pn->packets_observed] = (int)(pkt->clkn - pn->first_pkt_time);
-			pn->pattern_channels[pn->packets_observed] = pkt->channel;
-			pn->packets_observed++;
-			pn->total_packets_observed++;
-		}
-		btbb_winnow(pn);
-		if (btbb_piconet_get_flag(pn, BTBB_CLK27_VALID)) {
-			printf("got CLK1-27\n");
-			printf("clock offset = %d.\n", pn->clk_offset);
-		}
-	} else if (btbb_piconet_get_flag(pn, BTBB_CLK6_VALID)) {
-		btbb_uap_from_header(pkt, pn);
-		if (btbb_piconet_get_flag(pn, BTBB_CLK27_VALID)) {
-			printf("got CLK1-27\n");
-			printf("clock offset = %d.\n", pn->clk_offset);
-		}
-	} else if (btbb_uap_from_header(pkt, pn)) {
-		if (filter_uap == pn->UAP) {
-			btbb_init_hop_reversal(0, pn);
-			btbb_winnow(pn);
-		} else {
-			printf("failed to confirm UAP\n");
-		}
-	}
-	if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID)) {
-		btbb_piconet_set_flag(pn, BTBB_UAP_VALID, 1);
-		pn->UAP = filter_uap;
-	}
+	if (!pn || !btbb_piconet_get_flag(pn, BTBB_LAP_VALID) || !btbb_header_present(pkt))
+		return STAGE_IGNORE;
+	if (btbb_piconet_get_flag(pn, BTBB_FOLLOWING))
+		return STAGE_FOLLOWING;
+	if (!btbb_piconet_get_uap(pn))
+		return STAGE_FIND_UAP;
+	if (btbb_piconet_get_flag(pn, BTBB_HOP_REVERSAL_INIT))
+		return STAGE_WINNOWING;
+	return btbb_piconet_get_flag(pn, BTBB_CLK6_VALID) ? STAGE_CLK6_KNOWN : STAGE_CONFIRM_UAP;
 }
+
+static int on_ignore(btbb_packet *, btbb_piconet *) { return 0; }
+
+static int on_following(btbb_packet *pkt, btbb_piconet *pn)
+{
+	btbb_packet_set_uap(pkt, btbb_piconet_get_uap(pn));
+	pkt->flags |= (1u << BTBB_CLK6_VALID) | (1u << BTBB_CLK27_VALID);
+	if (btbb_decode(pkt))
+		btbb_print_packet(pkt);
+	else
+		printf("Failed to decode packet\n");
+	return 0;
+}
+
+static int on_find_uap(btbb_packet *pkt, btbb_piconet *pn)
+{
+	btbb_uap_from_header(pkt, pn);
+	return 0;
+}
+
+// The three stages with an assumed UAP share a frame: decode first, let the stage use the packet,
+// fall back to the assumed UAP if the stage's bookkeeping reset the piconet, and report -1 once
+// both clocks are known (the caller then starts following).
+static void announce_clk27(const btbb_piconet *pn)
+{
+	if (btbb_piconet_get_flag(pn, BTBB_CLK27_VALID))
+		printf("got CLK1-27\nclock offset = %d.\n", pn->clk_offset);
+}
+
+static void stage_winnowing(btbb_packet *pkt, btbb_piconet *pn, uint8_t)
+{
+	const int slot = pn->packets_observed;
+	if (slot < PN_MAX_PATTERN) {                  /* the reference writes past the arrays here */
+		pn->pattern_indices[slot] = (int)(pkt->clkn - pn->first_pkt_time);
+		pn->pattern_channels[slot] = pkt->channel;
+		pn->packets_observed = slot + 1;
+		pn->total_packets_observed++;
+	}
+	btbb_winnow(pn);
+	announce_clk27(pn);
+}
+
+static void stage_clk6_known(btbb_packet *pkt, btbb_piconet *pn, uint8_t)
+{
+	btbb_uap_from_header(pkt, pn);
+	announce_clk27(pn);
+}
+
+static void stage_confirm_uap(btbb_packet *pkt, btbb_piconet *pn, uint8_t assumed)
+{
+	if (!btbb_uap_from_header(pkt, pn))
+		return;
+	if (pn->UAP != assumed) {
+		printf("failed to confirm UAP\n");
+		return;
+	}
+	btbb_init_hop_reversal(0, pn);
+	btbb_winnow(pn);
+}
+
+template <void (*STAGE)(btbb_packet *, btbb_piconet *, uint8_t)>
+static int with_assumed_uap(btbb_packet *pkt, btbb_piconet *pn)
+{
+	const uint8_t assumed = pn->UAP;
+	btbb_decode(pkt);
+	STAGE(pkt, pn, assumed);
+	if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
+		btbb_piconet_set_uap(pn, assumed);
+	const uint32_t both = (1u << BTBB_CLK6_VALID) | (1u << BTBB_CLK27_VALID);
+	if ((pn->flags & both) != both)
+		return 0;
+	btbb_piconet_set_flag(pn, BTBB_FOLLOWING, 1);
+	return -1;
+}
+
+typedef int (*StageHandler)(btbb_packet *, btbb_piconet *);
+static const StageHandler stage_handler[STAGE_COUNT] = {
+	/* STAGE_IGNORE      */ on_ignore,
+	/* STAGE_FOLLOWING   */ on_following,
+	/* STAGE_WINNOWING   */ with_assumed_uap<stage_winnowing>,
+	/* STAGE_CLK6_KNOWN  */ with_assumed_uap<stage_clk6_known>,
+	/* STAGE_CONFIRM_UAP */ with_assumed_uap<stage_confirm_uap>,
+	/* STAGE_FIND_UAP    */ on_find_uap,
+};
+
+extern "C" {
 
 int64_t btbbx_piconet_state(const void *piconet, int field)
 {
@@ -441,35 +549,15 @@ int64_t btbbx_piconet_candidates(const void *piconet, uint32_t *dst, uint64_t ca
 /* bluetooth_piconet.c:851-899 */
 int btbb_process_packet(btbb_packet *pkt, btbb_piconet *pn)
 {
-	if (survey_mode) {
+	if (survey_mode)                              // the caller's piconet is ignored: one per LAP, kept here
 		pn = get_piconet(btbb_packet_get_lap(pkt));
-		btbb_piconet_set_channel_seen(pn, pkt->channel);
-		if (btbb_header_present(pkt) && !btbb_piconet_get_flag(pn, BTBB_UAP_VALID))
-			btbb_uap_from_header(pkt, pn);
-		return 0;
-	}
 	if (pn)
 		btbb_piconet_set_channel_seen(pn, pkt->channel);
-	if (pn && btbb_piconet_get_flag(pn, BTBB_LAP_VALID) && btbb_header_present(pkt)) {
-		if (btbb_piconet_get_flag(pn, BTBB_FOLLOWING)) {
-			btbb_packet_set_uap(pkt, btbb_piconet_get_uap(pn));
-			btbb_packet_set_flag(pkt, BTBB_CLK6_VALID, 1);
-			btbb_packet_set_flag(pkt, BTBB_CLK27_VALID, 1);
-			if (btbb_decode(pkt))
-				btbb_print_packet(pkt);
-			else
-				printf("Failed to decode packet\n");
-		} else if (btbb_piconet_get_uap(pn)) {
-			try_hop(pkt, pn);
-			if (btbb_piconet_get_flag(pn, BTBB_CLK6_VALID) &&
-			    btbb_piconet_get_flag(pn, BTBB_CLK27_VALID)) {
-				btbb_piconet_set_flag(pn, BTBB_FOLLOWING, 1);
-				return -1;
-			}
-		} else {
-			btbb_uap_from_header(pkt, pn);
-		}
-	}
+	if (!survey_mode)
+		return stage_handler[stage_of(pkt, pn)](pkt, pn);
+	// a survey only ever looks for UAPs
+	if (!btbb_piconet_get_flag(pn, BTBB_UAP_VALID) && btbb_header_present(pkt))
+		btbb_uap_from_header(pkt, pn);
 	return 0;
 }
 

@@ -148,6 +148,68 @@ def test_reversal_random_against_oracle():
         orc.orc_hop_cache_clear()
 
 
+def test_reversal_empty_list_stops_at_first_observation():
+    """A channel the pattern never produces leaves no candidate; the next btbb_winnow of the reference
+    then runs channel_winnow once, gets 0 and resets (bluetooth_piconet.c:596-601, 614-620): the batch
+    entry reports stop = 0 / count = 0 instead of skipping the (empty) list."""
+    orc = _libs.oracle()
+    lap, uap = 0x2468AC, 0x51
+    pn, _ = _hop.orc_pattern(orc, lap, uap, None)
+    c = pn.contents
+    c.first_pkt_time, c.clk_offset = 0, 5
+    c.pattern_indices[0], c.pattern_channels[0] = 0, 79
+    c.packets_observed = 1
+    assert orc.orc_init_hop_reversal(0, pn) == 0
+    rev = bt.HopReversal(bt.hop_cfg(lap, uap), 5, 79, 0)
+    assert rev.count == 0
+    c.pattern_indices[1], c.pattern_channels[1] = 40, 3
+    c.packets_observed = 2
+    assert orc.orc_winnow(pn) == 0 and c.winnowed == 0 and not (c.flags >> _hop.F_HOP_INIT & 1)
+    assert rev.winnow([0, 40], [79, 3])[:2] == (0, 0)
+    assert rev.winnow([], [])[:2] == (0, 0)                     # nothing to apply: unchanged, no stop
+    rev.close()
+    orc.orc_piconet_free(pn)
+    orc.orc_hop_cache_clear()
+
+
+def test_process_packet_on_unused_channel_resets(capfd):
+    """Packets reported on channel 79 (never hopped on): CLK1-6 is found from the headers, the hop
+    reversal opens with an empty candidate list and the first winnow resets the piconet -- state and
+    return values equal the oracle's after every packet."""
+    from test_gpu_packets import DropIn
+    lib, orc = bt.lib(), _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(710))
+    lap, uap = 0x13579B, 0x6D
+    _, seq = _hop.orc_pattern(orc, lap, uap, None)
+    pn = C.c_void_p(lib.btbb_piconet_new())
+    on = orc.orc_piconet_new()
+    lib.btbb_init_piconet(pn, lap)
+    orc.orc_init_piconet(on, lap)
+    lib.btbb_piconet_set_uap(pn, uap)
+    on.contents.UAP = uap
+    orc.orc_piconet_set_flag(on, _hop.F_UAP_VALID, 1)
+    resets = 0
+    for k, (sym, ch, clkn) in enumerate(_hop.piconet_traffic(rng, seq, lap, uap, 123456, 40)):
+        d = DropIn(lib, orc, lap)
+        d.set_data(sym, 79, clkn)
+        a, b = lib.btbb_process_packet(d.p, pn), orc.orc_process_packet(d.o, on)
+        assert a == b == 0, k
+        d.check(k)
+        c = on.contents
+        assert _state(lib, pn) == [c.num_candidates, c.winnowed, c.packets_observed, c.total_packets_observed,
+                                   c.first_pkt_time, c.flags, c.used_channels], k
+        assert lib.btbb_piconet_get_uap(pn) == c.UAP and lib.btbb_piconet_get_clk_offset(pn) == c.clk_offset
+        # the whole ladder (CLK1-6 found -> reversal opened empty -> winnow -> reset) runs inside one call
+        assert not (c.flags >> _hop.F_HOP_INIT & 1) and not (c.flags >> _hop.F_CLK27_VALID & 1), k
+        resets += int(c.total_packets_observed == 0 and c.packets_observed == 0 and c.num_candidates == 0)
+        d.close()
+    lib.btbb_piconet_unref(pn)
+    orc.orc_piconet_free(on)
+    orc.orc_hop_cache_clear()
+    capfd.readouterr()
+    assert resets >= 5
+
+
 def _state(lib, pn):
     return [int(lib.btbbx_piconet_state(pn, f)) for f in range(7)]
 
