@@ -90,6 +90,11 @@ typedef struct btbbx_pkt_out {
  * errors on the CURRENT HIP device.  Like btbb_init() the first non-zero value wins
  * (bluetooth_packet.c:288-289).  Returns 0 or a negative BTBBX_E_*. */
 int btbbx_init(int max_ac_errors);
+/* The same for every device of `devices[0..n_devices)` (HIP ordinals); the calling thread's current
+ * device is restored.  Needed before btbbx_scan_host_multi; one-process-per-GPU callers just select
+ * their device and call btbbx_init / btbb_init.  The tables are the same on every device: the first
+ * non-zero max_ac_errors of the PROCESS wins, as with the reference's one global map. */
+int btbbx_init_devices(const int *devices, int n_devices, int max_ac_errors);
 void btbbx_shutdown(void);
 const char *btbbx_last_error(void);
 int btbbx_device_count(void);
@@ -107,8 +112,11 @@ int btbbx_sync(void *hip_stream);
 /* All pointers are DEVICE pointers.  n_streams packed streams of n_words words each
  * lie pitch_words apart; offsets [0, search_bits) of every stream are tested, which
  * needs search_bits + 63 <= 64 * n_words.  Hits are appended (unordered) to d_hits (16-byte aligned),
- * *d_hit_count counts ALL hits even beyond hit_cap.  The caller zeroes *d_hit_count.
- * Asynchronous on hip_stream (NULL = the null stream). */
+ * *d_hit_count counts ALL hits even beyond hit_cap.  If the count exceeds hit_cap the hit_cap records
+ * that were stored are an UNSPECIFIED subset of the matches (whichever wavefronts came first), not the
+ * first ones: size the buffer from the count and scan again, use btbbx_scan_first_device for
+ * first-match semantics, or use the host wrappers below, which do this themselves.  The caller zeroes
+ * *d_hit_count.  Asynchronous on hip_stream (NULL = the null stream). */
 int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		      uint32_t n_streams, uint64_t search_bits,
 		      uint32_t lap, int max_ac_errors,
@@ -123,12 +131,32 @@ int btbbx_scan_first_device(const uint64_t *d_words, uint64_t n_words, uint64_t 
 			    void *hip_stream);
 
 /* Host convenience wrappers (copy in, scan on the GPU, copy out, sort by
- * (stream, offset)).  Return the number of hits found (may exceed cap; only cap are
- * written) or a negative BTBBX_E_*. */
+ * (stream, offset)).  Return the number of hits found or a negative BTBBX_E_*.  The count may exceed
+ * cap; then the cap records written are the cap SMALLEST (stream, offset) ones -- cap = 1 is the
+ * first match of btbb_find_ac (lib/src/bluetooth_packet.c:444-464).  Safe to call from several host
+ * threads at once (each call leases its own scratch memory and stream). */
 int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search_bits,
 			uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
 int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
 			   uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
+
+/* Time sharding over several GPUs of one node (no data-path collective): shard k of n
+ * owns offsets [first_offset, first_offset + search_bits) of the capture and must be given words
+ * [first_word, first_word + n_words) -- its slice plus a 63-symbol halo.  Offsets a shard reports are
+ * local; global = first_offset + local.  One-process-per-GPU callers (MPI-style ranks) use
+ * the plan directly; btbbx_scan_host_multi applies it over the listed devices with one host thread
+ * per device, sorts per device and concatenates.  Every listed device must have been initialised
+ * (btbbx_init_devices); a device may be listed more than once. */
+typedef struct btbbx_shard {
+	uint64_t first_word;      /* first word of the capture this shard reads */
+	uint64_t n_words;         /* words it reads (slice + halo), 0 for an empty shard */
+	uint64_t search_bits;     /* offsets it tests */
+	uint64_t first_offset;    /* = 64 * first_word */
+} btbbx_shard;
+int btbbx_shard_plan(uint64_t search_bits, uint32_t n_shards, uint32_t shard, btbbx_shard *out);
+int64_t btbbx_scan_host_multi(const uint64_t *words, uint64_t n_words, uint64_t search_bits,
+			      uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap,
+			      const int *devices, int n_devices);
 void btbbx_sort_hits(btbbx_hit *hits, size_t n);
 /* the same order for a hit list still in device memory (the host wrappers and the streaming ingest
  * sort here before copying out); synchronises hip_stream */

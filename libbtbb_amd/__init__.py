@@ -41,6 +41,11 @@ class Hit(C.Structure):
                 ("reserved", C.c_uint8), ("stream", C.c_uint16)]
 
 
+class Shard(C.Structure):
+    _fields_ = [("first_word", C.c_uint64), ("n_words", C.c_uint64), ("search_bits", C.c_uint64),
+                ("first_offset", C.c_uint64)]
+
+
 class Trial(C.Structure):
     _fields_ = [("uap", C.c_uint8), ("type", C.c_uint8), ("rv", C.c_int16)]
 
@@ -78,6 +83,7 @@ _vp, _u64, _u32 = C.c_void_p, C.c_uint64, C.c_uint32
 SIGNATURES = {
     # ---- btbbx.h
     "btbbx_init": (C.c_int, [C.c_int]),
+    "btbbx_init_devices": (C.c_int, [_vp, C.c_int, C.c_int]),
     "btbbx_shutdown": (None, []),
     "btbbx_last_error": (C.c_char_p, []),
     "btbbx_device_count": (C.c_int, []),
@@ -92,6 +98,8 @@ SIGNATURES = {
     "btbbx_scan_first_device": (C.c_int, [_vp, _u64, _u64, _u32, C.c_int, _vp, _vp]),
     "btbbx_scan_host": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
     "btbbx_scan_symbols": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
+    "btbbx_shard_plan": (C.c_int, [_u64, _u32, _u32, _vp]),
+    "btbbx_scan_host_multi": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64, _vp, C.c_int]),
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
     "btbbx_sort_hits_device": (C.c_int, [_vp, _u32, _vp]),
     "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
@@ -238,15 +246,43 @@ def _ptr(a):
 # ------------------------------------------------------------------------------------
 # thin host-buffer helpers (tests, small jobs); the benchmark uses the *_device entries
 # ------------------------------------------------------------------------------------
-def scan_words(words, search_bits, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20):
-    """All access codes in a packed stream held in host memory (numpy uint64)."""
+def init_devices(devices, max_ac_errors=2):
+    """btbb_init() on every listed HIP device (for scan_words_multi)."""
+    arr = (C.c_int * len(devices))(*devices)
+    check(lib().btbbx_init_devices(arr, len(devices), max_ac_errors), "btbbx_init_devices")
+
+
+def shard_plan(search_bits, n_shards, shard):
+    """The library's time-shard plan (btbbx_shard_plan): which words shard `shard` of `n_shards` reads."""
+    out = Shard()
+    check(lib().btbbx_shard_plan(search_bits, n_shards, shard, C.byref(out)), "btbbx_shard_plan")
+    return dict(first_word=out.first_word, n_words=out.n_words, search_bits=out.search_bits,
+                first_offset=out.first_offset)
+
+
+def scan_words(words, search_bits, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20, truncate=False):
+    """All access codes in a packed stream held in host memory (numpy uint64).  With truncate=True
+    the `cap` smallest (stream, offset) hits are returned when more were found."""
     words = np.ascontiguousarray(words, dtype=np.uint64)
     hits = np.zeros(cap, dtype=HIT_DTYPE)
     n = check(lib().btbbx_scan_host(_ptr(words), len(words), search_bits, lap, max_ac_errors, _ptr(hits), cap),
               "btbbx_scan_host")
-    if n > cap:
+    if n > cap and not truncate:
         raise BtbbError("hit buffer too small: %d > %d" % (n, cap))
-    return hits[:n]
+    return hits[:min(n, cap)]
+
+
+def scan_words_multi(words, search_bits, devices, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20, truncate=False):
+    """The same through btbbx_scan_host_multi: the capture is time-sharded over `devices` (HIP ordinals,
+    repeats allowed), one host thread per entry."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    hits = np.zeros(cap, dtype=HIT_DTYPE)
+    arr = (C.c_int * len(devices))(*devices)
+    n = check(lib().btbbx_scan_host_multi(_ptr(words), len(words), search_bits, lap, max_ac_errors, _ptr(hits), cap,
+                                          arr, len(devices)), "btbbx_scan_host_multi")
+    if n > cap and not truncate:
+        raise BtbbError("hit buffer too small: %d > %d" % (n, cap))
+    return hits[:min(n, cap)]
 
 
 def scan_symbols(symbols, search_length, lap=LAP_ANY, max_ac_errors=2, cap=1 << 20):

@@ -126,10 +126,12 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 		return -1;
 	if (!gpu_ready("btbb_find_ac"))
 		return -1;
+	CallScope scope;                                  // private scratch + stream: callers may be concurrent
+	hipStream_t q = scope_stream();
 	const uint64_t n_sym = (uint64_t)search_length + 63;     // last symbol the reference reads
 	const uint64_t n_words = (n_sym + 63) / 64;
 	const size_t sym_bytes = (n_sym + 15) & ~15ULL;
-	char *block = (char *)ctx_scratch(sym_bytes + (n_words + 2) * 8 + 16);
+	char *block = (char *)scope_device(sym_bytes + (n_words + 2) * 8 + 16);
 	if (!block) {
 		fprintf(stderr, "btbb_find_ac: %s\n", btbbx_last_error());
 		return -1;
@@ -140,7 +142,7 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 	uint8_t *d_sym = (uint8_t *)block;
 	uint64_t *d_first = (uint64_t *)(block + sym_bytes);
 	uint64_t *d_words = d_first + 1;
-	char *stage = (char *)ctx_pinned(sym_bytes + 16);
+	char *stage = (char *)scope_pinned(sym_bytes + 16);
 	uint64_t first = ~0ULL;
 	int rc = BTBBX_OK;
 	if (!stage) {
@@ -148,16 +150,16 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 	} else {
 		memcpy(stage, stream, n_sym);
 		memcpy(stage + sym_bytes, &first, 8);
-		if (hipMemcpyAsync(d_sym, stage, sym_bytes + 8, hipMemcpyHostToDevice, nullptr) != hipSuccess)
+		if (hipMemcpyAsync(d_sym, stage, sym_bytes + 8, hipMemcpyHostToDevice, q) != hipSuccess)
 			rc = BTBBX_E_NODEVICE;
 	}
 	if (!rc)
-		rc = btbbx_pack_device(d_sym, n_sym, d_words, nullptr);
+		rc = btbbx_pack_device(d_sym, n_sym, d_words, q);
 	if (!rc)
 		rc = btbbx_scan_first_device(d_words, n_words, (uint64_t)search_length,
-					     lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, d_first, nullptr);
-	if (!rc && (hipMemcpyAsync(stage + sym_bytes + 8, d_first, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
-		    hipStreamSynchronize(nullptr) != hipSuccess))
+					     lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, d_first, q);
+	if (!rc && (hipMemcpyAsync(stage + sym_bytes + 8, d_first, 8, hipMemcpyDeviceToHost, q) != hipSuccess ||
+		    hipStreamSynchronize(q) != hipSuccess))
 		rc = BTBBX_E_NODEVICE;
 	if (!rc)
 		memcpy(&first, stage + sym_bytes + 8, 8);
@@ -359,19 +361,12 @@ struct DevPacketBufs {
 	btbbx_trial *d_trials;
 };
 
-static int dev_bufs(DevPacketBufs &b)
+static int dev_bufs(DevPacketBufs &b)          // inside a CallScope
 {
-	static void *block = nullptr, *mirror = nullptr;
-	if (!block) {
-		hipError_t e = hipMalloc(&block, PB_TOTAL);
-		if (e != hipSuccess)
-			return hip_fail(e, "hipMalloc(packet buffers)");
-	}
-	if (!mirror) {
-		hipError_t e = hipHostMalloc(&mirror, PB_TOTAL, hipHostMallocDefault);
-		if (e != hipSuccess)
-			return hip_fail(e, "hipHostMalloc(packet buffers)");
-	}
+	void *mirror = nullptr;
+	void *block = scope_packet_block(&mirror, PB_TOTAL);
+	if (!block)
+		return BTBBX_E_NOMEM;
 	b.dev = (char *)block;
 	b.host = (char *)mirror;
 	b.d_sym = (uint8_t *)(b.dev + PB_SYM);
@@ -442,6 +437,8 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 {
 	if (!gpu_ready("btbb_uap_from_header"))
 		return BTBBX_E_NODEVICE;
+	CallScope scope;        // the caller (btbb_uap_from_header) holds the outer scope: same lease in _commit
+	hipStream_t q = scope_stream();
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
@@ -458,11 +455,11 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 	memcpy(b.host + PB_OUT, &out, sizeof(out));
 	memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
 	memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
-	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_PKT, hipMemcpyHostToDevice, nullptr));
-	rc = launch_trials_state(b.d_sym, b.d_in, b.d_out, b.dev + PB_STATE, b.d_trials, nullptr);
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, PB_PKT, hipMemcpyHostToDevice, q));
+	rc = launch_trials_state(b.d_sym, b.d_in, b.d_out, b.dev + PB_STATE, b.d_trials, q);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, nullptr));
-	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpyAsync(b.host + PB_TRIALS, b.d_trials, 64 * sizeof(btbbx_trial), hipMemcpyDeviceToHost, q));
+	HIP_TRY(hipStreamSynchronize(q));
 	memcpy(trials64, b.host + PB_TRIALS, 64 * sizeof(btbbx_trial));
 	return BTBBX_OK;
 }
@@ -472,13 +469,15 @@ int packet_gpu_trials(const btbb_packet *pkt, btbbx_trial *trials64)
 // the device.
 int packet_gpu_trials_commit(btbb_packet *pkt, const TrialPlan *plan)
 {
+	CallScope scope;
+	hipStream_t q = scope_stream();
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
-	rc = launch_trials_merge(b.dev + PB_STATE, b.d_in, b.d_out, b.d_pay, plan, nullptr);
+	rc = launch_trials_merge(b.dev + PB_STATE, b.d_in, b.d_out, b.d_pay, plan, q);
 	if (rc) return rc;
-	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, PB_PKT - PB_OUT, hipMemcpyDeviceToHost, nullptr));
-	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, PB_PKT - PB_OUT, hipMemcpyDeviceToHost, q));
+	HIP_TRY(hipStreamSynchronize(q));
 	btbbx_pkt_out out;
 	memcpy(&out, b.host + PB_OUT, sizeof(out));
 	apply_out(pkt, out, true, b);
@@ -490,6 +489,8 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 {
 	if (!gpu_ready("btbb_decode"))
 		return BTBBX_E_NODEVICE;
+	CallScope scope;
+	hipStream_t q = scope_stream();
 	DevPacketBufs b;
 	int rc = dev_bufs(b);
 	if (rc) return rc;
@@ -507,25 +508,25 @@ int packet_gpu_decode(btbb_packet *pkt, uint32_t mode, const TrialPlan *plan, in
 		memcpy(b.host + PB_PAY, pkt->payload, PKT_MAX_PAYLOAD_BITS);
 		memset(b.host + PB_PAY + PKT_MAX_PAYLOAD_BITS, 0, 2752 - PKT_MAX_PAYLOAD_BITS);
 	}
-	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, nullptr));
+	HIP_TRY(hipMemcpyAsync(b.dev, b.host, touches_payload ? PB_PKT : PB_PAY, hipMemcpyHostToDevice, q));
 	if (mode & DEC_TRIALS) {                 // single try_clock / crc_check calls (rare): separate steps
-		rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, nullptr);
+		rc = btbbx_pack_device(b.d_sym, 3200, b.d_pkt, q);
 		if (rc) return rc;
 		uint64_t *d_out_payload = (uint64_t *)((char *)b.d_out + offsetof(btbbx_pkt_out, payload));
-		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, nullptr);
+		rc = btbbx_pack_device(b.d_pay, 2752, d_out_payload, q);
 		if (rc) return rc;
-		rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, nullptr);
+		rc = launch_decode(b.d_pkt, b.d_in, 1, b.d_out, mode, plan, q);
 		if (rc) return rc;
-		rc = btbbx_unpack_device(d_out_payload, 2752, b.d_pay, nullptr);
+		rc = btbbx_unpack_device(d_out_payload, 2752, b.d_pay, q);
 		if (rc) return rc;
 	} else {                                 // pack + decode + unpack in one launch
-		rc = launch_decode_bytes(b.d_sym, b.d_pay, b.d_in, b.d_out, mode, touches_payload, nullptr);
+		rc = launch_decode_bytes(b.d_sym, b.d_pay, b.d_in, b.d_out, mode, touches_payload, q);
 		if (rc) return rc;
 	}
 	// pkt_out and (when touched) the payload bits are adjacent: one copy back
 	HIP_TRY(hipMemcpyAsync(b.host + PB_OUT, b.dev + PB_OUT, (touches_payload ? PB_PKT : PB_PAY) - PB_OUT,
-			       hipMemcpyDeviceToHost, nullptr));
-	HIP_TRY(hipStreamSynchronize(nullptr));
+			       hipMemcpyDeviceToHost, q));
+	HIP_TRY(hipStreamSynchronize(q));
 	memcpy(&out, b.host + PB_OUT, sizeof(out));
 	if (header_present) *header_present = out.header_present;
 	if (header_rv) *header_rv = out.header_rv;

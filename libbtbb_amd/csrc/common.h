@@ -74,6 +74,12 @@ uint64_t host_gen_syncword(uint32_t lap);
 uint64_t host_syndrome(uint64_t cw);
 
 // ---- context ------------------------------------------------------------------------
+// One context per HIP device (tables are replicated, nothing is shared between devices).  Every
+// entry point works on the context of the calling thread's CURRENT device, so one-process-per-GPU
+// callers (hipSetDevice once) and one-process-many-GPUs callers (btbbx_scan_host_multi: one host
+// thread per device) go through the same code.
+#define BTBBX_MAX_DEVICES 16
+
 struct Ctx {
 	bool ready = false;
 	int device = -1;
@@ -83,21 +89,26 @@ struct Ctx {
 	void *d_tab_block = nullptr;
 	void *d_hslots = nullptr;
 	void *d_bitmap2 = nullptr;
-	// packet-chain tables
-	void *d_chain = nullptr;
-	// scratch for the host convenience wrappers and the drop-in API
-	void *d_scratch = nullptr;
-	size_t scratch_bytes = 0;
-	void *h_pinned = nullptr;
-	size_t pinned_bytes = 0;
 };
 
-Ctx &ctx();
+Ctx &ctx();                              // context of the current device (never null; maybe !ready)
 int ctx_require();                       // BTBBX_OK or error (sets last error)
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
-void *ctx_scratch(size_t bytes);         // grow-only device scratch
-void *ctx_pinned(size_t bytes);          // grow-only pinned host staging
+
+// Scratch memory, pinned staging and a stream for ONE host call.  A CallScope at the top of an entry
+// point leases a buffer set of the current device for the calling thread (nested scopes share the
+// outermost lease), so concurrent callers never see each other's staged symbols or results.
+struct CallScope {
+	CallScope();
+	~CallScope();
+	CallScope(const CallScope &) = delete;
+	CallScope &operator=(const CallScope &) = delete;
+};
+void *scope_device(size_t bytes);        // grow-only device scratch of the innermost live scope
+void *scope_pinned(size_t bytes);        // grow-only pinned host staging
+void *scope_packet_block(void **pinned_mirror, size_t bytes);   // fixed-size device block + pinned mirror
+hipStream_t scope_stream();              // private non-blocking stream of the lease
 
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_fail(_e, #expr); } while (0)
 

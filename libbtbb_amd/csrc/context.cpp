@@ -9,13 +9,24 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
-static Ctx g_ctx;
+static Ctx g_ctx[BTBBX_MAX_DEVICES];
+static std::mutex g_init_lock;            // table builds / re-builds and shutdown
+static int g_table_errors = 0;            // process-wide: the first non-zero btbb_init value
 static thread_local char g_err[512] = "";
 
-Ctx &ctx() { return g_ctx; }
+static int current_device()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BTBBX_MAX_DEVICES)
+		return 0;
+	return d;
+}
+
+Ctx &ctx() { return g_ctx[current_device()]; }
 
 void set_error(const char *fmt, ...)
 {
@@ -41,49 +52,160 @@ extern "C" int btbbx_device_count(void)
 	return n;
 }
 
-extern "C" int btbbx_table_errors(void) { return g_ctx.ready ? g_ctx.table_errors : -1; }
+extern "C" int btbbx_table_errors(void)
+{
+	const Ctx &c = ctx();
+	return c.ready ? c.table_errors : -1;
+}
 
 int ctx_require()
 {
-	if (!g_ctx.ready) {
-		set_error("btbbx: not initialised (call btbb_init/btbbx_init first)");
+	if (!ctx().ready) {
+		set_error("btbbx: not initialised on this device (call btbb_init / btbbx_init / btbbx_init_devices first)");
 		return BTBBX_E_NOTINIT;
 	}
 	return BTBBX_OK;
 }
 
-void *ctx_scratch(size_t bytes)
+// ---- call scopes: leased scratch / staging / stream -----------------------------------------
+
+struct CallBufs {
+	int device = 0;
+	void *d_scratch = nullptr;
+	size_t scratch_bytes = 0;
+	void *h_pinned = nullptr;
+	size_t pinned_bytes = 0;
+	void *pkt_dev = nullptr, *pkt_host = nullptr;
+	size_t pkt_bytes = 0;
+	hipStream_t stream = nullptr;
+};
+
+static std::mutex g_pool_lock;
+static std::vector<CallBufs *> g_pool[BTBBX_MAX_DEVICES];
+static thread_local CallBufs *tl_bufs = nullptr;
+static thread_local int tl_depth = 0;
+
+static void bufs_free(CallBufs *b)
 {
-	if (bytes <= g_ctx.scratch_bytes)
-		return g_ctx.d_scratch;
-	if (g_ctx.d_scratch)
-		(void)hipFree(g_ctx.d_scratch);
-	g_ctx.d_scratch = nullptr;
-	g_ctx.scratch_bytes = 0;
-	size_t want = bytes + bytes / 4 + 4096;
-	if (hipMalloc(&g_ctx.d_scratch, want) != hipSuccess) {
+	if (b->d_scratch) (void)hipFree(b->d_scratch);
+	if (b->h_pinned) (void)hipHostFree(b->h_pinned);
+	if (b->pkt_dev) (void)hipFree(b->pkt_dev);
+	if (b->pkt_host) (void)hipHostFree(b->pkt_host);
+	if (b->stream) (void)hipStreamDestroy(b->stream);
+	delete b;
+}
+
+CallScope::CallScope()
+{
+	if (tl_depth++ > 0)
+		return;
+	const int dev = current_device();
+	{
+		std::lock_guard<std::mutex> g(g_pool_lock);
+		if (!g_pool[dev].empty()) {
+			tl_bufs = g_pool[dev].back();
+			g_pool[dev].pop_back();
+		}
+	}
+	if (!tl_bufs) {
+		tl_bufs = new CallBufs();
+		tl_bufs->device = dev;
+	}
+}
+
+CallScope::~CallScope()
+{
+	if (--tl_depth > 0)
+		return;
+	CallBufs *b = tl_bufs;
+	tl_bufs = nullptr;
+	if (!b)
+		return;
+	std::lock_guard<std::mutex> g(g_pool_lock);
+	g_pool[b->device].push_back(b);
+}
+
+hipStream_t scope_stream()
+{
+	CallBufs *b = tl_bufs;
+	if (!b)
+		return nullptr;
+	if (!b->stream && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess)
+		b->stream = nullptr;                       // falls back to the NULL stream
+	return b->stream;
+}
+
+void *scope_device(size_t bytes)
+{
+	CallBufs *b = tl_bufs;
+	if (!b) {
+		set_error("internal: scope_device outside a CallScope");
+		return nullptr;
+	}
+	if (bytes <= b->scratch_bytes)
+		return b->d_scratch;
+	if (b->d_scratch) {
+		if (b->stream) (void)hipStreamSynchronize(b->stream);
+		(void)hipFree(b->d_scratch);
+	}
+	b->d_scratch = nullptr;
+	b->scratch_bytes = 0;
+	const size_t want = bytes + bytes / 4 + 4096;
+	if (hipMalloc(&b->d_scratch, want) != hipSuccess) {
 		set_error("btbbx: device scratch allocation of %zu bytes failed", want);
 		return nullptr;
 	}
-	g_ctx.scratch_bytes = want;
-	return g_ctx.d_scratch;
+	b->scratch_bytes = want;
+	return b->d_scratch;
 }
 
-void *ctx_pinned(size_t bytes)
+void *scope_pinned(size_t bytes)
 {
-	if (bytes <= g_ctx.pinned_bytes)
-		return g_ctx.h_pinned;
-	if (g_ctx.h_pinned)
-		(void)hipHostFree(g_ctx.h_pinned);
-	g_ctx.h_pinned = nullptr;
-	g_ctx.pinned_bytes = 0;
-	size_t want = bytes + bytes / 4 + 4096;
-	if (hipHostMalloc(&g_ctx.h_pinned, want, hipHostMallocDefault) != hipSuccess) {
+	CallBufs *b = tl_bufs;
+	if (!b) {
+		set_error("internal: scope_pinned outside a CallScope");
+		return nullptr;
+	}
+	if (bytes <= b->pinned_bytes)
+		return b->h_pinned;
+	if (b->h_pinned) {
+		if (b->stream) (void)hipStreamSynchronize(b->stream);
+		(void)hipHostFree(b->h_pinned);
+	}
+	b->h_pinned = nullptr;
+	b->pinned_bytes = 0;
+	const size_t want = bytes + bytes / 4 + 4096;
+	if (hipHostMalloc(&b->h_pinned, want, hipHostMallocDefault) != hipSuccess) {
 		set_error("btbbx: pinned host allocation of %zu bytes failed", want);
 		return nullptr;
 	}
-	g_ctx.pinned_bytes = want;
-	return g_ctx.h_pinned;
+	b->pinned_bytes = want;
+	return b->h_pinned;
+}
+
+void *scope_packet_block(void **pinned_mirror, size_t bytes)
+{
+	CallBufs *b = tl_bufs;
+	if (!b) {
+		set_error("internal: scope_packet_block outside a CallScope");
+		return nullptr;
+	}
+	if (b->pkt_bytes < bytes) {
+		if (b->pkt_dev) (void)hipFree(b->pkt_dev);
+		if (b->pkt_host) (void)hipHostFree(b->pkt_host);
+		b->pkt_dev = b->pkt_host = nullptr;
+		b->pkt_bytes = 0;
+		hipError_t e = hipMalloc(&b->pkt_dev, bytes);
+		if (e == hipSuccess)
+			e = hipHostMalloc(&b->pkt_host, bytes, hipHostMallocDefault);
+		if (e != hipSuccess) {
+			hip_fail(e, "packet buffers");
+			return nullptr;
+		}
+		b->pkt_bytes = bytes;
+	}
+	*pinned_mirror = b->pkt_host;
+	return b->pkt_dev;
 }
 
 // ---- syndrome map ---------------------------------------------------------------------
@@ -136,7 +258,7 @@ struct MapBuilder {
 static int upload_tables(int max_ac_errors)
 {
 	const HostTables &t = host_tables();
-	Ctx &c = g_ctx;
+	Ctx &c = ctx();
 
 	// entry count = sum_{k<=n} C(58,k)
 	uint64_t entries = 0, binom = 1;
@@ -187,20 +309,28 @@ static int upload_tables(int max_ac_errors)
 	// one block: tabA | tabB | bitmap
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
 	size_t total = off_m + 4 * LDS_BITMAP_WORDS;
-	if (c.d_tab_block) { (void)hipFree(c.d_tab_block); c.d_tab_block = nullptr; }
-	if (c.d_hslots) { (void)hipFree(c.d_hslots); c.d_hslots = nullptr; }
-	if (c.d_bitmap2) { (void)hipFree(c.d_bitmap2); c.d_bitmap2 = nullptr; }
+	// Build the new set beside the old one and swap only when every copy has succeeded: a failure
+	// leaves the context as it was, and nothing is freed under a scan that may still be running.
+	struct Fresh {
+		void *tab = nullptr, *hslots = nullptr, *bitmap2 = nullptr;
+		~Fresh() { if (tab) (void)hipFree(tab); if (hslots) (void)hipFree(hslots); if (bitmap2) (void)hipFree(bitmap2); }
+	} fresh;
 	if (!mb.bitmap2.empty()) {
-		HIP_TRY(hipMalloc(&c.d_bitmap2, mb.bitmap2.size() * 4));
-		HIP_TRY(hipMemcpy(c.d_bitmap2, mb.bitmap2.data(), mb.bitmap2.size() * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMalloc(&fresh.bitmap2, mb.bitmap2.size() * 4));
+		HIP_TRY(hipMemcpy(fresh.bitmap2, mb.bitmap2.data(), mb.bitmap2.size() * 4, hipMemcpyHostToDevice));
 	}
-	HIP_TRY(hipMalloc(&c.d_tab_block, total));
-	HIP_TRY(hipMalloc(&c.d_hslots, mb.slots.size() * sizeof(uint64_t)));
-	char *base = (char *)c.d_tab_block;
+	HIP_TRY(hipMalloc(&fresh.tab, total));
+	HIP_TRY(hipMalloc(&fresh.hslots, mb.slots.size() * sizeof(uint64_t)));
+	char *base = (char *)fresh.tab;
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_m, mb.bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c.d_hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(fresh.hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	HIP_TRY(hipDeviceSynchronize());                   // scans queued on any stream still read the old tables
+	std::swap(c.d_tab_block, fresh.tab);
+	std::swap(c.d_hslots, fresh.hslots);
+	std::swap(c.d_bitmap2, fresh.bitmap2);             // `fresh` now owns the old set and frees it
+	base = (char *)c.d_tab_block;
 	c.scan.tabA = (const uint32_t *)(base + off_a);
 	c.scan.tabB = (const uint32_t *)(base + off_b);
 	c.scan.bitmap = (const uint32_t *)(base + off_m);
@@ -220,13 +350,15 @@ static int upload_tables(int max_ac_errors)
 	return BTBBX_OK;
 }
 
-extern "C" int btbbx_init(int max_ac_errors)
+// tables for the calling thread's current device; g_init_lock held
+static int init_current_device(int max_ac_errors)
 {
-	if (max_ac_errors < 0 || max_ac_errors > 5) {
-		set_error("btbbx_init: max_ac_errors out of range");
-		return BTBBX_E_ARG;
-	}
-	Ctx &c = g_ctx;
+	const int dev = current_device();
+	Ctx &c = g_ctx[dev];
+	// first non-zero max_ac_errors builds the map, later calls keep it -- for the whole process, as in
+	// the reference (bluetooth_packet.c:288-289: `if ((syndrome_map == NULL) && (max_ac_errors))`)
+	if (g_table_errors == 0 && max_ac_errors > 0)
+		g_table_errors = max_ac_errors;
 	if (!c.ready) {
 		int n = 0;
 		hipError_t e = hipGetDeviceCount(&n);
@@ -235,24 +367,61 @@ extern "C" int btbbx_init(int max_ac_errors)
 				  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
 			return BTBBX_E_NODEVICE;
 		}
-		HIP_TRY(hipGetDevice(&c.device));
+		c.device = dev;
 		hipDeviceProp_t prop;
-		HIP_TRY(hipGetDeviceProperties(&prop, c.device));
+		HIP_TRY(hipGetDeviceProperties(&prop, dev));
 		c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 		int rc = chain_upload(host_tables());
 		if (rc)
 			return rc;
-		rc = upload_tables(max_ac_errors);
+		rc = upload_tables(g_table_errors);
 		if (rc)
 			return rc;
 		c.ready = true;
 		return BTBBX_OK;
 	}
-	// first non-zero max_ac_errors builds the map, later calls keep it
-	// (bluetooth_packet.c:288-289: `if ((syndrome_map == NULL) && (max_ac_errors))`)
-	if (c.table_errors == 0 && max_ac_errors > 0)
-		return upload_tables(max_ac_errors);
+	if (c.table_errors != g_table_errors)
+		return upload_tables(g_table_errors);
 	return BTBBX_OK;
+}
+
+extern "C" int btbbx_init(int max_ac_errors)
+{
+	if (max_ac_errors < 0 || max_ac_errors > 5) {
+		set_error("btbbx_init: max_ac_errors out of range");
+		return BTBBX_E_ARG;
+	}
+	std::lock_guard<std::mutex> g(g_init_lock);
+	return init_current_device(max_ac_errors);
+}
+
+extern "C" int btbbx_init_devices(const int *devices, int n_devices, int max_ac_errors)
+{
+	if (max_ac_errors < 0 || max_ac_errors > 5 || n_devices < 0 || (n_devices && !devices)) {
+		set_error("btbbx_init_devices: bad argument");
+		return BTBBX_E_ARG;
+	}
+	const int have = btbbx_device_count();
+	int home = 0;
+	if (have <= 0 || hipGetDevice(&home) != hipSuccess) {
+		set_error("btbbx_init_devices: no HIP device available -- this library has no CPU path");
+		return BTBBX_E_NODEVICE;
+	}
+	std::lock_guard<std::mutex> g(g_init_lock);
+	int rc = BTBBX_OK;
+	for (int i = 0; i < n_devices && !rc; i++) {
+		if (devices[i] < 0 || devices[i] >= have || devices[i] >= BTBBX_MAX_DEVICES) {
+			set_error("btbbx_init_devices: device %d does not exist (%d visible)", devices[i], have);
+			rc = BTBBX_E_ARG;
+			break;
+		}
+		if (hipSetDevice(devices[i]) != hipSuccess)
+			rc = hip_fail(hipGetLastError(), "hipSetDevice");
+		else
+			rc = init_current_device(max_ac_errors);
+	}
+	(void)hipSetDevice(home);
+	return rc;
 }
 
 void hop_pool_release();     // hop.hip
@@ -260,15 +429,30 @@ void sort_scratch_release(); // sort.hip
 
 extern "C" void btbbx_shutdown(void)
 {
-	Ctx &c = g_ctx;
+	std::lock_guard<std::mutex> g(g_init_lock);
+	int home = 0;
+	(void)hipGetDevice(&home);
 	hop_pool_release();
 	sort_scratch_release();
-	if (c.d_tab_block) (void)hipFree(c.d_tab_block);
-	if (c.d_hslots) (void)hipFree(c.d_hslots);
-	if (c.d_bitmap2) (void)hipFree(c.d_bitmap2);
-	if (c.d_scratch) (void)hipFree(c.d_scratch);
-	if (c.h_pinned) (void)hipHostFree(c.h_pinned);
-	c = Ctx();
+	for (int d = 0; d < BTBBX_MAX_DEVICES; d++) {
+		Ctx &c = g_ctx[d];
+		std::vector<CallBufs *> mine;
+		{
+			std::lock_guard<std::mutex> p(g_pool_lock);
+			mine.swap(g_pool[d]);
+		}
+		if (!c.ready && mine.empty())
+			continue;
+		(void)hipSetDevice(d);
+		for (CallBufs *b : mine)
+			bufs_free(b);
+		if (c.d_tab_block) (void)hipFree(c.d_tab_block);
+		if (c.d_hslots) (void)hipFree(c.d_hslots);
+		if (c.d_bitmap2) (void)hipFree(c.d_bitmap2);
+		c = Ctx();
+	}
+	g_table_errors = 0;
+	(void)hipSetDevice(home);
 }
 
 // ---- memory helpers -----------------------------------------------------------------------

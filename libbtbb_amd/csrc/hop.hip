@@ -537,6 +537,7 @@ struct HopWorkspace {
 	HopObs *d_obs;
 	WinnowVerdict *d_verdict;
 	uint32_t *d_total;
+	int device;               // the HIP device the block lives on (a workspace is only reused there)
 	void *h_block;            // pinned: observations going in, verdict / total coming back
 	HopObs *h_obs;
 	WinnowVerdict *h_verdict;
@@ -563,17 +564,21 @@ static void workspace_free(HopWorkspace *w)
 
 static HopWorkspace *workspace_get()
 {
+	int dev = 0;
+	(void)hipGetDevice(&dev);
 	{
 		std::lock_guard<std::mutex> g(pool_lock);
-		if (!pool.empty()) {
-			HopWorkspace *w = pool.back();
-			pool.pop_back();
-			return w;
-		}
+		for (size_t i = 0; i < pool.size(); i++)
+			if (pool[i]->device == dev) {
+				HopWorkspace *w = pool[i];
+				pool.erase(pool.begin() + (long)i);
+				return w;
+			}
 	}
 	HopWorkspace *w = (HopWorkspace *)calloc(1, sizeof(*w));
 	if (!w)
 		return nullptr;
+	w->device = dev;
 	size_t off = 0;
 	auto carve = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
 	const size_t o_c0 = carve(sizeof(uint32_t) * HOP_GROUPS), o_c1 = carve(sizeof(uint32_t) * HOP_GROUPS);

@@ -232,6 +232,7 @@ int btbb_uap_from_header(btbb_packet *pkt, btbb_piconet *pn)
 		return 0;
 	}
 
+	CallScope scope;                              // trials and their commit share one buffer lease
 	btbbx_trial trial[64];                        // one launch: trial[clock] for every CLK1-6 value
 	if (packet_gpu_trials(pkt, trial)) {
 		fprintf(stderr, "btbb_uap_from_header: GPU path failed: %s\n", btbbx_last_error());

@@ -874,33 +874,31 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
 			return BTBBX_E_ARG;
 		}
-		static bool attr_set = false;
-		if (!attr_set) {
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<0>),
-						    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES));
-			attr_set = true;
-		}
-		static int variant = -1;
-		if (variant < 0) {
-			const char *v = getenv("BTBBX_SCAN_VARIANT");      // ablation switch for profiling only
-			variant = v ? atoi(v) : 0;
-		}
 		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
 		// 2^26-bit bitmap in L2 inside the survivor loop (after / instead of the LDS one)
-		int run_variant = variant;
-		if (variant == 0 && c.scan.bitmap2 && c.table_errors >= 4)
+		int run_variant = 0;
+		if (c.scan.bitmap2 && c.table_errors >= 4)
 			run_variant = c.table_errors == 4 ? 9 : 8;
+#ifdef BTBBX_ABLATION
+		// profiling builds only (tools/): kernels with parts of the work removed.  They return WRONG hit
+		// lists by design, so the shipped library does not contain them.
+		if (const char *v = getenv("BTBBX_SCAN_VARIANT"))
+			if (atoi(v) > 0)
+				run_variant = atoi(v);
+#endif
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
 		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
 		switch (run_variant) {
+#ifdef BTBBX_ABLATION
 		case 1: LAUNCH_VARIANT(1); break;
 		case 2: LAUNCH_VARIANT(2); break;
 		case 3: LAUNCH_VARIANT(3); break;
 		case 4: LAUNCH_VARIANT(4); break;
 		case 5: LAUNCH_VARIANT(5); break;
 		case 7: LAUNCH_VARIANT(7); break;
+#endif
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
 		default: LAUNCH_VARIANT(0); break;
@@ -1030,41 +1028,62 @@ extern "C" void btbbx_sort_hits(btbbx_hit *hits, size_t n)
 		memcpy(hits, src, n * sizeof(btbbx_hit));
 }
 
-static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits,
-			     uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap)
+// Scan words already on the current device and bring the hits back in (stream, offset) order.
+// `cap` limits what is WRITTEN, never what is found: when more offsets match than the device buffer
+// of the first pass holds, the scan is repeated with a buffer of the size the counter reported, so
+// that the records handed back are always the `cap` SMALLEST (stream, offset) ones -- a caller asking
+// for one hit gets the first match, as btbb_find_ac would return it (bluetooth_packet.c:444-464).
+static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits, uint32_t lap,
+			     int max_ac_errors, btbbx_hit *hits, uint64_t cap, uint64_t offset_base, hipStream_t q)
 {
-	uint32_t dev_cap = cap > 0xffffffffULL ? 0xffffffffu : (uint32_t)cap;
-	btbbx_hit *d_hits = nullptr;
-	uint32_t *d_count = nullptr;
-	if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) {
+	struct Dev {
+		btbbx_hit *hits = nullptr;
+		uint32_t *count = nullptr;
+		~Dev() { if (hits) (void)hipFree(hits); if (count) (void)hipFree(count); }
+	} d;
+	// first guess: room for what the caller can take, but no more than one hit per 256 offsets + slack
+	uint64_t guess = search_bits / 256 + 4096;
+	if (guess > cap)
+		guess = cap;
+	uint32_t dev_cap = guess > 0xffffffffULL ? 0xffffffffu : (uint32_t)guess;
+	if (hipMalloc(&d.count, sizeof(uint32_t)) != hipSuccess) {
 		set_error("btbbx_scan: counter allocation failed");
 		return BTBBX_E_NOMEM;
 	}
-	if (dev_cap && hipMalloc(&d_hits, (size_t)dev_cap * sizeof(btbbx_hit)) != hipSuccess) {
-		(void)hipFree(d_count);
-		set_error("btbbx_scan: hit buffer allocation failed");
-		return BTBBX_E_NOMEM;
-	}
-	int64_t result;
 	uint32_t count = 0;
-	int rc = BTBBX_OK;
-	if (hipMemset(d_count, 0, sizeof(uint32_t)) != hipSuccess)
-		rc = BTBBX_E_NODEVICE;
-	if (!rc)
-		rc = btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors,
-				       d_hits, dev_cap, d_count, nullptr);
-	if (!rc && hipMemcpy(&count, d_count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess)
-		rc = hip_fail(hipGetLastError(), "hit count readback");
-	if (!rc) {
-		uint32_t n = count < dev_cap ? count : dev_cap;
-		if (n && (rc = btbbx_sort_hits_device(d_hits, (uint32_t)n, nullptr)) == BTBBX_OK &&
-		    hipMemcpy(hits, d_hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost) != hipSuccess)
-			rc = hip_fail(hipGetLastError(), "hit readback");
+	for (int pass = 0; pass < 2; pass++) {
+		if (dev_cap && hipMalloc(&d.hits, (size_t)dev_cap * sizeof(btbbx_hit)) != hipSuccess) {
+			set_error("btbbx_scan: hit buffer allocation failed (%u records)", dev_cap);
+			return BTBBX_E_NOMEM;
+		}
+		HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(uint32_t), q));
+		int rc = btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap,
+					   d.count, q);
+		if (rc)
+			return rc;
+		HIP_TRY(hipMemcpyAsync(&count, d.count, sizeof(count), hipMemcpyDeviceToHost, q));
+		HIP_TRY(hipStreamSynchronize(q));
+		if (count <= dev_cap || cap == 0)
+			break;
+		// more matches than records kept, and the kept ones are whichever lanes came first: repeat
+		// with room for all of them, then keep the smallest
+		if (d.hits) (void)hipFree(d.hits);
+		d.hits = nullptr;
+		dev_cap = count;
 	}
-	result = rc ? rc : (int64_t)count;
-	if (d_hits) (void)hipFree(d_hits);
-	(void)hipFree(d_count);
-	return result;
+	const uint32_t have = count < dev_cap ? count : dev_cap;
+	if (have) {
+		int rc = btbbx_sort_hits_device(d.hits, have, q);
+		if (rc)
+			return rc;
+		const uint64_t n = have < cap ? have : cap;
+		HIP_TRY(hipMemcpyAsync(hits, d.hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost, q));
+		HIP_TRY(hipStreamSynchronize(q));
+		if (offset_base)
+			for (uint64_t i = 0; i < n; i++)
+				hits[i].offset += offset_base;
+	}
+	return (int64_t)count;
 }
 
 extern "C" int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search_bits,
@@ -1076,11 +1095,13 @@ extern "C" int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint
 	rc = check_scan_args(n_words, n_words, 1, search_bits);
 	if (rc)
 		return rc;
-	uint64_t *d_words = (uint64_t *)ctx_scratch((n_words + 2) * 8);
+	CallScope scope;
+	hipStream_t q = scope_stream();
+	uint64_t *d_words = (uint64_t *)scope_device((n_words + 2) * 8);
 	if (!d_words)
 		return BTBBX_E_NOMEM;
-	HIP_TRY(hipMemcpy(d_words, words, n_words * 8, hipMemcpyHostToDevice));
-	return scan_resident(d_words, n_words, search_bits, lap, max_ac_errors, hits, cap);
+	HIP_TRY(hipMemcpyAsync(d_words, words, n_words * 8, hipMemcpyHostToDevice, q));
+	return scan_resident(d_words, n_words, search_bits, lap, max_ac_errors, hits, cap, 0, q);
 }
 
 extern "C" int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
@@ -1093,16 +1114,132 @@ extern "C" int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, u
 		set_error("btbbx_scan_symbols: search_length + 63 exceeds n_symbols");
 		return BTBBX_E_ARG;
 	}
+	CallScope scope;
+	hipStream_t q = scope_stream();
 	uint64_t n_words = (n_symbols + 63) / 64;
 	size_t sym_bytes = (n_symbols + 15) & ~15ULL;
-	char *block = (char *)ctx_scratch(sym_bytes + (n_words + 2) * 8);
+	char *block = (char *)scope_device(sym_bytes + (n_words + 2) * 8);
 	if (!block)
 		return BTBBX_E_NOMEM;
 	uint8_t *d_sym = (uint8_t *)block;
 	uint64_t *d_words = (uint64_t *)(block + sym_bytes);
-	HIP_TRY(hipMemcpy(d_sym, symbols, n_symbols, hipMemcpyHostToDevice));
-	rc = btbbx_pack_device(d_sym, n_symbols, d_words, nullptr);
+	HIP_TRY(hipMemcpyAsync(d_sym, symbols, n_symbols, hipMemcpyHostToDevice, q));
+	rc = btbbx_pack_device(d_sym, n_symbols, d_words, q);
 	if (rc)
 		return rc;
-	return scan_resident(d_words, n_words, search_length, lap, max_ac_errors, hits, cap);
+	return scan_resident(d_words, n_words, search_length, lap, max_ac_errors, hits, cap, 0, q);
+}
+
+// ---- time sharding over the GPUs of one node -------------------------------------
+//
+// The path shards with no exchange step: shard k owns a contiguous, word-aligned range of offsets and
+// reads 63 symbols past its end (an access code that starts at the last owned offset ends there).
+// The same plan serves one-process-per-GPU callers (bench.py, torch.distributed ranks: each rank asks
+// for its own shard) and btbbx_scan_host_multi below (one host thread per listed device).
+
+extern "C" int btbbx_shard_plan(uint64_t search_bits, uint32_t n_shards, uint32_t shard, btbbx_shard *out)
+{
+	if (!out || n_shards == 0 || shard >= n_shards) {
+		set_error("btbbx_shard_plan: shard %u of %u", shard, n_shards);
+		return BTBBX_E_ARG;
+	}
+	const uint64_t words_total = (search_bits + 63) / 64;
+	const uint64_t per = (words_total + n_shards - 1) / n_shards;
+	uint64_t w0 = (uint64_t)shard * per;
+	if (w0 > words_total)
+		w0 = words_total;
+	uint64_t w1 = w0 + per;
+	if (w1 > words_total)
+		w1 = words_total;
+	uint64_t end = w1 * 64;
+	if (end > search_bits)
+		end = search_bits;
+	out->first_word = w0;
+	out->first_offset = w0 * 64;
+	out->search_bits = end > w0 * 64 ? end - w0 * 64 : 0;
+	out->n_words = out->search_bits ? (out->search_bits + 63 + 63) / 64 : 0;
+	return BTBBX_OK;
+}
+
+#include <thread>
+
+extern "C" int64_t btbbx_scan_host_multi(const uint64_t *words, uint64_t n_words, uint64_t search_bits, uint32_t lap,
+					 int max_ac_errors, btbbx_hit *hits, uint64_t cap, const int *devices,
+					 int n_devices)
+{
+	if (!words || n_devices <= 0 || !devices || (!hits && cap)) {
+		set_error("btbbx_scan_host_multi: bad argument");
+		return BTBBX_E_ARG;
+	}
+	int rc = check_scan_args(n_words, n_words, 1, search_bits);
+	if (rc)
+		return rc;
+	struct Part {
+		btbbx_shard plan;
+		std::vector<btbbx_hit> hits;
+		int64_t found = 0;
+		char err[256] = "";
+	};
+	std::vector<Part> parts((size_t)n_devices);
+	std::vector<std::thread> workers;
+	int home = 0;
+	(void)hipGetDevice(&home);
+	for (int k = 0; k < n_devices; k++) {
+		Part &p = parts[(size_t)k];
+		btbbx_shard_plan(search_bits, (uint32_t)n_devices, (uint32_t)k, &p.plan);
+		if (!p.plan.search_bits)
+			continue;
+		const int dev = devices[k];
+		workers.emplace_back([&p, dev, words, lap, max_ac_errors, cap]() {
+			auto fail = [&p](int64_t code) {
+				p.found = code;
+				snprintf(p.err, sizeof(p.err), "%s", btbbx_last_error());
+			};
+			if (hipSetDevice(dev) != hipSuccess)
+				return fail(hip_fail(hipGetLastError(), "hipSetDevice"));
+			int rc = ctx_require();
+			if (rc)
+				return fail(rc);
+			CallScope scope;
+			hipStream_t q = scope_stream();
+			uint64_t *d_words = (uint64_t *)scope_device((p.plan.n_words + 2) * 8);
+			if (!d_words)
+				return fail(BTBBX_E_NOMEM);
+			if (hipMemcpyAsync(d_words, words + p.plan.first_word, p.plan.n_words * 8, hipMemcpyHostToDevice, q) !=
+			    hipSuccess)
+				return fail(hip_fail(hipGetLastError(), "shard upload"));
+			// a shard can hold at most what the caller takes in total
+			uint64_t want = p.plan.search_bits / 256 + 4096;
+			if (want > cap)
+				want = cap;
+			for (;;) {
+				p.hits.resize((size_t)want);
+				const int64_t n = scan_resident(d_words, p.plan.n_words, p.plan.search_bits, lap, max_ac_errors,
+								p.hits.data(), want, p.plan.first_offset, q);
+				if (n < 0)
+					return fail(n);
+				p.found = n;
+				if ((uint64_t)n <= want || want >= cap)
+					break;
+				want = (uint64_t)n < cap ? (uint64_t)n : cap;      // dense stream: once more with room
+			}
+			p.hits.resize((size_t)((uint64_t)p.found < want ? (uint64_t)p.found : want));
+		});
+	}
+	for (std::thread &t : workers)
+		t.join();
+	(void)hipSetDevice(home);
+	int64_t total = 0;
+	uint64_t written = 0;
+	for (const Part &p : parts) {
+		if (p.found < 0) {
+			set_error("btbbx_scan_host_multi: %s", p.err);
+			return p.found;
+		}
+		total += p.found;
+		// shards are disjoint and ascending: concatenation is the (stream, offset) order
+		for (size_t i = 0; i < p.hits.size() && written < cap; i++)
+			hits[written++] = p.hits[i];
+	}
+	return total;
 }

@@ -20,17 +20,29 @@ __global__ __launch_bounds__(256) void hit_keys_kernel(const btbbx_hit *hits, ui
 		keys[i] = ((uint64_t)hits[i].stream << 48) | (hits[i].offset & 0xffffffffffffULL);
 }
 
-static std::mutex sort_lock;
-static void *sort_block;            // keys in | keys out | values out | rocPRIM temporary
-static size_t sort_block_bytes;
+// one scratch block per device: keys in | keys out | values out | rocPRIM temporary
+struct SortScratch {
+	std::mutex lock;
+	void *block = nullptr;
+	size_t bytes = 0;
+};
+static SortScratch sort_scratch[BTBBX_MAX_DEVICES];
 
 void sort_scratch_release()         // btbbx_shutdown
 {
-	std::lock_guard<std::mutex> g(sort_lock);
-	if (sort_block)
-		(void)hipFree(sort_block);
-	sort_block = nullptr;
-	sort_block_bytes = 0;
+	int home = 0;
+	(void)hipGetDevice(&home);
+	for (int d = 0; d < BTBBX_MAX_DEVICES; d++) {
+		SortScratch &s = sort_scratch[d];
+		std::lock_guard<std::mutex> g(s.lock);
+		if (s.block) {
+			(void)hipSetDevice(d);
+			(void)hipFree(s.block);
+		}
+		s.block = nullptr;
+		s.bytes = 0;
+	}
+	(void)hipSetDevice(home);
 }
 
 extern "C" int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_stream)
@@ -38,7 +50,13 @@ extern "C" int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_s
 	if (n < 2)
 		return BTBBX_OK;
 	hipStream_t stream = (hipStream_t)hip_stream;
-	std::lock_guard<std::mutex> g(sort_lock);
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BTBBX_MAX_DEVICES)
+		dev = 0;
+	SortScratch &sc = sort_scratch[dev];
+	void *&sort_block = sc.block;
+	size_t &sort_block_bytes = sc.bytes;
+	std::lock_guard<std::mutex> g(sc.lock);
 	size_t tmp_bytes = 0;
 	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (HitRec *)nullptr,
 					  (HitRec *)nullptr, (size_t)n, 0u, 64u, stream));

@@ -15,19 +15,13 @@ def plan(total_search_bits, world):
 
     Returns a list of dicts {first_word, n_words, search_bits, first_offset}: rank r must hold
     words [first_word, first_word + n_words) of the stream (slice + halo) and test offsets
-    [0, search_bits) of that buffer; global offset = first_offset + local offset."""
+    [0, search_bits) of that buffer; global offset = first_offset + local offset.
+
+    The plan itself is the C library's (btbbx_shard_plan, include/btbbx.h) -- the same one
+    btbbx_scan_host_multi applies inside one process -- so the two multi-GPU forms cannot drift."""
+    from . import shard_plan
     assert world >= 1 and total_search_bits >= 0
-    words_total = (total_search_bits + 63) // 64
-    per = (words_total + world - 1) // world
-    out = []
-    for r in range(world):
-        w0 = min(r * per, words_total)
-        w1 = min(w0 + per, words_total)
-        first_offset = w0 * 64
-        search_bits = max(0, min(w1 * 64, total_search_bits) - first_offset)
-        n_words = (search_bits + HALO_BITS + 63) // 64 if search_bits else 0
-        out.append(dict(first_word=w0, n_words=n_words, search_bits=search_bits, first_offset=first_offset))
-    return out
+    return [shard_plan(total_search_bits, world, r) for r in range(world)]
 
 
 def merge(per_rank_hits, plans):

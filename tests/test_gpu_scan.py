@@ -334,3 +334,89 @@ def test_device_hit_sort():
         assert np.array_equal(key(got), key(host)) and np.all(np.diff(key(got).astype(np.int64)) >= 0)
         full = ["stream", "offset", "lap", "ac_errors"]
         assert np.array_equal(np.sort(got, order=full), np.sort(h, order=full))      # a permutation of the input
+
+
+@pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33])
+def test_sharded_product_scan_equals_single_scan(lap):
+    """btbbx_scan_host_multi (the C-ABI form of the N-GPU path): the library's own shard plan --
+    word-aligned slices + 63-symbol halo -- run through the PRODUCT kernels, one host thread per
+    listed device, equals the single scan and the oracle.  Here every shard runs on device 0."""
+    kw = dict(stride=512) if lap == bt.LAP_ANY else dict(stride=512, lap=lap)
+    words, sym, _ = stream(131, 3000 + 7, **kw)
+    n = len(sym) - 63 - 11                              # not word aligned on purpose
+    want = _libs.orc_find_all(sym, n, lap if lap != bt.LAP_ANY else _libs.LAP_ANY, 2)
+    assert as_tuples(bt.scan_words(words, n, lap, 2)) == want and len(want) > 250
+    bt.init_devices([0], 2)
+    for shards in (1, 2, 3, 8):
+        got = bt.scan_words_multi(words, n, [0] * shards, lap, 2)
+        assert as_tuples(got) == want, shards
+        # ... and shard by shard, the way one-process-per-GPU ranks use the plan (bench.py --gpus N)
+        parts, pos = [], 0
+        for k in range(shards):
+            p = bt.shard_plan(n, shards, k)
+            assert p["first_offset"] == pos and p["first_offset"] == 64 * p["first_word"]
+            pos += p["search_bits"]
+            if p["search_bits"]:
+                assert p["search_bits"] + 63 <= 64 * p["n_words"] and p["first_word"] + p["n_words"] <= len(words)
+                h = bt.scan_words(words[p["first_word"]:p["first_word"] + p["n_words"]], p["search_bits"], lap, 2)
+                parts += [(int(x["offset"]) + p["first_offset"], int(x["lap"]), int(x["ac_errors"])) for x in h]
+        assert pos == n and parts == want, shards
+    with pytest.raises(bt.BtbbError):
+        bt.scan_words_multi(words, n, [0, 99], lap, 2)              # no such device
+
+
+def test_truncated_host_scan_keeps_the_smallest_hits():
+    """`cap` smaller than the number of matches: the host wrappers hand back the cap SMALLEST
+    (stream, offset) hits -- cap = 1 is btbb_find_ac's first match -- not whichever wavefront won."""
+    words, sym, _ = stream(132, 1 << 13, stride=512)                 # ~1000 hits
+    n = len(sym) - 63
+    full = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, 2))
+    assert len(full) > 700
+    for cap in (1, 2, 7, 64, 500):
+        for _ in range(3):                                           # the race is different every time
+            assert as_tuples(bt.scan_words(words, n, bt.LAP_ANY, 2, cap=cap, truncate=True)) == full[:cap], cap
+        assert as_tuples(bt.scan_words_multi(words, n, [0, 0, 0], bt.LAP_ANY, 2, cap=cap, truncate=True)) == full[:cap]
+    hits = np.zeros(4, dtype=bt.HIT_DTYPE)
+    s8 = np.ascontiguousarray(sym)
+    cnt = bt.lib().btbbx_scan_symbols(_libs.ptr(s8), len(s8), n, bt.LAP_ANY, 2, _libs.ptr(hits), 4)
+    assert cnt == len(full) and as_tuples(hits) == full[:4]
+
+
+def test_concurrent_drop_in_callers():
+    """Several host threads inside btbb_find_ac / btbbx_scan_host at once, each on its own buffer
+    (the reference's functions only touch the caller's data, so multi-channel callers do this):
+    every call leases private scratch memory and a private stream, results equal the sequential ones."""
+    import threading
+    lib = bt.lib()
+    jobs = []
+    for k in range(6):
+        words, sym, _ = stream(140 + k, 512 + 64 * k, stride=2048 + 512 * k)
+        jobs.append((words, np.ascontiguousarray(sym), len(sym) - 63))
+    want_scan = [as_tuples(bt.scan_words(w, n, bt.LAP_ANY, 2)) for w, s, n in jobs]
+    want_first = []
+    for w, s, n in jobs:
+        pkt = C.c_void_p(None)
+        want_first.append(lib.btbb_find_ac(_libs.ptr(s), min(n, 60000), bt.LAP_ANY, 2, C.byref(pkt)))
+        if pkt.value:
+            lib.btbb_packet_unref(pkt)
+    errors = []
+
+    def worker(k):
+        try:
+            w, s, n = jobs[k]
+            for rep in range(25):
+                assert as_tuples(bt.scan_words(w, n, bt.LAP_ANY, 2)) == want_scan[k]
+                pkt = C.c_void_p(None)
+                assert lib.btbb_find_ac(_libs.ptr(s), min(n, 60000), bt.LAP_ANY, 2, C.byref(pkt)) == want_first[k]
+                if pkt.value:
+                    assert want_scan[k] and lib.btbb_packet_get_lap(pkt) == want_scan[k][0][1]
+                    lib.btbb_packet_unref(pkt)
+        except Exception as e:                                       # noqa: BLE001 -- reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
