@@ -4,17 +4,23 @@
 Workload (BASELINE.json configs[1]): promiscuous LAP_ANY access-code scan of a 4 GiB
 single-channel packed bitstream resident in HBM (2^35 symbols; iid noise plus one ID-packet
 sync word with 0..3 bit errors every 4096 symbols, generated on the device by
-btbbx_synth_device).  One "step" = one pass of the scan kernel over the whole stream.
-With --gpus N every rank scans its own 4 GiB time shard of the same logical stream (weak
-scaling, no data-path collective); torch.distributed is used for the barrier and for the
-max-over-ranks of the timing only.
+btbbx_synth_device).  One "step" = one pass of the scan kernel over the whole shard.
+With --gpus N the logical capture is N x 4 GiB and rank r takes shard r of the library's own
+time-shard plan (btbbx_shard_plan: word-aligned slice + 63-symbol halo, the plan
+btbbx_scan_host_multi applies inside one process) -- weak scaling, no data-path collective;
+torch.distributed is used for the barrier and for the max-over-ranks of the timing only.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (nbits / 8 read + 16 B per reported hit written) / mean kernel time from HIP events on the
 launch stream, against the 8 TB/s HBM peak.  `cpu_baseline` = the UNMODIFIED reference
 (oracle/_ref/libbtbb_ref.so, all-matches loop around btbb_find_ac) -- or, if that file is
-missing, the oracle port -- timed on this box's host cores over a bounded slice of the same
-stream; its hit list is also compared with the GPU's (field "parity").
+missing, the oracle port -- timed on ALL of this box's host threads over a bounded slice of
+the same stream; its hit list is also compared with the GPU's (field "parity").
+
+`secondary` (N = 1 only, timed in the same run, after the headline region): BASELINE configs 3 and
+5 -- the known-LAP full chain over 79 hop-channel streams (scan -> sort -> gather -> header +
+payload decode) and the 64-seed CLK1-6 brute force over a stream of 2^20 detected packets -- each
+with its own roofline figure and the reference's CPU loop on a bounded sample beside it.
 """
 import argparse
 import ctypes as C
@@ -37,10 +43,37 @@ SEED = 20260926
 STRIDE = 4096
 
 
-def cpu_baseline(words_host, first_word, gpu_hits, cores):
-    """Reference (or port) all-matches scan of `words_host` on `cores` host threads."""
+def host_cpu():
+    """What the CPU baseline runs on: model string, logical threads, physical cores."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return {"model": model, "threads": threads, "physical_cores": len(cores) or None}
+
+
+def cpu_baseline(words_host, first_word, gpu_hits, cpu):
+    """Reference (or port) all-matches scan of `words_host`, one thread per host thread."""
     import _libs
     from libbtbb_amd import synth
+    cores = cpu["threads"]
     ref = _libs.ref()
     kind = "reference" if ref is not None else "port"
     if ref is not None:
@@ -72,12 +105,221 @@ def cpu_baseline(words_host, first_word, gpu_hits, cores):
     sel = gpu_hits[(gpu_hits["offset"] >= lo_bit) & (gpu_hits["offset"] < lo_bit + n)]
     sel = sel[np.argsort(sel["offset"], kind="stable")]
     gpu_list = [(int(h["offset"]) - lo_bit, int(h["lap"]), int(h["ac_errors"])) for h in sel]
+    rate = n / dt / 1e9
     return {
-        "value": round(n / dt / 1e9, 4), "unit": "Gbit/s", "cores": cores, "kind": kind,
-        "sample": "first %d symbols of the same stream, %d threads x all-matches loop around btbb_find_ac "
+        "value": round(rate, 4), "unit": "Gbit/s", "cores": cores, "kind": kind,
+        "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"],
+        "per_thread_Msym_s": round(rate * 1e3 / cores, 2),
+        "sample": "first %d symbols of the same stream, %d threads (every logical CPU of the box; SMT siblings "
+                  "share a core where threads > physical_cores) x all-matches loop around btbb_find_ac "
                   "(one symbol per byte; unpack %.2f s excluded)" % (n, cores, unpack_s),
         "hits": len(cpu_hits),
     }, cpu_hits == gpu_list
+
+
+class Timer:
+    """HIP-event timing on the stream the kernels are launched on (torch's current stream, whose
+    handle is what the C ABI receives)."""
+
+    def __init__(self, stream):
+        self.s = stream
+
+    def ms(self, fn, reps, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(self.s)
+        for _ in range(reps):
+            fn()
+        b.record(self.s)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+
+def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
+    """BASELINE configs 3 and 5, driver-timed: see the module docstring."""
+    import _libs
+    from libbtbb_amd import synth
+    tm = Timer(cur)
+    out = {}
+    ref = _libs.ref() if with_cpu else None
+    if ref is not None:
+        ref.btbb_init(2)
+
+    # ---- the capture: 79 channel streams.  2^14 words per channel are built on the host (real
+    # DM1 / DH1 / DM3 / FHS packets of one piconet every 4096 symbols, CLK1-6 = slot number mod 64,
+    # whitened, up to one symbol error in the header region) and tiled 64 x along time on the device.
+    lap, uap = 0x9E8B33, 0x47
+    nch, wpc0, tiles = 79, 1 << 14, 64
+    rng = np.random.default_rng(SEED)
+    base = synth.noise_words(SEED + 3, 0, nch * wpc0).reshape(nch, wpc0)
+    types = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_FHS]
+    slots = wpc0 * 64 // 4096 - 1
+    pay_bytes = 0
+    t_build = time.perf_counter()
+    for ch in range(nch):
+        symc = synth.unpack_bits(base[ch])
+        for k in range(slots):
+            t_ = types[(k + ch) % 4]
+            body = rng.integers(0, 256, int(rng.integers(1, 17)), dtype=np.uint8).tobytes()
+            p = synth.build_packet(lap, uap, k & 63, t_, lt_addr=1 + k % 7, flags=k % 8, body=body,
+                                   fhs_bits=synth.fhs_payload(lap, uap, 0x1234, k, rng))
+            pos = k * 4096 + 100 + int(rng.integers(0, 64))
+            symc[pos:pos + len(p)] = p
+        base[ch] = synth.pack_bits(symc)
+    t_build = time.perf_counter() - t_build
+    wpc = wpc0 * tiles
+    d3 = torch.from_numpy(base.view(np.int64)).to(dev).repeat(1, tiles).contiguous()      # (79, wpc)
+    nbits = wpc * 64 - 63
+    cap = nch * slots * tiles + (1 << 16)
+    hits = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    pk = torch.zeros(cap * 50, dtype=torch.int64, device=dev)
+    ln = torch.zeros(cap, dtype=torch.int32, device=dev)
+    pin = torch.zeros(cap, 4, dtype=torch.int32, device=dev)
+    pout = torch.zeros(cap * bt.PKTOUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    state = {}
+
+    def scan():
+        cnt.zero_()
+        bt.check(lib.btbbx_scan_device(d3.data_ptr(), wpc, wpc, nch, nbits, lap, 2, hits.data_ptr(), cap, cnt.data_ptr(), hs))
+
+    def chain():
+        scan()
+        n = int(cnt.item())                                     # the one host round trip of the chain
+        assert n <= cap
+        bt.check(lib.btbbx_sort_hits_device(hits.data_ptr(), n, hs))
+        bt.check(lib.btbbx_gather_packets_device(d3.data_ptr(), wpc, wpc, hits.data_ptr(), n, 3125, pk.data_ptr(),
+                                                 ln.data_ptr(), hs))
+        # pkt_in per packet, on the device: captured length, CLK1-6 from the slot number, flags
+        # WHITENED | UAP_VALID | CLK6_VALID, the piconet's UAP
+        off = hits[: 2 * n].view(n, 2)[:, 0]
+        pin[:n, 0] = ln[:n]
+        pin[:n, 1] = ((off >> 12) & 63).to(torch.int32)
+        pin[:n, 2] = (1 << 0) | (1 << 2) | (1 << 4)
+        pin[:n, 3] = uap
+        bt.check(lib.btbbx_decode_device(pk.data_ptr(), pin.data_ptr(), n, pout.data_ptr(), hs))
+        state["n"] = n
+
+    chain()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        chain()
+    torch.cuda.synchronize()
+    chain_ms = (time.perf_counter() - t0) / reps * 1e3
+    n3 = state["n"]
+    scan_ms = tm.ms(scan, 5)
+    res = pout.cpu().numpy().view(bt.PKTOUT_DTYPE)[:n3]
+    ok = (res["payload_rv"] == 10) | (res["payload_rv"] == 1000)
+    pay_bytes = float(res["payload_length"][ok].sum())
+    alg = nch * nbits / 8 + 16 * n3 + n3 * (391 + 32) + pay_bytes
+    scan_alg = nch * nbits / 8 + 16 * n3
+    entry = {
+        "config": "BASELINE configs[2]: known-LAP full decode chain (find_ac -> gather -> header + payload "
+                  "decode) over 79 hop-channel streams, %.2f GiB packed in HBM, one GPU" % (nch * wpc * 8 / 2**30),
+        "value": round(nch * nbits / (chain_ms * 1e-3) / 1e9, 1), "unit": "Gbit/s", "ms_per_step": round(chain_ms, 3),
+        "packets": n3, "packets_per_s": round(n3 / (chain_ms * 1e-3)), "crc_ok": int(ok.sum()),
+        "roofline": {"bound": "hbm", "achieved": round(alg / (chain_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "algorithmic_bytes_per_step": int(alg),
+                     "kernel": "scan_known_lap_kernel", "kernel_ms": round(scan_ms, 4),
+                     "kernel_frac": round(scan_alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
+        "host_build_s": round(t_build, 2),
+    }
+    if ref is not None:
+        syms = [np.ascontiguousarray(synth.unpack_bits(base[ch])) for ch in range(nch)]
+
+        def one(ch):
+            good = C.c_uint64(0)
+            n = ref.refint_known_lap_chain(_libs.ptr(syms[ch]), len(syms[ch]), lap, 2, uap, 4096, C.byref(good))
+            return int(n), int(good.value)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cpu["threads"]) as ex:
+            parts = list(ex.map(one, range(nch)))
+        dt = time.perf_counter() - t0
+        cpu_n, cpu_ok = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        # the same channels on the GPU: tile 0 = offsets below wpc0 * 64 - 63 of every stream
+        hh = hits.cpu().numpy().view(bt.HIT_DTYPE)[:n3]
+        first = hh["offset"] < wpc0 * 64 - 63
+        entry["cpu_baseline"] = {
+            "value": round(nch * (wpc0 * 64 - 63) / dt / 1e9, 4), "unit": "Gbit/s", "cores": cpu["threads"],
+            "kind": "reference", "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"],
+            "packets_per_s": round(cpu_n / dt),
+            "sample": "the untiled capture (79 channels x 2^20 symbols): btbb_find_ac all-matches loop + "
+                      "btbb_packet_set_data + btbb_header_present + btbb_decode_header + btbb_decode_payload per match, "
+                      "one channel per task on %d threads" % cpu["threads"],
+        }
+        entry["parity"] = bool(cpu_n == int(first.sum()) and cpu_ok == int(ok[first].sum()))
+    out["known_lap_79ch_chain"] = entry
+
+    # ---- config 5: CLK1-6 / UAP brute force over a stream of 2^20 detected packets (the packets the
+    # chain above gathered, tiled): 64 x {try_clock, crc_check} per packet, and the HEC-only table
+    n_src = min(n3, nch * slots)
+    npk = 1 << 20
+    idx = (torch.arange(npk, device=dev) % n_src)
+    pk5 = pk[: n3 * 50].view(n3, 50)[idx].contiguous()
+    in5 = torch.zeros(npk, 4, dtype=torch.int32, device=dev)
+    in5[:, 0] = ln[:n3][idx]
+    in5[:, 2] = 1                                             # WHITENED; neither UAP nor clock known
+    tr5 = torch.zeros(npk * 64, dtype=torch.int32, device=dev)
+    tab = torch.zeros(npk * 32, dtype=torch.int32, device=dev)
+
+    def trials():
+        bt.check(lib.btbbx_trials_device(pk5.data_ptr(), in5.data_ptr(), npk, tr5.data_ptr(), hs))
+
+    def uaptab():
+        bt.check(lib.btbbx_uap_table_device(pk5.data_ptr(), in5.data_ptr(), npk, tab.data_ptr(), hs))
+    t_tr = tm.ms(trials, 3)
+    t_u = tm.ms(uaptab, 5)
+    alg5 = npk * (391 + 256)
+    entry = {
+        "config": "BASELINE configs[4]: UAP / CLK1-6 brute force, 64 whitening seeds x (HEC -> UAP, CRC check) "
+                  "per packet over a stream of 2^20 detected packets (DM1 / DH1 / DM3 / FHS as captured, 400 B "
+                  "packed each), one GPU",
+        "value": round(npk / (t_tr * 1e-3)), "unit": "packets/s", "ms_per_step": round(t_tr, 3),
+        "trials_per_s": round(npk * 64 / (t_tr * 1e-3)),
+        "roofline": {"bound": "hbm", "achieved": round(alg5 / (t_tr * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(alg5 / (t_tr * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "algorithmic_bytes_per_step": alg5, "kernel": "trials_kernel", "kernel_ms": round(t_tr, 4),
+                     "traffic": None},
+        "hec_only_table": {"value": round(npk / (t_u * 1e-3)), "unit": "packets/s", "ms_per_step": round(t_u, 4),
+                           "kernel": "uap_table_kernel",
+                           "frac": round(npk * (8 + 128) / (t_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+    }
+    if ref is not None:
+        # bounded sample: the first 256 gathered packets as 3125-symbol buffers, one host thread
+        m = min(256, n_src)
+        words = pk[: m * 50].cpu().numpy().view(np.uint64).reshape(m, 50)
+        lens = ln[:m].cpu().numpy()
+        buf = np.zeros((m, 3200), dtype=np.uint8)
+        for i in range(m):
+            buf[i] = synth.unpack_bits(words[i])
+        length = int(lens.min())
+        table = np.zeros(m * 64, dtype=np.uint32)
+        t0 = time.perf_counter()
+        ref.refint_clk6_trials(_libs.ptr(buf), m, 3200, length, lap, _libs.ptr(table))
+        dt = time.perf_counter() - t0
+        # GPU table for the same packets at the same captured length
+        in_s = torch.zeros(m, 4, dtype=torch.int32, device=dev)
+        in_s[:, 0] = length
+        in_s[:, 2] = 1
+        tr_s = torch.zeros(m * 64, dtype=torch.int32, device=dev)
+        bt.check(lib.btbbx_trials_device(pk.data_ptr(), in_s.data_ptr(), m, tr_s.data_ptr(), hs))
+        torch.cuda.synchronize()
+        g = tr_s.cpu().numpy().view(bt.TRIAL_DTYPE)
+        gpu_tab = g["uap"].astype(np.uint32) | (g["rv"].astype(np.int32).astype(np.uint32) << 8)
+        entry["cpu_baseline"] = {
+            "value": round(m / dt, 1), "unit": "packets/s", "cores": 1, "kind": "reference",
+            "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"],
+            "sample": "%d of the same packets, the 64-candidate try_clock + crc_check loop of btbb_uap_from_header "
+                      "(bluetooth_piconet.c:675-690) on one thread" % m,
+        }
+        entry["parity"] = bool(np.array_equal(gpu_tab, table))
+    out["clk6_bruteforce"] = entry
+    return out
 
 
 def main():
@@ -88,6 +330,7 @@ def main():
     ap.add_argument("--gib", type=float, default=4.0, help="packed stream size per GPU in GiB")
     ap.add_argument("--cpu-symbols", type=int, default=1 << 30, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 block")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "exercising the N>1 path where ranks share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
@@ -111,12 +354,15 @@ def main():
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     import libbtbb_amd as bt
+    from libbtbb_amd import shard
     bt.init(2)
     lib = bt.lib()
 
-    nwords = int(args.gib * (1 << 30)) // 8
-    nbits = nwords * 64 - 63
-    first_word = rank * nwords                     # time shard of the logical stream
+    # the logical capture is `world` x --gib; this rank's shard of it (slice + 63-symbol halo)
+    words_per_gpu = int(args.gib * (1 << 30)) // 8
+    total_bits = world * words_per_gpu * 64 - 63
+    plan = shard.plan(total_bits, world)[rank]
+    nwords, nbits, first_word = plan["n_words"], plan["search_bits"], plan["first_word"]
     stream = torch.empty(nwords, dtype=torch.int64, device=dev)
     cap = nbits // STRIDE + (1 << 16)              # injections + chance matches + slack
     hits_t = torch.empty(cap * 2, dtype=torch.int64, device=dev)
@@ -163,16 +409,17 @@ def main():
 
     result = None
     if rank == 0:
-        value = world * nbits * args.steps / elapsed / 1e9
+        value = total_bits * args.steps / elapsed / 1e9          # every offset of the logical capture, once per step
         alg_bytes = nbits / 8 + 16 * nhits
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
-        # (profiles/traffic.json says how); only quoted for the workload it was measured on
-        traffic = None
+        # HBM traffic per launch: NOT measured in this run -- the value of the last rocprofv3 --pmc passes over
+        # this same command (separate passes, FETCH_SIZE doubled as the guide prescribes), see the file named
+        traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if abs(args.gib - 4.0) < 1e-9:
                 traffic = int(tj["bytes_per_launch"])
+                traffic_source = "profiles/traffic.json (%s); not re-measured in this run" % tj.get("source", "rocprofv3 --pmc")
         except Exception:
             traffic = None
         result = {
@@ -185,22 +432,26 @@ def main():
                                    "bitstream per GPU, max_ac_errors=2, sync word every %d symbols"
                                    % (args.gib, STRIDE),
                        "symbols_per_gpu": nbits, "hits_per_gpu": nhits,
-                       "parallelism": "time-sharded x%d, no collectives" % world},
+                       "parallelism": "time-sharded x%d (btbbx_shard_plan: slices + 63-symbol halo), no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_lap_any_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        cpu = host_cpu()
         if world == 1 and not args.no_cpu:
             ncpu_words = min(nwords, (args.cpu_symbols + 63) // 64)
             words_host = stream[:ncpu_words].cpu().numpy().view(np.uint64)
             raw = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:nhits]
-            cores = max(1, min(os.cpu_count() or 1, 64))
-            base, parity = cpu_baseline(words_host, 0, raw, cores)
+            base, parity = cpu_baseline(words_host, 0, raw, cpu)
             result["cpu_baseline"] = base
             result["parity"] = bool(parity)
         else:
             result["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary:
+            del stream, hits_t
+            torch.cuda.empty_cache()
+            result["secondary"] = secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -12,8 +12,15 @@
  * Each declaration cites the reference declaration it replaces
  * (lib/src/btbb.h:<line> in /root/reference).
  *
- * Not provided (outside the hot path): hop reversal
- * (btbb_init_hop_reversal / btbb_winnow), pcap/pcapng writers, BLE (lell_*).
+ * Provided beyond the packet half: the piconet half including hop reversal
+ * (btbb_init_hop_reversal / btbb_winnow, GPU candidate lists) and the BR/EDR pcap / pcapng
+ * writers.  NOT provided: the Bluetooth LE half (lell_* and the LE capture writers) -- a
+ * caller that uses it keeps the reference's objects for those symbols.
+ *
+ * Threads: every call that goes to the GPU leases private staging memory and a private
+ * stream, so different threads may work on DIFFERENT packets / piconets at the same time
+ * (the reference's own rule: its functions only touch the caller's objects).  One object is
+ * for one thread at a time; btbb_init() and the survey-mode globals are process wide.
  */
 #ifndef INCLUDED_BTBB_H
 #define INCLUDED_BTBB_H

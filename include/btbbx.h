@@ -139,6 +139,11 @@ int64_t btbbx_scan_host(const uint64_t *words, uint64_t n_words, uint64_t search
 			uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
 int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
 			   uint32_t lap, int max_ac_errors, btbbx_hit *hits, uint64_t cap);
+/* First match only, from host memory: *first_hit = the match with the smallest offset in
+ * [0, search_length) -- what btbb_find_ac returns (lib/src/bluetooth_packet.c:444-464).  Returns 1
+ * (found), 0 (none) or a negative BTBBX_E_*.  search_length + 63 <= n_symbols, search_length < 2^32. */
+int btbbx_find_first_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
+			     uint32_t lap, int max_ac_errors, btbbx_hit *first_hit);
 
 /* Time sharding over several GPUs of one node (no data-path collective): shard k of n
  * owns offsets [first_offset, first_offset + search_bits) of the capture and must be given words

@@ -98,6 +98,7 @@ SIGNATURES = {
     "btbbx_scan_first_device": (C.c_int, [_vp, _u64, _u64, _u32, C.c_int, _vp, _vp]),
     "btbbx_scan_host": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
     "btbbx_scan_symbols": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
+    "btbbx_find_first_symbols": (C.c_int, [_vp, _u64, _u64, _u32, C.c_int, _vp]),
     "btbbx_shard_plan": (C.c_int, [_u64, _u32, _u32, _vp]),
     "btbbx_scan_host_multi": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64, _vp, C.c_int]),
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),

@@ -126,60 +126,23 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 		return -1;
 	if (!gpu_ready("btbb_find_ac"))
 		return -1;
-	CallScope scope;                                  // private scratch + stream: callers may be concurrent
-	hipStream_t q = scope_stream();
-	const uint64_t n_sym = (uint64_t)search_length + 63;     // last symbol the reference reads
-	const uint64_t n_words = (n_sym + 63) / 64;
-	const size_t sym_bytes = (n_sym + 15) & ~15ULL;
-	char *block = (char *)scope_device(sym_bytes + (n_words + 2) * 8 + 16);
-	if (!block) {
-		fprintf(stderr, "btbb_find_ac: %s\n", btbbx_last_error());
-		return -1;
-	}
-	// Device block: symbols | sentinel for the first-match word | packed words.  The sentinel sits
-	// right behind the symbols so that ONE host-to-device copy from pinned staging brings both in;
-	// pack + scan + the 8-byte result copy are queued behind it and the call synchronises once.
-	uint8_t *d_sym = (uint8_t *)block;
-	uint64_t *d_first = (uint64_t *)(block + sym_bytes);
-	uint64_t *d_words = d_first + 1;
-	char *stage = (char *)scope_pinned(sym_bytes + 16);
-	uint64_t first = ~0ULL;
-	int rc = BTBBX_OK;
-	if (!stage) {
-		rc = BTBBX_E_NOMEM;
-	} else {
-		memcpy(stage, stream, n_sym);
-		memcpy(stage + sym_bytes, &first, 8);
-		if (hipMemcpyAsync(d_sym, stage, sym_bytes + 8, hipMemcpyHostToDevice, q) != hipSuccess)
-			rc = BTBBX_E_NODEVICE;
-	}
-	if (!rc)
-		rc = btbbx_pack_device(d_sym, n_sym, d_words, q);
-	if (!rc)
-		rc = btbbx_scan_first_device(d_words, n_words, (uint64_t)search_length,
-					     lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, d_first, q);
-	if (!rc && (hipMemcpyAsync(stage + sym_bytes + 8, d_first, 8, hipMemcpyDeviceToHost, q) != hipSuccess ||
-		    hipStreamSynchronize(q) != hipSuccess))
-		rc = BTBBX_E_NODEVICE;
-	if (!rc)
-		memcpy(&first, stage + sym_bytes + 8, 8);
-	if (rc) {
+	btbbx_hit first;
+	const int rc = btbbx_find_first_symbols(stream, (uint64_t)search_length + 63, (uint64_t)search_length,
+						lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, &first);
+	if (rc < 0) {
 		fprintf(stderr, "btbb_find_ac: GPU scan failed: %s\n", btbbx_last_error());
 		return -1;
 	}
-	if (first == ~0ULL)
+	if (rc == 0)
 		return -1;
-	int offset = (int)(first >> 32);
-	uint32_t found_lap = (uint32_t)(first >> 8) & 0xffffff;
-	uint8_t ac_errors = (uint8_t)(first & 0xff);
 	if (*pkt_ptr == NULL)
 		*pkt_ptr = btbb_packet_new();
 	/* init_packet, :201-208.  Known-LAP searches store the caller's 32-bit value. */
-	(*pkt_ptr)->LAP = lap == LAP_ANY ? found_lap : lap;
-	(*pkt_ptr)->ac_errors = ac_errors;
+	(*pkt_ptr)->LAP = lap == LAP_ANY ? first.lap : lap;
+	(*pkt_ptr)->ac_errors = first.ac_errors;
 	(*pkt_ptr)->flags = 0;
 	btbb_packet_set_flag(*pkt_ptr, BTBB_WHITENED, 1);
-	return offset;
+	return (int)first.offset;
 }
 
 /* :467-480 */

@@ -1130,6 +1130,56 @@ extern "C" int64_t btbbx_scan_symbols(const char *symbols, uint64_t n_symbols, u
 	return scan_resident(d_words, n_words, search_length, lap, max_ac_errors, hits, cap, 0, q);
 }
 
+// First match of one symbol-per-byte buffer (what btbb_find_ac returns, bluetooth_packet.c:444-464):
+// one pinned staging copy in, pack + scan (atomicMin over offset << 32 | lap << 8 | errors) queued
+// behind it, 8 bytes back, one synchronisation.
+extern "C" int btbbx_find_first_symbols(const char *symbols, uint64_t n_symbols, uint64_t search_length,
+					uint32_t lap, int max_ac_errors, btbbx_hit *first_hit)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!symbols || !first_hit || search_length + 63 > n_symbols || search_length >= (1ULL << 32)) {
+		set_error("btbbx_find_first_symbols: bad argument (search_length + 63 must not exceed n_symbols, search_length < 2^32)");
+		return BTBBX_E_ARG;
+	}
+	if (search_length == 0)
+		return 0;
+	CallScope scope;                                  // private scratch + stream: callers may be concurrent
+	hipStream_t q = scope_stream();
+	const uint64_t n_sym = search_length + 63;            // last symbol the reference reads
+	const uint64_t n_words = (n_sym + 63) / 64;
+	const size_t sym_bytes = (n_sym + 15) & ~15ULL;
+	// Device block: symbols | sentinel for the first-match word | packed words.  The sentinel sits
+	// right behind the symbols so that ONE host-to-device copy from pinned staging brings both in.
+	char *block = (char *)scope_device(sym_bytes + (n_words + 2) * 8 + 16);
+	char *stage = (char *)scope_pinned(sym_bytes + 16);
+	if (!block || !stage)
+		return BTBBX_E_NOMEM;
+	uint8_t *d_sym = (uint8_t *)block;
+	uint64_t *d_first = (uint64_t *)(block + sym_bytes);
+	uint64_t *d_words = d_first + 1;
+	uint64_t first = ~0ULL;
+	memcpy(stage, symbols, n_sym);
+	memcpy(stage + sym_bytes, &first, 8);
+	HIP_TRY(hipMemcpyAsync(d_sym, stage, sym_bytes + 8, hipMemcpyHostToDevice, q));
+	rc = btbbx_pack_device(d_sym, n_sym, d_words, q);
+	if (!rc)
+		rc = btbbx_scan_first_device(d_words, n_words, search_length, lap, max_ac_errors, d_first, q);
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpyAsync(stage + sym_bytes + 8, d_first, 8, hipMemcpyDeviceToHost, q));
+	HIP_TRY(hipStreamSynchronize(q));
+	memcpy(&first, stage + sym_bytes + 8, 8);
+	if (first == ~0ULL)
+		return 0;
+	memset(first_hit, 0, sizeof(*first_hit));
+	first_hit->offset = first >> 32;
+	first_hit->lap = lap == BTBBX_LAP_ANY ? (uint32_t)(first >> 8) & 0xffffff : lap;
+	first_hit->ac_errors = (uint8_t)(first & 0xff);
+	return 1;
+}
+
 // ---- time sharding over the GPUs of one node -------------------------------------
 //
 // The path shards with no exchange step: shard k owns a contiguous, word-aligned range of offsets and

@@ -134,3 +134,79 @@ size_t refint_packet_offsetof(const char *field)
 #undef OFF
 	return (size_t)-1;
 }
+
+/* ---- bounded CPU legs of bench.py's secondary measurements ("kind": "reference") -------------
+ * Natively looped so that Python is not in the timed path; still the unmodified reference code. */
+
+/* BASELINE config 3 on one channel: all known-LAP matches (first-match btbb_find_ac resumed past
+ * every hit) and, per match, what a caller with known UAP / CLK1-6 does with the packet:
+ * btbb_packet_set_data, btbb_decode_header, btbb_decode_payload (bluetooth_packet.c:467-480,
+ * 1198-1297; btbb_decode itself also prints every packet, :1311-1314).  CLK1-6 of a packet found
+ * at offset o is (o / clk_div) & 63 -- the synthetic capture's rule.  Returns the number of
+ * matches; *crc_ok counts payload results of 10 / 1000. */
+size_t refint_known_lap_chain(char *stream, uint64_t n_symbols, uint32_t lap, int max_ac_errors, uint8_t uap,
+			      uint32_t clk_div, uint64_t *crc_ok)
+{
+	size_t n = 0;
+	uint64_t off = 0, good = 0;
+	const uint64_t search_length = n_symbols - 63;
+	btbb_packet *found = NULL;
+	btbb_packet *pkt = btbb_packet_new();
+	while (off < search_length) {
+		uint64_t left = search_length - off, at, avail;
+		int chunk = left > 0x40000000ULL ? 0x40000000 : (int)left;
+		int r = btbb_find_ac(stream + off, chunk, lap, max_ac_errors, &found);
+		if (r < 0) {
+			off += (uint64_t)chunk;
+			continue;
+		}
+		at = off + (uint64_t)r;
+		avail = n_symbols - at;
+		pkt->LAP = lap;
+		pkt->flags = 0;
+		btbb_packet_set_flag(pkt, BTBB_WHITENED, 1);
+		btbb_packet_set_data(pkt, stream + at, avail > MAX_SYMBOLS ? MAX_SYMBOLS : (int)avail, 0,
+				     (uint32_t)(((at / clk_div) & 63) << 1));
+		btbb_packet_set_uap(pkt, uap);
+		btbb_packet_set_flag(pkt, BTBB_CLK6_VALID, 1);
+		if (btbb_header_present(pkt) && btbb_decode_header(pkt)) {
+			int rv = btbb_decode_payload(pkt);
+			good += rv == 10 || rv == 1000;
+		}
+		n++;
+		off = at + 1;
+	}
+	if (found)
+		btbb_packet_unref(found);
+	btbb_packet_unref(pkt);
+	*crc_ok = good;
+	return n;
+}
+
+/* BASELINE config 5: the 64-candidate loop of btbb_uap_from_header (bluetooth_piconet.c:675-690) on
+ * n_packets packets of `stride` symbols each: try_clock + crc_check for every CLK1-6 value.  Returns a
+ * checksum of the results so that nothing is optimised away; table[p * 64 + c] = uap | rv << 8. */
+uint64_t refint_clk6_trials(char *symbols, uint32_t n_packets, uint32_t stride, uint32_t length, uint32_t lap,
+			    uint32_t *table)
+{
+	uint64_t sum = 0;
+	uint32_t p;
+	int c;
+	btbb_packet *pkt = btbb_packet_new();
+	for (p = 0; p < n_packets; p++) {
+		memset(pkt, 0, sizeof(*pkt));
+		pkt->refcount = 1;
+		pkt->LAP = lap;
+		btbb_packet_set_flag(pkt, BTBB_WHITENED, 1);
+		btbb_packet_set_data(pkt, symbols + (size_t)p * stride, (int)length, 0, 0);
+		for (c = 0; c < 64; c++) {
+			uint8_t u = try_clock(c, pkt);
+			int rv = crc_check(c, pkt);
+			if (table)
+				table[(size_t)p * 64 + c] = (uint32_t)u | ((uint32_t)rv << 8);
+			sum = sum * 31 + u + ((uint64_t)rv << 8);
+		}
+	}
+	btbb_packet_unref(pkt);
+	return sum;
+}

@@ -185,6 +185,9 @@ def ref():
         "btbb_uap_from_header": (C.c_int, [vp, vp]),
         "btbb_process_packet": (C.c_int, [vp, vp]),
         "refint_find_all": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, C.c_size_t]),
+        "refint_known_lap_chain": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint8, C.c_uint32,
+                                                C.POINTER(C.c_uint64)]),
+        "refint_clk6_trials": (C.c_uint64, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
         "refint_gen_syndrome": (C.c_uint64, [C.c_uint64]),
         "refint_unfec13": (C.c_int, [vp, vp, C.c_int]),
         "refint_fec23": (C.c_uint16, [C.c_uint16]),

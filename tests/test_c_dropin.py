@@ -82,3 +82,107 @@ def test_c90_caller_runs_like_the_oracle(tmp_path):
     blocks = _capture.pcapng_blocks(_capture.normalize_pcapng(open(prefix + ".pcapng", "rb").read()))
     assert [b[0] for b in blocks] == [0x0A0D0D0A, 1] + [6] * len(want)
     assert b"dropin_caller" in blocks[1][1] and struct.pack("<HH", 0xD340, 12) in blocks[1][1]
+
+
+def _pc_flags(prefix):
+    """`pkg-config --cflags --libs libbtbb` for the scratch prefix -- through pkg-config when the box
+    has one, otherwise by expanding the installed libbtbb.pc the same way."""
+    pcdir = os.path.join(prefix, "lib", "pkgconfig")
+    import shutil
+    if shutil.which("pkg-config"):
+        env = dict(os.environ, PKG_CONFIG_PATH=pcdir)
+        return subprocess.run(["pkg-config", "--cflags", "--libs", "libbtbb"], check=True, capture_output=True,
+                              text=True, env=env).stdout.split()
+    var, fields = {}, {}
+    for line in open(os.path.join(pcdir, "libbtbb.pc")):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        if ":" in line and ("=" not in line or line.index(":") < line.index("=")):
+            k, v = line.split(":", 1)
+            fields[k.strip()] = v.strip()
+        else:
+            k, v = line.split("=", 1)
+            var[k.strip()] = v.strip()
+
+    def expand(v):
+        for _ in range(5):
+            for k, val in var.items():
+                v = v.replace("${%s}" % k, val)
+        return v
+    assert fields["Name"].startswith("libbtbb") and fields["Version"]
+    return (expand(fields["Cflags"]) + " " + expand(fields["Libs"])).split()
+
+
+def _install(tmp_path):
+    prefix = str(tmp_path / "prefix")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "libbtbb_amd", "csrc"), "install", "PREFIX=" + prefix],
+                   check=True, capture_output=True)
+    return prefix
+
+
+def test_install_layout_and_pkg_config_build(tmp_path):
+    """`make install` lays the library out like the reference's cmake install (libbtbb.so.1.0, SONAME
+    and dev links, btbb.h, libbtbb.pc) and the C90 caller builds from the installed files alone with
+    the flags libbtbb.pc gives (lib/libbtbb.pc.in, lib/src/CMakeLists.txt:42-67)."""
+    prefix = _install(tmp_path)
+    lib = os.path.join(prefix, "lib")
+    assert os.path.isfile(os.path.join(lib, "libbtbb.so.1.0")) and not os.path.islink(os.path.join(lib, "libbtbb.so.1.0"))
+    assert os.readlink(os.path.join(lib, "libbtbb.so.1")) == "libbtbb.so.1.0"
+    assert os.readlink(os.path.join(lib, "libbtbb.so")) == "libbtbb.so.1"
+    assert os.path.isfile(os.path.join(prefix, "include", "btbb.h")) and os.path.isfile(os.path.join(prefix, "include", "btbbx.h"))
+    flags = _pc_flags(prefix)
+    assert "-lbtbb" in flags and any(f.startswith("-I") for f in flags)
+    exe = str(tmp_path / "caller_pc")
+    subprocess.run(["gcc", "-std=c90", "-pedantic", "-Wall", "-Werror", SRC, "-o", exe] + flags +
+                   ["-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libbtbb.so.1" in out and "libbtbb_amd" not in out
+    out = subprocess.run(["readelf", "-d", os.path.join(lib, "libbtbb.so.1.0")], capture_output=True, text=True).stdout
+    assert "SONAME" in out and "libbtbb.so.1" in out
+
+
+def _sketch_block():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2."):text.index("## 3.")]
+    block = sec[sec.index("```c") + 4:]
+    return block[:block.index("```")]
+
+
+def _build_sketch(tmp_path):
+    prefix = _install(tmp_path)
+    (tmp_path / "sketch_block.inc").write_text(_sketch_block())
+    exe = str(tmp_path / "sketch")
+    lib = os.path.join(prefix, "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(tmp_path),
+                    os.path.join(ROOT, "tests", "c", "sketch_harness.c"), "-o", exe] + _pc_flags(prefix) +
+                   ["-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True)
+    return exe
+
+
+def test_integration_sketch_compiles(tmp_path):
+    """The reference-side patch printed in INTEGRATION.md section 2 is real code: it compiles (with the
+    three reference-internal names it uses stood in by the harness) and links against the install."""
+    assert "btbbx_find_first_symbols" in _sketch_block()
+    _build_sketch(tmp_path)
+
+
+@pytest.mark.gpu
+def test_integration_sketch_first_match(tmp_path):
+    """...and returns the FIRST access code of a window that holds several (first-match semantics of
+    btbb_find_ac), call after call, exactly like the shipped drop-in and the oracle."""
+    exe = _build_sketch(tmp_path)
+    rng = np.random.default_rng(11)
+    sym = rng.integers(0, 2, 30000, dtype=np.uint8)
+    for k, pos in enumerate((700, 701 + 64, 5000, 5200, 12345, 29000)):       # dense and sparse neighbours
+        sym[pos:pos + 64] = synth.bits_lsb(synth.syncword(0x100000 + 77 * k), 64)
+    path = str(tmp_path / "win.sym")
+    sym.tofile(path)
+    res = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = [int(l.split("=")[1]) for l in res.stdout.splitlines() if l.startswith("AC ")]
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    want = [o for (o, l, e) in _libs.orc_find_all(np.ascontiguousarray(sym), len(sym) - 63, _libs.LAP_ANY, 2)]
+    assert got == want and len(got) >= 6
+    assert "bad=0" in res.stdout
