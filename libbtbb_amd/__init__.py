@@ -24,7 +24,7 @@ except Exception:  # pragma: no cover - torch is optional for the C library
 from . import synth  # noqa: F401  (host-side synthetic traffic, numpy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbtbb_amd.so")
+LIB_PATH = os.environ.get("LIBBTBB_AMD_SO") or os.path.join(_HERE, "libbtbb_amd.so")   # the override is for kernel A/B runs
 
 LAP_ANY = 0xFFFFFFFF
 PKT_WORDS = 50

@@ -20,29 +20,36 @@
 // ---- scan kernel geometry ---------------------------------------------------------
 #define SCAN_THREADS   1024                // one workgroup per CU, 16 wave64
 #define SCAN_WAVES     (SCAN_THREADS / 64)
-#define TABA_BITS      13                  // window bits 32..44
-#define TABB_BITS      12                  // window bits 45..56
+#define TABA_FIRST     34                  // the (64,30) code is systematic: window bits 0..33 are their own syndrome,
+#define TABA_BITS      11                  //   only bits 34..56 need tables: 34..44 (tabA) and
+#define TABB_BITS      12                  //   45..56 (tabB, with the class-0 barker / PN constant folded in)
 #define BITMAP_BITS    19                  // projection width of the candidate bitmap
 #define QRING          128                 // per-wave candidate ring (entries; it never holds more than 127)
+#ifndef SCAN_UNROLL
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
+#endif
 #define PARK_SLOTS     2                   // private candidate slots per lane
 #define CAND_BYTES     12                  // a parked candidate: position code + its 64-bit window
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
 // probe needs no address adds.
 #define LDS_TABB_WORDS   (1u << TABB_BITS)            // 4096 u32  = 16 KiB
-#define LDS_TABA_WORDS   (1u << TABA_BITS)            // 8192 u32  = 32 KiB
+#define LDS_TABA_WORDS   (1u << TABA_BITS)            // 2048 u32  =  8 KiB
 #define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 16384 u32 = 64 KiB
 #define LDS_OFF_TABB     0u
 #define LDS_OFF_TABA     (LDS_OFF_TABB + 4u * LDS_TABB_WORDS)
 #define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
 #define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING candidates
 #define LDS_OFF_PARK     (LDS_OFF_QUEUE + CAND_BYTES * SCAN_WAVES * QRING)    // 16 x 64 x PARK_SLOTS candidates
-#define SCAN_LDS_BYTES   (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // = 160 KiB, all of it
+#define LDS_OFF_ZERO     (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // one dword that stays 0
+#define SCAN_LDS_BYTES   (LDS_OFF_ZERO + 16u)                                           // = 136 KiB
+#ifndef SCAN_READ_MODE
+#define SCAN_READ_MODE   0                 // how idle lanes sit out a table read: 0 = exec mask, 1 = parked address
+#endif
 
 // ---- device-side table bundle -----------------------------------------------------
 struct ScanTables {
-	const uint32_t *tabA;      // [8192]   low-32 syndrome of window bits 32..44
+	const uint32_t *tabA;      // [2048]   low-32 syndrome of window bits 34..44
 	const uint32_t *tabB;      // [4096]   low-32 syndrome of bits 45..56 ^ class-0 constant
 	const uint32_t *bitmap;    // 2^BITMAP_BITS-bit set: projection of acceptable syndromes
 	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)

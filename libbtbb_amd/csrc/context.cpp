@@ -292,7 +292,7 @@ static int upload_tables(int max_ac_errors)
 		uint64_t s = 0;
 		for (int i = 0; i < TABA_BITS; i++)
 			if ((v >> i) & 1)
-				s ^= t.col[32 + i];
+				s ^= t.col[TABA_FIRST + i];
 		tabA[v] = (uint32_t)s;
 	}
 	uint64_t kclass[2];
@@ -302,7 +302,7 @@ static int upload_tables(int max_ac_errors)
 		uint64_t s = kclass[0];
 		for (int i = 0; i < TABB_BITS; i++)
 			if ((v >> i) & 1)
-				s ^= t.col[32 + TABA_BITS + i];
+				s ^= t.col[TABA_FIRST + TABA_BITS + i];
 		tabB[v] = (uint32_t)s;
 	}
 

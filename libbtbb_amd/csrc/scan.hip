@@ -22,7 +22,7 @@
 // Known LAP: a bit-sliced mismatch count of the top 12 sync-word bits prunes (1.9 % left for
 // max_ac_errors = 2), the survivors get the full popcount(window ^ syncword) of :433.
 //
-// One persistent 1024-thread workgroup per CU (16 wave64) keeps the 112 KiB of tables in
+// One persistent 1024-thread workgroup per CU (16 wave64) keeps the 88 KiB of tables in
 // LDS; workgroups stride over 64 KiB-bit tiles of the stream(s).  Pure integer work, no
 // MFMA; bound by VALU/LDS issue, not by HBM (see DESIGN.md for the roofline accounting).
 #include <stdlib.h>
@@ -102,8 +102,8 @@ __device__ __forceinline__ bool verify_lap_any(const ScanArgs &a, uint64_t w, ui
 	// byte tables in global memory cost eight divergent loads per candidate, which is what bounded
 	// the scan for tables built for three or more errors.)
 	const uint64_t low = w & LOW57;
-	const uint32_t s_lo = (uint32_t)low ^ lds_ld(LDS_OFF_TABA + (((uint32_t)(low >> 32) & ((1u << TABA_BITS) - 1)) << 2))
-			      ^ lds_ld(LDS_OFF_TABB + ((uint32_t)(low >> (32 + TABA_BITS)) << 2)) ^ (cls ? a.t.kdiff : 0u);
+	const uint32_t s_lo = (uint32_t)low ^ lds_ld(LDS_OFF_TABA + (((uint32_t)(low >> TABA_FIRST) & ((1u << TABA_BITS) - 1)) << 2))
+			      ^ lds_ld(LDS_OFF_TABB + ((uint32_t)(low >> (TABA_FIRST + TABA_BITS)) << 2)) ^ (cls ? a.t.kdiff : 0u);
 	const uint32_t s_hi = ((uint32_t)(a.t.kclass[cls] >> 32) ^ (__popcll(low & a.t.hi_mask[0]) & 1)
 			       ^ ((__popcll(low & a.t.hi_mask[1]) & 1) << 1)) & 3;
 	const uint64_t syn = ((uint64_t)s_hi << 32) | s_lo;
@@ -177,8 +177,8 @@ __device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t vali
 	cls = ~(twos | fours);
 }
 
-// One survivor costs about 19 VALU + 3 DS instructions:
-//   syndrome_low32 = w[31:0] ^ tabA[w[44:32]] ^ tabB[w[56:45]] ^ (class ? kdiff : 0)
+// One survivor costs about 17 VALU + 3 DS instructions:
+//   syndrome_low32 = w[31:0] ^ tabA[w[44:34]] ^ tabB[w[56:45]] ^ (class ? kdiff : 0)
 // for the window w at offset p of the dword triple (e0,e1,e2), then a probe of the candidate
 // bitmap with its low 19 bits.  The stages are separate functions so that the survivor loop
 // can issue the LDS reads of its two chains back to back, each under the exec mask of the
@@ -194,8 +194,9 @@ __device__ __forceinline__ Probe probe_addr(uint32_t e0, uint32_t e1, uint32_t e
 	Probe r;
 	const uint32_t wlo = alignbit(e1, e0, p);
 	const uint32_t whi = alignbit(e2, e1, p);
-	r.offA = (whi << 2) & (((1u << TABA_BITS) - 1) << 2);
-	r.offB = (whi >> (TABA_BITS - 2)) & (((1u << TABB_BITS) - 1) << 2);
+	// whi = window bits 32..63: bits 34..44 sit at 2..12 -- already the byte offset of a u32 entry
+	r.offA = whi & (((1u << TABA_BITS) - 1) << 2);
+	r.offB = (whi >> (TABA_FIRST - 32 + TABA_BITS - 2)) & (((1u << TABB_BITS) - 1) << 2);
 	const uint32_t cmask = (uint32_t)__builtin_amdgcn_sbfe(cls, p, 1);     // 0 or ~0
 	r.x = BITOP3(cmask, kdiff, wlo, 0x6a);                                 // wlo ^ (cmask & kdiff)
 	return r;
@@ -246,6 +247,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
 		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
 		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
+		if (tid == 0)
+			lds_st(LDS_OFF_ZERO, 0u);
 	}
 	__syncthreads();
 
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		pend = 0;
 	};
 	auto push_hits = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t lap, uint32_t nerr) {
-		if (a.first || VARIANT == 7) {            // first-match mode (or ablation 7): hits go out one by one
+		if (a.first) {                            // first-match mode: atomicMin, hits go out one by one
 			if (hit)
 				emit_hit(a, stream, offset, lap, nerr);
 			return;
@@ -345,10 +348,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			const uint32_t code = lds_ld(o);
 			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
 			offset = code_word(code, stream) * 64 + (code & 63);
-			if (VARIANT != 5)                                  // ablation: park + compact, no verification
-				hit = verify_lap_any(a, w, lap, nerr);
-			else
-				hit = w == 0x123456789abcdefULL;
+			hit = verify_lap_any(a, w, lap, nerr);
 		}
 		push_hits(hit, stream, offset, lap, nerr);
 		q_head += n;
@@ -455,17 +455,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			}
 			barker32(d[u][1], d[u][2], validA, m[u][0], cls[u][0]);    // offsets 0..31: window bits 57.. in d1:d2
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls[u][1]);    // offsets 32..63
-			if (VARIANT == 1) {      // ablation: pre-filter only
-				if (__popc(m[u][0]) + __popc(m[u][1]) == 33)
-					park(((it + u) << 12) | (lane << 6), d[u][0], d[u][1]);
-				m[u][0] = m[u][1] = 0;
-			}
 		}
 
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
 		// survivor of every 32-offset half in flight (2 * UNROLL independent chains).  The LDS
-		// reads of all chains are issued before any result is used, each under the exec mask
-		// of the lanes that really have a survivor there.
+		// reads of all chains are issued before any result is used.  Lanes without a survivor in a
+		// chain do not take part in its reads: SCAN_READ_MODE 0 switches them off in the exec mask
+		// (a v_cmp, an s_and_saveexec, a skip branch and an s_or per group of reads), mode 1 parks them
+		// on one fixed address each (a v_cndmask per read; equal addresses are broadcast, so parked
+		// lanes cost no bank conflicts and the scalar instructions disappear).
 		for (;;) {
 			uint32_t any = 0;
 #pragma unroll
@@ -481,11 +479,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int h = 0; h < 2; h++) {
 					p[u][h] = lowest_bit(m[u][h]);
 					q[u][h] = probe_addr(d[u][h], d[u][h + 1], d[u][h + 2], cls[u][h], kdiff, p[u][h]);
-					t1[u][h] = t2[u][h] = bw[u][h] = 0;
-					if (VARIANT != 2 && m[u][h]) {
+#if SCAN_READ_MODE == 1
+					t1[u][h] = lds_ld(LDS_OFF_TABA + (m[u][h] ? q[u][h].offA : 0u));
+					t2[u][h] = lds_ld(LDS_OFF_TABB + (m[u][h] ? q[u][h].offB : 0u));
+#else
+					t1[u][h] = t2[u][h] = 0;
+					if (m[u][h]) {
 						t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
 						t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
 					}
+#endif
 				}
 			uint32_t anybit = 0, bit[UNROLL][2], i2[UNROLL][2];
 #pragma unroll
@@ -493,22 +496,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
+					bw[u][h] = 0;
 					if (VARIANT == 8) {
 						// tables for >= 4 errors: the LDS bitmap passes more than half of the survivors,
 						// so probe the 2^26-bit bitmap in L2 / Infinity Cache right here instead
 						i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
 						if (m[u][h])
 							bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
-					} else if (VARIANT != 2 && VARIANT != 3 && m[u][h])
-						bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
+					} else {
+#if SCAN_READ_MODE == 1
+						// parked lanes read the spare zero word behind the tables: no candidate
+						bw[u][h] = lds_ld(LDS_OFF_BITMAP + (m[u][h] ? bitmap_off(proj[u][h]) : LDS_OFF_ZERO - LDS_OFF_BITMAP));
+#else
+						if (m[u][h])
+							bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
+#endif
+					}
 				}
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
-					if (VARIANT == 2 || VARIANT == 3)          // ablation: no bitmap probe
-						bit[u][h] = m[u][h] && proj[u][h] == 0x12345678u;
-					else if (VARIANT == 8)
+					if (VARIANT == 8)
 						bit[u][h] = (bw[u][h] >> (i2[u][h] & 31)) & 1;
 					else
 						bit[u][h] = (bw[u][h] >> (proj[u][h] & 31)) & 1;    // bw == 0 without a survivor
@@ -517,8 +526,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 						const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
 						bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
 					}
-					if (VARIANT == 4)                          // ablation: full probe, no candidates
-						bit[u][h] &= proj[u][h] == 0x12345678u;
 					anybit |= bit[u][h];
 					m[u][h] &= m[u][h] - 1;
 				}
@@ -875,30 +882,15 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 			return BTBBX_E_ARG;
 		}
 		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
-		// 2^26-bit bitmap in L2 inside the survivor loop (after / instead of the LDS one)
+		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one)
 		int run_variant = 0;
 		if (c.scan.bitmap2 && c.table_errors >= 4)
 			run_variant = c.table_errors == 4 ? 9 : 8;
-#ifdef BTBBX_ABLATION
-		// profiling builds only (tools/): kernels with parts of the work removed.  They return WRONG hit
-		// lists by design, so the shipped library does not contain them.
-		if (const char *v = getenv("BTBBX_SCAN_VARIANT"))
-			if (atoi(v) > 0)
-				run_variant = atoi(v);
-#endif
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
 		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
 		switch (run_variant) {
-#ifdef BTBBX_ABLATION
-		case 1: LAUNCH_VARIANT(1); break;
-		case 2: LAUNCH_VARIANT(2); break;
-		case 3: LAUNCH_VARIANT(3); break;
-		case 4: LAUNCH_VARIANT(4); break;
-		case 5: LAUNCH_VARIANT(5); break;
-		case 7: LAUNCH_VARIANT(7); break;
-#endif
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
 		default: LAUNCH_VARIANT(0); break;
