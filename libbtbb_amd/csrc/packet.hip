@@ -71,12 +71,13 @@ __device__ __forceinline__ uint32_t wh_start_const(uint32_t clock, uint32_t skip
 }
 
 // Per-workgroup LDS copies of the small tables the decoders index with per-lane values inside
-// their inner loops (whitening slice, CRC byte step, FEC 2/3 parity and correction): a DS read
-// instead of a divergent constant-memory load or a 10-step loop.  2.1 KiB, built by
+// their inner loops (whitening slice, CRC byte / word step, FEC 2/3 parity and correction): a DS read
+// instead of a divergent constant-memory load or a 10-step loop.  3.6 KiB, built by
 // chain_lds_init() at kernel start.
 struct ChainLds {
 	uint32_t wh32[128];        // 32 whitening bits from phase idx (idx <= 126)
 	uint16_t crc[256];         // crc_byte(0, x): one byte through the reflected CRC-CCITT register
+	uint16_t crc_z[3][256];    // the same followed by 1, 2, 3 zero bytes (slicing: four bytes per step)
 	uint8_t  par23[1024];      // FEC 2/3 parity of 10 data bits
 	int8_t   fix23[32];
 	uint8_t  whiten_idx[64];
@@ -111,6 +112,17 @@ __device__ __forceinline__ uint32_t crc_byte_calc(uint32_t crc, uint32_t byte)
 __device__ __forceinline__ uint32_t crc_byte(uint32_t crc, uint32_t byte)
 {
 	return (crc >> 8) ^ g_lds.crc[(crc ^ byte) & 0xff];
+}
+
+// Four bytes per step.  The register update is linear over GF(2) and the register is 16 bits wide, so
+// after the bytes b0..b3 (b0 first) it holds
+//     Z3[(crc ^ b0) & 0xff] ^ Z2[(crc >> 8) ^ b1] ^ Z1[b2] ^ Z0[b3],   Zk[x] = byte x followed by k zero bytes:
+// four INDEPENDENT table reads instead of a chain of four dependent ones (the CRC over the 187 / 343 bytes
+// of a DH3 / DH5 trial is what the brute force spends its time in, and it was bound by that latency).
+__device__ __forceinline__ uint32_t crc_word(uint32_t crc, uint32_t w)
+{
+	const uint32_t x = crc ^ w;
+	return g_lds.crc_z[2][x & 0xff] ^ g_lds.crc_z[1][(x >> 8) & 0xff] ^ g_lds.crc_z[0][(w >> 16) & 0xff] ^ g_lds.crc[w >> 24];
 }
 
 __device__ __forceinline__ uint32_t crc_seed(uint32_t uap) { return rev8(uap & 0xff) << 8; }
@@ -165,8 +177,14 @@ __device__ void chain_lds_init()
 {
 	for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
 		g_lds.wh32[i] = (uint32_t)wh_bits_const(i < 127 ? i : 0, 32);
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
-		g_lds.crc[i] = (uint16_t)crc_byte_calc(0, i);
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+		uint32_t c = crc_byte_calc(0, i);
+		g_lds.crc[i] = (uint16_t)c;
+		for (int k = 0; k < 3; k++) {
+			c = crc_byte_calc(c, 0);
+			g_lds.crc_z[k][i] = (uint16_t)c;
+		}
+	}
 	for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
 		uint32_t par = 0;
 		for (int b = 0; b < 10; b++)
@@ -218,12 +236,16 @@ struct Sink {
 	__device__ Sink(uint32_t seed, uint64_t *o) : crc(seed), out(o) {}
 	__device__ __forceinline__ void push(uint64_t bits, uint32_t n)   // n <= 32
 	{
-		acc |= bits << nacc;
-		nacc += n;
-		while (nacc >= 8) {
-			crc = crc_byte(crc, (uint32_t)acc & 0xff);
-			acc >>= 8;
-			nacc -= 8;
+		if (n == 32 && nacc == 0) {                                   // whole word on a byte boundary
+			crc = crc_word(crc, (uint32_t)bits);
+		} else {
+			acc |= bits << nacc;
+			nacc += n;
+			while (nacc >= 8) {
+				crc = crc_byte(crc, (uint32_t)acc & 0xff);
+				acc >>= 8;
+				nacc -= 8;
+			}
 		}
 		if (WRITE) {
 			oacc |= bits << onacc;
@@ -671,6 +693,120 @@ __global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, co
 	t.type = (uint8_t)s.type;
 	t.rv = (int16_t)rv;
 	trials[(uint64_t)pkt * 64 + clock] = t;
+}
+
+// The throughput shape for large batches (BASELINE config 5: 10^6 detected packets).  Wrong candidate
+// clocks turn the 4 type bits into noise, so the 64 trials of one packet spread over all sixteen
+// decoders: in trials_kernel a wave executes up to nine different paths one after the other with a
+// few lanes each, and the long ones (the CRC over 187 / 343 bytes of DH3 / DH5) run at ~6 % lane use.
+// Here a workgroup takes TB_PACKETS packets = 64 x TB_PACKETS trials:
+//   1. try_clock for every trial, lane = clock (dense, one path): UAP and type;
+//   2. a counting sort of the trial numbers by type, in LDS;
+//   3. crc_check over the sorted list: a wave's 64 consecutive entries are trials of ONE type (except
+//      at the few type boundaries), so every decoder runs with full lanes;
+//   4. results back in (packet, clock) order, coalesced.
+// Trials are independent of each other (the one cross-trial dependency of the reference, EV4 reading
+// the llid / flow a previous trial left, cannot change a result -- see do_EV4), so the order in which
+// they run is free.
+#ifndef TB_PACKETS
+#define TB_PACKETS 16          /* measured: 64 -> 4.09 ms, 32 -> 2.49, 16 -> 2.13, 8 -> 4.20 per 2^20 packets (occupancy vs bucket size) */
+#endif
+#define TB_TRIALS  (TB_PACKETS * 64)
+__global__ __launch_bounds__(256) void trials_bucket_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+							     uint32_t n_packets, btbbx_trial *trials)
+{
+	// 51 words per row: in step 3 the lanes of a wave read the same word of 64 DIFFERENT packets, and an
+	// odd pitch (in 8-byte units) puts those on 32 different bank pairs (with 52 it was 8-way conflicts)
+	__shared__ uint64_t pk[TB_PACKETS][BTBBX_PKT_WORDS + 1];
+	__shared__ btbbx_pkt_in pin[TB_PACKETS];
+	__shared__ uint32_t hdr_ut[TB_PACKETS];         // per packet: U(header) | type << 8 | FEC 1/3 ok << 16
+	__shared__ uint16_t clk_ut[64];                 // per clock:  U(whitening bits) | their type bits << 8
+	__shared__ uint16_t order[TB_TRIALS];           // trial numbers, grouped by type
+	__shared__ uint16_t t_slot[TB_TRIALS];          // rank of a trial among the trials of its type
+	__shared__ uint8_t t_uap[TB_TRIALS], t_type[TB_TRIALS], t_ret[TB_TRIALS];
+	__shared__ int16_t t_rv[TB_TRIALS];
+	__shared__ uint32_t type_count[16], type_base[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63;
+	const uint32_t first = blockIdx.x * TB_PACKETS;
+	const uint32_t mine = n_packets - first < TB_PACKETS ? n_packets - first : TB_PACKETS;
+
+	for (uint32_t i = tid; i < TB_PACKETS * (BTBBX_PKT_WORDS + 1); i += 256) {
+		const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
+		pk[p][w] = (p < mine && w < BTBBX_PKT_WORDS) ? packets[(uint64_t)(first + p) * BTBBX_PKT_WORDS + w] : 0;
+	}
+	if (tid < mine)
+		pin[tid] = in[first + tid];
+	if (tid < 16)
+		type_count[tid] = 0;
+	chain_lds_init();                                       // ends with a barrier
+
+	// 1a. once per packet (lane = packet) and once per clock (lane = clock): uap_from_hec (:693-705) and the
+	// type field are GF(2)-linear in the 18 header bits and unwhitening XORs a clock-dependent constant onto
+	// them, so try_clock(c) = U(header) ^ U(whitening bits of c) -- as in uap_table_kernel
+	if (tid < mine) {
+		uint32_t dis;
+		const uint32_t hdr = header_fec13(pk[tid], dis);
+		hdr_ut[tid] = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
+	} else if (tid >= 64 && tid < 128) {
+		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
+		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
+	}
+	__syncthreads();
+	// 1b. every trial: UAP, type, and its rank among the trials of that type (one LDS atomic)
+	const uint32_t total = mine * 64;
+	for (uint32_t i = tid; i < total; i += 256) {
+		const uint32_t p = i >> 6;
+		const uint32_t h = hdr_ut[p];
+		uint32_t uap = pin[p].uap, type = pin[p].type, ret = 0;     // FEC 1/3 failure: nothing changes
+		if (h & 0x10000u) {
+			const uint32_t v = (h ^ ((pin[p].flags & F_WHITENED) ? clk_ut[lane] : 0u)) & 0xffff;
+			uap = ret = v & 0xff;
+			type = v >> 8;
+		}
+		t_uap[i] = (uint8_t)uap;
+		t_type[i] = (uint8_t)type;
+		t_ret[i] = (uint8_t)ret;
+		t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (uint32_t t = 0; t < 16; t++) {
+			type_base[t] = run;
+			run += type_count[t];
+		}
+	}
+	__syncthreads();
+	// 2. the trial numbers in type order
+	for (uint32_t i = tid; i < total; i += 256)
+		order[type_base[t_type[i] & 15] + t_slot[i]] = (uint16_t)i;
+	__syncthreads();
+	// 3. crc_check in type order: a wave's 64 consecutive entries are (nearly always) one decoder
+	for (uint32_t k = tid; k < total; k += 256) {
+		const uint32_t i = order[k], p = i >> 6, clock = i & 63;
+		PState s;
+		s.w = pk[p];
+		s.length = (int)pin[p].length;
+		s.flags = pin[p].flags;
+		s.uap = t_uap[i];
+		s.type = t_type[i];
+		s.llid = pin[p].llid;
+		s.flow = pin[p].flow;
+		s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
+		s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
+		s.out = nullptr;
+		s.written = 0;
+		t_rv[i] = (int16_t)do_crc_check<false>(s, clock);
+	}
+	__syncthreads();
+	// 4. out, in (packet, clock) order
+	for (uint32_t i = tid; i < total; i += 256) {
+		btbbx_trial t;
+		t.uap = t_ret[i];
+		t.type = t_type[i];
+		t.rv = t_rv[i];
+		trials[(uint64_t)first * 64 + i] = t;
+	}
 }
 
 // Small batches (a handful of packets from a live receiver): one workgroup per (packet, clock),
@@ -1198,9 +1334,12 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 	if (n_packets <= 256)        // latency shape while 64 n waves are only a few rounds over the chip
 		hipLaunchKernelGGL(trials_wide_kernel, dim3(n_packets * 64), dim3(64), 0, (hipStream_t)hip_stream,
 				   d_packets, d_in, n_packets, d_trials);
-	else
+	else if (n_packets < 4096)   // a wave per packet still fills the chip
 		hipLaunchKernelGGL(trials_kernel, dim3((n_packets + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
 				   d_packets, d_in, n_packets, d_trials);
+	else                         // trials bucketed by packet type: every decoder runs with full lanes
+		hipLaunchKernelGGL(trials_bucket_kernel, dim3((n_packets + TB_PACKETS - 1) / TB_PACKETS), dim3(256), 0,
+				   (hipStream_t)hip_stream, d_packets, d_in, n_packets, d_trials);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
