@@ -307,3 +307,113 @@ def test_config4_full_size_million_packets():
             tt = trials[i, clock]
             assert (int(tt["uap"]), int(tt["type"]), int(tt["rv"])) == (u, p.contents.packet_type, rv), (i, clock)
         orc.orc_packet_free(p)
+
+
+@pytest.mark.gpu
+def test_config2_full_size_known_lap_chain_79_channels_8gib():
+    """BASELINE config 2 at the size one GPU holds (79 channel streams, 8 GiB packed, one launch per
+    stage): known-LAP find_ac -> sort -> gather -> header + payload decode of EVERY detected packet.
+    The capture is 2^14 words per channel of real DM1 / DH1 / DM3 / FHS traffic of one piconet (built
+    on the host, CLK1-6 = slot number) tiled along time on the device, so everything is known by
+    construction: every injected packet is found exactly once per tile with 0 errors, the list is
+    strictly increasing in (stream, offset), every header decodes to the type / LT_ADDR / flags that
+    were sent with the piconet's UAP, every payload CRC holds, and the first tile equals the oracle
+    packet by packet."""
+    import torch
+    import libbtbb_amd as bt
+    bt.init(2)
+    lib = bt.lib()
+    uap = 0x47
+    nch, wpc0 = 79, 1 << 14
+    tiles = ((8 << 30) // 8 // nch) // wpc0                          # 829 tiles: 8 GiB in all
+    rng = np.random.default_rng(_libs.seed(2026))
+    base = synth.noise_words(777, 0, nch * wpc0).reshape(nch, wpc0).copy()
+    types = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_FHS]
+    slots = wpc0 * 64 // 4096 - 1
+    sent = {}
+    for ch in range(nch):
+        symc = synth.unpack_bits(base[ch])
+        for k in range(slots):
+            t_ = types[(k + ch) % 4]
+            body = rng.integers(0, 256, int(rng.integers(1, 17)), dtype=np.uint8).tobytes()
+            p = synth.build_packet(LAP, uap, k & 63, t_, lt_addr=1 + k % 7, flags=k % 8, body=body,
+                                   fhs_bits=synth.fhs_payload(LAP, uap, 0x1234, k, rng))
+            pos = k * 4096 + 100 + int(rng.integers(0, 64))
+            symc[pos:pos + len(p)] = p
+            sent[(ch, pos)] = (t_, 1 + k % 7, k % 8)
+        base[ch] = synth.pack_bits(symc)
+    wpc = wpc0 * tiles
+    d = torch.from_numpy(base.view(np.int64)).cuda().repeat(1, tiles).contiguous()
+    nbits = wpc * 64 - 63
+    want_n = nch * slots * tiles
+    cap = want_n + 4096
+    hits = torch.zeros(cap * 2, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bt.check(lib.btbbx_scan_device(d.data_ptr(), wpc, wpc, nch, nbits, LAP, 2, hits.data_ptr(), cap, cnt.data_ptr(), None))
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    assert n == want_n                                           # every packet, every tile; no chance match at <= 2 errors
+    bt.check(lib.btbbx_sort_hits_device(hits.data_ptr(), n, None))
+    rec = hits[: 2 * n].view(n, 2)
+    off, meta = rec[:, 0], rec[:, 1]                             # offset | lap, errors, stream
+    stream = (meta >> 48) & 0xFFFF
+    key = stream * (wpc * 64) + off
+    assert bool((key[1:] > key[:-1]).all())
+    assert bool(((meta & 0xFFFFFF) == LAP).all()) and bool((((meta >> 32) & 0xFF) == 0).all())
+    # offsets are the host positions repeated every wpc0 * 64 symbols
+    pos0 = torch.tensor(sorted(sent), dtype=torch.int64, device="cuda")       # (channel, position) of tile 0
+    per_ch = slots * tiles
+    assert bool((stream.view(nch, per_ch) == torch.arange(nch, device="cuda").view(nch, 1)).all())
+    local = (off % (wpc0 * 64)).view(nch, tiles, slots)
+    assert bool((local == pos0[:, 1].view(nch, 1, slots)).all())
+    # gather + decode, all packets
+    pk = torch.zeros(n * 50, dtype=torch.int64, device="cuda")
+    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    bt.check(lib.btbbx_gather_packets_device(d.data_ptr(), wpc, wpc, hits.data_ptr(), n, 3125, pk.data_ptr(), ln.data_ptr(), None))
+    pin = torch.zeros(n, 4, dtype=torch.int32, device="cuda")
+    pin[:, 0] = ln
+    pin[:, 1] = ((off >> 12) & 63).to(torch.int32)
+    pin[:, 2] = (1 << 0) | (1 << 2) | (1 << 4)
+    pin[:, 3] = uap
+    pout = torch.zeros(n * bt.PKTOUT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    bt.check(lib.btbbx_decode_device(pk.data_ptr(), pin.data_ptr(), n, pout.data_ptr(), None))
+    torch.cuda.synchronize()
+    o32 = pout.view(torch.int32).view(n, bt.PKTOUT_DTYPE.itemsize // 4)
+    names = bt.PKTOUT_DTYPE.names
+    f = {name: bt.PKTOUT_DTYPE.fields[name][1] for name in names}
+    header_rv, payload_rv = o32[:, f["header_rv"] // 4], o32[:, f["payload_rv"] // 4]
+    b8 = pout.view(n, bt.PKTOUT_DTYPE.itemsize)
+    typ, lt, fl, pu = (b8[:, f[x]] for x in ("type", "lt_addr", "hdr_flags", "uap"))
+    assert bool((header_rv == 1).all()) and bool((pu == uap).all())
+    exp = torch.tensor([sent[k_] for k_ in sorted(sent)], dtype=torch.uint8, device="cuda").view(nch, 1, slots, 3)
+    got = torch.stack([typ, lt, fl], dim=1).view(nch, tiles, slots, 3)
+    assert bool((got == exp).all())
+    assert bool(((payload_rv == 10) | (payload_rv == 1000)).all())              # every CRC holds (FHS reports 1000)
+    assert bool((payload_rv.view(nch, tiles, slots)[:, :, :] == payload_rv.view(nch, tiles, slots)[:, :1, :]).all())
+    # the first tile against the oracle, packet by packet (a sample of the channels)
+    orc = _libs.oracle()
+    orc.orc_init(2)
+    res0 = pout.view(n, -1)
+    first_rows = (torch.arange(nch, device="cuda").view(nch, 1) * per_ch + torch.arange(slots, device="cuda").view(1, slots)).view(-1)
+    r0 = res0[first_rows].cpu().numpy().view(bt.PKTOUT_DTYPE).reshape(nch, slots)
+    for ch in (0, 17, 78):
+        symc = np.ascontiguousarray(synth.unpack_bits(base[ch]))
+        want = _libs.orc_find_all(symc, wpc0 * 64 - 63, LAP, 2)
+        assert [w[0] for w in want] == [p_ for (c_, p_) in sorted(sent) if c_ == ch]
+        for k in range(0, slots, 7):
+            o = want[k][0]
+            s = np.ascontiguousarray(symc[o:o + 3125])
+            p = orc.orc_packet_new()
+            orc.orc_packet_init_found(p, LAP, 0)
+            orc.orc_packet_set_data(p, _libs.ptr(s), len(s), ch, ((o >> 12) & 63) << 1)
+            p.contents.UAP = uap
+            orc.orc_packet_set_flag(p, 2, 1)
+            orc.orc_packet_set_flag(p, 4, 1)
+            assert orc.orc_decode_header(p) == 1
+            rv = orc.orc_decode_payload(p)
+            st = p.contents
+            g = r0[ch, k]
+            assert (int(g["payload_rv"]), int(g["type"]), int(g["lt_addr"]), int(g["hdr_flags"]), int(g["hec"]),
+                    int(g["payload_length"])) == (rv, st.packet_type, st.packet_lt_addr, st.packet_flags, st.packet_hec,
+                                                  st.payload_length), (ch, k)
+            orc.orc_packet_free(p)
