@@ -14,8 +14,9 @@
  *
  * Provided beyond the packet half: the piconet half including hop reversal
  * (btbb_init_hop_reversal / btbb_winnow, GPU candidate lists) and the BR/EDR pcap / pcapng
- * writers.  NOT provided: the Bluetooth LE half (lell_* and the LE capture writers) -- a
- * caller that uses it keeps the reference's objects for those symbols.
+ * writers.  NOT provided: the Bluetooth LE half (lell_* and the LE capture writers) -- the
+ * library exports those symbols only to abort with a diagnostic when one is called; a caller
+ * that uses LE keeps the reference's objects for them.
  *
  * Threads: every call that goes to the GPU leases private staging memory and a private
  * stream, so different threads may work on DIFFERENT packets / piconets at the same time

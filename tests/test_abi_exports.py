@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -110,3 +111,23 @@ def test_headers_are_valid_c90_and_cxx(tmp_path):
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")], check=True)
     text = open(os.path.join(inc, "btbbx.h")).read() + open(os.path.join(inc, "btbb.h")).read()
     assert "torch" not in text and "hip/" not in text
+
+
+def test_le_symbols_bind_and_fail_loudly():
+    """The LE half of libbtbb's ABI (lell_*, reference btbb.h:229-281) is outside this library, but the
+    SONAME is libbtbb's: every LE symbol is exported so that a program linked against the reference binds,
+    and calling one aborts at once with a diagnostic instead of dying in a lazy symbol lookup."""
+    import libbtbb_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", libbtbb_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    have = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    want = {"lell_allocate_and_decode", "lell_packet_new", "lell_packet_ref", "lell_packet_unref",
+            "lell_get_access_address", "lell_get_access_address_offenses", "lell_packet_is_data",
+            "lell_get_channel_index", "lell_get_channel_k", "lell_get_adv_type_str", "lell_print",
+            "lell_pcapng_create_file", "lell_pcapng_append_packet", "lell_pcapng_record_connect_req",
+            "lell_pcapng_close", "lell_pcap_create_file", "lell_pcap_ppi_create_file", "lell_pcap_append_packet",
+            "lell_pcap_append_ppi_packet", "lell_pcap_close"}
+    assert want <= have
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import libbtbb_amd as bt; "
+            "bt.lib(); ctypes.CDLL(bt.LIB_PATH).lell_packet_new()" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "lell_packet_new" in r.stderr and "not" in r.stderr
