@@ -554,6 +554,310 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	flush_hits();
 }
 
+#if SCAN_DESIGN == 1
+// ---- LAP_ANY, word-queue variant ---------------------------------------------------------------------
+// The lock-step loop above keeps < 50 % of its lanes busy (a lane has 4 +- 1.9 survivors per 32 offsets and
+// the loop runs until the slowest of 256 chains is done).  Here the pre-filter of a tile only WRITES what it
+// found -- one 32-byte record per stream word: survivor and class masks of both 32-offset halves and the
+// four stream dwords, two ds_write_b128 per lane, no compaction -- into a per-wave ring in LDS, and a second
+// loop keeps two chains per lane (slot 0: a lower half, slot 1: an upper half) and hands every lane whose
+// chain is used up the next queued one, in ballot-rank order, every WQ_ROUND passes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u4_t;
+#ifndef WQ_ROUND
+#define WQ_ROUND 2
+#endif
+
+template <int VARIANT>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_wq_kernel(ScanArgs a)
+{
+	extern __shared__ uint32_t lds[];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t wave = tid >> 6;
+	const uint32_t wq_off = LDS_OFF_WQ + WQ_BYTES * WQ_RING * wave;
+	const uint32_t cand_off = LDS_OFF_WQCAND + CAND_BYTES * WQ_CAND * wave;
+	const uint32_t kdiff = a.t.kdiff;
+
+	uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, n_mine;
+	if (a.xcd_tiles) {
+		const uint32_t xcd = blockIdx.x & 7, lo_t = xcd * a.xcd_tiles;
+		const uint32_t hi_t = min((uint64_t)lo_t + a.xcd_tiles, a.n_tiles);
+		tile_step = gridDim.x >> 3;
+		first_tile = lo_t + (blockIdx.x >> 3);
+		n_mine = first_tile < hi_t ? (hi_t - first_tile + tile_step - 1) / tile_step : 0;
+	} else {
+		n_mine = first_tile < a.n_tiles ? (uint32_t)((a.n_tiles - first_tile + tile_step - 1) / tile_step) : 0;
+	}
+	{
+		char *ldsb = reinterpret_cast<char *>(lds);
+		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
+		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
+		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
+		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
+		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
+		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
+		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
+		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
+		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
+	}
+	__syncthreads();
+
+	auto code_word = [&](uint32_t code, uint32_t &stream) {
+		const uint32_t tile = first_tile + (code >> 12) * tile_step;
+		uint32_t t = tile;
+		stream = 0;
+		if (a.n_streams > 1) {
+			stream = tile / (uint32_t)a.tiles_per_stream;
+			t = tile - stream * (uint32_t)a.tiles_per_stream;
+		}
+		return (uint64_t)t * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
+	};
+	uint32_t pend = 0;
+	uint32_t h_off = 0, h_hi = 0, h_lap = 0;
+	auto flush_hits = [&]() {
+		if (pend == 0)
+			return;
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(a.hit_count, pend);
+		base = __builtin_amdgcn_readfirstlane(base);
+		const uint32_t idx = base + lane;
+		if (lane < pend && idx < a.hit_cap) {
+			uint4 rec;
+			rec.x = h_off;
+			rec.y = h_hi & 0xffff;
+			rec.z = h_lap >> 8;
+			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
+			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+		}
+		pend = 0;
+	};
+	auto push_hits = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t lap, uint32_t nerr) {
+		if (a.first) {
+			if (hit)
+				emit_hit(a, stream, offset, lap, nerr);
+			return;
+		}
+		const uint64_t m = __ballot(hit);
+		if (!m)
+			return;
+		const uint32_t c = (uint32_t)__popcll(m);
+		if (pend + c > 64)
+			flush_hits();
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+		const int dst = (int)((hit ? pend + rank : (pend ? 0u : c)) << 2);
+		const uint32_t r_off = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)offset);
+		const uint32_t r_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((uint32_t)(offset >> 32) | (stream << 16)));
+		const uint32_t r_lap = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((lap << 8) | nerr));
+		if (lane - pend < c) {
+			h_off = r_off;
+			h_hi = r_hi;
+			h_lap = r_lap;
+		}
+		pend += c;
+	};
+	uint32_t c_count = 0;
+	auto cand_verify = [&]() {
+		bool hit = false;
+		uint32_t stream = 0, lap = 0, nerr = 0;
+		uint64_t offset = 0;
+		if (lane < c_count) {
+			const uint32_t o = cand_off + CAND_BYTES * lane;
+			const uint32_t code = lds_ld(o);
+			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
+			offset = code_word(code, stream) * 64 + (code & 63);
+			hit = verify_lap_any(a, w, lap, nerr);
+		}
+		push_hits(hit, stream, offset, lap, nerr);
+		c_count = 0;
+	};
+	auto cand_push = [&](bool flag, uint32_t code, uint32_t wlo, uint32_t whi) {
+#pragma unroll
+		for (uint32_t half = 0; half < 2; half++) {
+			const bool mine = flag && (lane >> 5) == half;
+			const uint64_t mask = __ballot(mine);
+			if (!mask)
+				continue;
+			const uint32_t n = (uint32_t)__popcll(mask);
+			if (c_count + n > WQ_CAND)
+				cand_verify();
+			if (mine) {
+				const uint32_t slot = c_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+						__builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+				const uint32_t o = cand_off + CAND_BYTES * slot;
+				lds_st(o, code);
+				lds_st(o + 4, wlo);
+				lds_st(o + 8, whi);
+			}
+			c_count += n;
+		}
+	};
+
+	// tile cursor (as in the lock-step kernel)
+	struct Cursor { uint32_t stream; uint64_t t; };
+	Cursor cur = {a.n_streams, 0};
+	uint32_t handed = 0;
+	if (n_mine) {
+		cur.stream = a.n_streams > 1 ? first_tile / (uint32_t)a.tiles_per_stream : 0;
+		cur.t = first_tile - (uint64_t)cur.stream * a.tiles_per_stream;
+	}
+	auto advance = [&](Cursor &c) {
+		if (++handed >= n_mine) {
+			c.stream = a.n_streams;
+			return;
+		}
+		c.t += tile_step;
+		while (c.t >= a.tiles_per_stream && c.stream < a.n_streams) {
+			c.t -= a.tiles_per_stream;
+			c.stream++;
+		}
+	};
+	auto tile_full = [&](uint64_t tt) {
+		return (tt + 1) * SCAN_THREADS + 1 <= a.n_words && (tt + 1) * (SCAN_THREADS * 64ull) <= a.search_bits;
+	};
+	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
+		lo = hi = 0;
+		if (c.stream >= a.n_streams)
+			return;
+		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + c.t * SCAN_THREADS;
+		if (tile_full(c.t)) {
+			lo = tp[tid];
+			hi = tp[tid + 1];
+		} else {
+			const uint64_t w = c.t * SCAN_THREADS + tid;
+			lo = w < a.n_words ? tp[tid] : 0;
+			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
+		}
+	};
+
+	// ---- producer: the next tile's words are always in flight; produce() turns them into 64 records
+	Cursor tc = cur;
+	uint64_t lo, hi;
+	load_pair(cur, lo, hi);
+	advance(cur);
+	uint32_t produced = 0;                        // word records written so far (wave-uniform, multiple of 64)
+	auto produce = [&]() {
+		const Cursor mine = tc;
+		const uint64_t wlo = lo, whi = hi;
+		tc = cur;                                 // prefetch the tile after this one
+		load_pair(cur, lo, hi);
+		advance(cur);
+		const uint32_t d0 = (uint32_t)wlo, d1 = (uint32_t)(wlo >> 32), d2 = (uint32_t)whi, d3 = (uint32_t)(whi >> 32);
+		uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
+		if (!tile_full(mine.t)) {
+			const uint64_t first_off = (mine.t * SCAN_THREADS + tid) * 64;
+			const uint64_t valid = first_off >= a.search_bits ? 0ULL
+				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+			validA = (uint32_t)valid;
+			validB = (uint32_t)(valid >> 32);
+		}
+		uint32_t mA, cA, mB, cB;
+		barker32(d1, d2, validA, mA, cA);
+		barker32(d2, d3, validB, mB, cB);
+		const uint32_t o = wq_off + WQ_BYTES * ((produced & (WQ_RING - 1)) + lane);
+		*reinterpret_cast<lds_u4_t *>(o) = u32x4{mA, cA, d0, d1};
+		*reinterpret_cast<lds_u4_t *>(o + 16) = u32x4{d2, d3, mB, cB};
+		produced += 64;
+	};
+
+	// ---- consumer: slot 0 works on lower halves (record dwords 0..4), slot 1 on upper halves (3..7)
+	uint32_t qh[2] = {0, 0};                      // next record of each queue (wave-uniform)
+	uint32_t cm[2] = {0, 0}, ccls[2] = {0, 0}, ce0[2] = {0, 0}, ce1[2] = {0, 0}, ce2[2] = {0, 0}, ccb[2] = {0, 0};
+	auto refill = [&](const int s) {
+		const bool need = cm[s] == 0;
+		const uint64_t mask = __ballot(need);
+		uint32_t n = (uint32_t)__popcll(mask);
+		const uint32_t avail = produced - qh[s];
+		n = n < avail ? n : avail;
+		if (!n)
+			return;
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+		if (need && rank < n) {
+			const uint32_t w = qh[s] + rank;
+			const uint32_t o = wq_off + WQ_BYTES * (w & (WQ_RING - 1));
+			if (s == 0) {
+				const u32x4 v = *reinterpret_cast<lds_u4_t *>(o);
+				cm[0] = v.x; ccls[0] = v.y; ce0[0] = v.z; ce1[0] = v.w;
+				ce2[0] = lds_ld(o + 16);
+			} else {
+				const u32x4 v = *reinterpret_cast<lds_u4_t *>(o + 16);
+				ce1[1] = v.x; ce2[1] = v.y; cm[1] = v.z; ccls[1] = v.w;
+				ce0[1] = lds_ld(o + 12);
+			}
+			ccb[s] = (w << 6) | ((uint32_t)s << 5);        // tile iteration << 12 | word lane << 6 | half << 5
+		}
+		qh[s] += n;
+	};
+	auto pass = [&]() {
+		uint32_t p[2], t1[2], t2[2], bw[2], proj[2], i2[2];
+		Probe q[2];
+#pragma unroll
+		for (int s = 0; s < 2; s++) {
+			p[s] = lowest_bit(cm[s]);
+			q[s] = probe_addr(ce0[s], ce1[s], ce2[s], ccls[s], kdiff, p[s]);
+			t1[s] = lds_ld(LDS_OFF_TABA + q[s].offA);            // lanes between chains read along: harmless
+			t2[s] = lds_ld(LDS_OFF_TABB + q[s].offB);
+		}
+#pragma unroll
+		for (int s = 0; s < 2; s++) {
+			proj[s] = xor3(q[s].x, t1[s], t2[s]);
+			if (VARIANT == 8) {
+				i2[s] = (proj[s] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+				bw[s] = cm[s] ? a.t.bitmap2[i2[s] >> 5] : 0u;
+			} else {
+				bw[s] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[s]));
+			}
+		}
+		uint32_t bit[2];
+#pragma unroll
+		for (int s = 0; s < 2; s++)
+			bit[s] = VARIANT == 8 ? bw[s] >> (i2[s] & 31) : bw[s] >> (proj[s] & 31);      // bit 0 counts
+		if (__ballot(((bit[0] | bit[1]) & 1) != 0)) {
+			// rare (0.3 % of the survivors): now look properly -- lanes between chains do not count
+			uint32_t todo = 0;
+#pragma unroll
+			for (int s = 0; s < 2; s++) {
+				uint32_t b = cm[s] ? bit[s] & 1 : 0u;
+				if (VARIANT == 9 && b) {
+					const uint32_t j2 = (proj[s] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+					b = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
+				}
+				todo |= b << s;
+			}
+			while (__ballot(todo != 0)) {
+				const int s = (todo & 1) ? 0 : 1;
+				const uint32_t e0 = s ? ce0[1] : ce0[0], e1 = s ? ce1[1] : ce1[0], e2 = s ? ce2[1] : ce2[0];
+				const uint32_t pp = s ? p[1] : p[0];
+				cand_push(todo != 0, (s ? ccb[1] : ccb[0]) | (pp & 31), alignbit(e1, e0, pp), alignbit(e2, e1, pp));
+				todo &= todo - 1;
+			}
+		}
+#pragma unroll
+		for (int s = 0; s < 2; s++)
+			cm[s] &= cm[s] - 1;
+	};
+
+	for (;;) {
+		while (tc.stream < a.n_streams && produced - (qh[0] < qh[1] ? qh[0] : qh[1]) <= WQ_RING - 64)
+			produce();
+		refill(0);
+		refill(1);
+		if (!__ballot((cm[0] | cm[1]) != 0)) {
+			if (tc.stream >= a.n_streams && qh[0] == produced && qh[1] == produced)
+				break;
+			continue;                             // only empty chains came up: take the next ones
+		}
+#pragma unroll
+		for (int r = 0; r < WQ_ROUND; r++)
+			pass();
+	}
+	if (c_count)
+		cand_verify();
+	flush_hits();
+}
+#endif   // SCAN_DESIGN == 1
+
 // ---- known LAP --------------------------------------------------------------------------
 
 // bit-sliced "mismatches in sync-word bits 52..63 <= limit" for 32 offsets: twelve planes
@@ -886,10 +1190,17 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		int run_variant = 0;
 		if (c.scan.bitmap2 && c.table_errors >= 4)
 			run_variant = c.table_errors == 4 ? 9 : 8;
+#if SCAN_DESIGN == 1
+#define LAUNCH_VARIANT(V) do { \
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_wq_kernel<V>), \
+					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES_WQ)); \
+		hipLaunchKernelGGL(scan_lap_any_wq_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES_WQ, stream, a); } while (0)
+#else
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
 		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
+#endif
 		switch (run_variant) {
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
