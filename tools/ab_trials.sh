@@ -5,5 +5,5 @@ for so in libbtbb_amd/libbtbb_amd.so libbtbb_amd/variants/*.so; do
   LIBBTBB_AMD_SO=$PWD/$so timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print('$so', ' | '.join('%s %s %s ms=%s' % (k, v['value'], v['unit'], v['ms_per_step']) for k,v in d['secondary'].items()))"
+print('$so', ' | '.join('%s %s %s ms=%s kernel_ms=%s' % (k, v['value'], v['unit'], v['ms_per_step'], v['roofline']['kernel_ms']) for k,v in d['secondary'].items()))"
 done

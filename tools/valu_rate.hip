@@ -42,6 +42,16 @@ KERNEL(k_ffbl, OP8_1("v_ffbl_b32"))
 KERNEL(k_bcnt, OP8("v_bcnt_u32_b32"))
 KERNEL(k_mul_lo, OP8_3("v_mad_u32_u24"))
 KERNEL(k_fma, OP8_3("v_fma_f32"))
+KERNEL(k_perm, OP8_3("v_perm_b32"))
+KERNEL(k_alignbyte, OP8_3("v_alignbyte_b32"))
+KERNEL(k_cndmask, OP8("v_cndmask_b32"))
+KERNEL(k_or3, OP8_3("v_or3_b32"))
+KERNEL(k_xad, OP8_3("v_xad_u32"))
+KERNEL(k_lshl_or, OP8_3("v_lshl_or_b32"))
+KERNEL(k_bfi, OP8_3("v_bfi_b32"))
+KERNEL(k_mbcnt, OP8("v_mbcnt_lo_u32_b32"))
+KERNEL(k_bfm, OP8("v_bfm_b32"))
+KERNEL(k_movdpp, asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));)
 __global__ __launch_bounds__(1024) void k_bitop3(uint32_t *out, uint32_t seed)
 {
 	uint32_t a = threadIdx.x ^ seed, b = a * 3 + 1, c = a + 7, d = b ^ 0x55;
@@ -83,7 +93,7 @@ int main()
 {
 	uint32_t *d_out;
 	hipMalloc(&d_out, 256 * 1024 * 4);
-	for (int w = 1; w <= 4; w *= 2) {
+	for (int w = 4; w <= 4; w *= 2) {
 		run("v_and_b32", k_and, d_out, w);
 		run("v_xor_b32", k_xor, d_out, w);
 		run("v_add_u32", k_add, d_out, w);
@@ -97,6 +107,16 @@ int main()
 		run("v_bcnt_u32_b32", k_bcnt, d_out, w);
 		run("v_mad_u32_u24", k_mul_lo, d_out, w);
 		run("v_fma_f32", k_fma, d_out, w);
+		run("v_perm_b32", k_perm, d_out, w);
+		run("v_alignbyte_b32", k_alignbyte, d_out, w);
+		run("v_cndmask_b32", k_cndmask, d_out, w);
+		run("v_or3_b32", k_or3, d_out, w);
+		run("v_xad_u32", k_xad, d_out, w);
+		run("v_lshl_or_b32", k_lshl_or, d_out, w);
+		run("v_bfi_b32", k_bfi, d_out, w);
+		run("v_mbcnt_lo", k_mbcnt, d_out, w);
+		run("v_bfm_b32", k_bfm, d_out, w);
+		run("v_mov_dpp", k_movdpp, d_out, w);
 	}
 	return 0;
 }
