@@ -483,7 +483,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 					t1[u][h] = lds_ld(LDS_OFF_TABA + (m[u][h] ? q[u][h].offA : 0u));
 					t2[u][h] = lds_ld(LDS_OFF_TABB + (m[u][h] ? q[u][h].offB : 0u));
 #else
-					t1[u][h] = t2[u][h] = 0;
+					// lanes without a survivor keep whatever these registers held: their projection is
+					// garbage, but their bitmap word below stays 0
+					asm volatile("" : "=v"(t1[u][h]), "=v"(t2[u][h]));
 					if (m[u][h]) {
 						t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
 						t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
@@ -517,11 +519,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
+					// only bit 0 of bit[][] counts (one shift here, the masking in the rare branch below)
 					if (VARIANT == 8)
-						bit[u][h] = (bw[u][h] >> (i2[u][h] & 31)) & 1;
+						bit[u][h] = bw[u][h] >> (i2[u][h] & 31);
 					else
-						bit[u][h] = (bw[u][h] >> (proj[u][h] & 31)) & 1;    // bw == 0 without a survivor
-					if (VARIANT == 9 && bit[u][h]) {
+						bit[u][h] = bw[u][h] >> (proj[u][h] & 31);          // bw == 0 without a survivor
+					if (VARIANT == 9 && (bit[u][h] & 1)) {
 						// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
 						const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
 						bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
@@ -529,12 +532,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 					anybit |= bit[u][h];
 					m[u][h] &= m[u][h] - 1;
 				}
-			if (anybit) {
+			if (anybit & 1) {
 #pragma unroll
 				for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 					for (int h = 0; h < 2; h++)
-						if (bit[u][h])      // rare: rebuild the window of this offset and keep it with the code
+						if (bit[u][h] & 1)  // rare: rebuild the window of this offset and keep it with the code
 							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31),
 							     alignbit(d[u][h + 1], d[u][h], p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], p[u][h]));
 			}
