@@ -712,7 +712,10 @@ __global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, co
 #define TB_PACKETS 16          /* measured: 64 -> 4.09 ms, 32 -> 2.49, 16 -> 2.13, 8 -> 4.20 per 2^20 packets (occupancy vs bucket size) */
 #endif
 #define TB_TRIALS  (TB_PACKETS * 64)
-__global__ __launch_bounds__(256) void trials_bucket_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+#ifndef TB_WAVES_ATTR
+#define TB_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(256) TB_WAVES_ATTR void trials_bucket_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 							     uint32_t n_packets, btbbx_trial *trials)
 {
 	// 51 words per row: in step 3 the lanes of a wave read the same word of 64 DIFFERENT packets, and an
