@@ -29,7 +29,7 @@
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
 #endif
 #define PARK_SLOTS     2                   // private candidate slots per lane
-#define CAND_BYTES     12                  // a parked candidate: position code + its 64-bit window
+#define CAND_BYTES     16                  // a parked candidate: position code + its 64-bit window + pad (one ds_*_b128)
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
 // probe needs no address adds.
@@ -41,21 +41,11 @@
 #define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
 #define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING candidates
 #define LDS_OFF_PARK     (LDS_OFF_QUEUE + CAND_BYTES * SCAN_WAVES * QRING)    // 16 x 64 x PARK_SLOTS candidates
-#define LDS_OFF_ZERO     (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // one dword that stays 0
-#define SCAN_LDS_BYTES   (LDS_OFF_ZERO + 16u)                                           // = 136 KiB
-// word-queue variant (SCAN_DESIGN 1): the space behind the tables holds, per wave, a ring of word records
-// (survivor and class masks of both halves + the four stream dwords) and a small candidate stack
-#define WQ_RING          128u              // word records per wave
-#define WQ_BYTES         32u
-#define WQ_CAND          40u               // candidates per wave awaiting the exact check
-#define LDS_OFF_WQ       LDS_OFF_QUEUE
-#define LDS_OFF_WQCAND   (LDS_OFF_WQ + WQ_BYTES * SCAN_WAVES * WQ_RING)
-#define SCAN_LDS_BYTES_WQ (LDS_OFF_WQCAND + CAND_BYTES * SCAN_WAVES * WQ_CAND)         // 159.5 KiB
-#ifndef SCAN_DESIGN
-#define SCAN_DESIGN      0                 // 0 = lock-step survivor loop, 1 = word queue + dense refilled loop
-#endif
-#ifndef SCAN_READ_MODE
-#define SCAN_READ_MODE   0                 // how idle lanes sit out a table read: 0 = exec mask, 1 = parked address
+#define LDS_OFF_PROF     (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // -DSCAN_PROFILE: 32 counters per wave
+#ifdef SCAN_PROFILE
+#define SCAN_LDS_BYTES   (LDS_OFF_PROF + 128u * SCAN_WAVES)
+#else
+#define SCAN_LDS_BYTES   LDS_OFF_PROF                                                   // = 152 KiB
 #endif
 
 // ---- device-side table bundle -----------------------------------------------------

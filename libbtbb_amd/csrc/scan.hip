@@ -50,6 +50,23 @@ struct ScanArgs {
 	ScanTables t;
 };
 
+// Debug build (-DSCAN_PROFILE): where the LAP_ANY kernel's wave time goes.  Lane 0 of every wave adds the
+// s_memtime ticks since its previous mark to a per-wave counter in LDS (global atomics here would stall the
+// very loads the loop waits for); the counters go out once at the end and the launcher prints the table.
+//   0 = tile loads + barker filter, 1..13 = survivor pass k, 16 = loop exit, 17 = compaction,
+//   18 = exact checks, 19 = wait for the prefetched words
+#ifdef SCAN_PROFILE
+__device__ unsigned long long g_scan_prof[32];
+#define PROF_MARK(k) do { uint64_t now_; __builtin_amdgcn_sched_barrier(0); \
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); __builtin_amdgcn_sched_barrier(0); \
+		if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t *>(prof_off + 4u * (k)), (uint32_t)(now_ - prof_t), \
+						      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); prof_t = now_; } while (0)
+#define PROF_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define PROF_MARK(k) do { (void)(k); } while (0)
+#define PROF_PIN(x) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
 {
 	return __builtin_amdgcn_alignbit(hi, lo, sh);
@@ -88,6 +105,11 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 __device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
 __device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
+// a candidate record (position code, 64-bit window, pad) moves as one 16-byte DS access
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+__device__ __forceinline__ u32x4 lds_ld4(uint32_t byte_off) { return *reinterpret_cast<lds_u32x4_t *>(byte_off); }
+__device__ __forceinline__ void lds_st4(uint32_t byte_off, u32x4 v) { *reinterpret_cast<lds_u32x4_t *>(byte_off) = v; }
 
 // w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
 // batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
@@ -217,7 +239,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	const uint32_t wave = tid >> 6;
 	const uint32_t slot_off = LDS_OFF_PARK + CAND_BYTES * (wave * 64 * PARK_SLOTS + lane * PARK_SLOTS);
 	const uint32_t ring_off = LDS_OFF_QUEUE + CAND_BYTES * wave * QRING;
-	const uint32_t kdiff = a.t.kdiff;
+	uint32_t kdiff = a.t.kdiff;
+	asm volatile("" : "+v"(kdiff));           // keep it in a VGPR: a VALU op with an SGPR source issues at half rate
 
 	// Tile order.  The dispatcher is observed to place workgroup b on XCD b % 8 (not a contract: a
 	// different placement costs L2 sharing, never correctness).  Each XCD gets one contiguous
@@ -247,10 +270,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
 		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
 		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
-		if (tid == 0)
-			lds_st(LDS_OFF_ZERO, 0u);
 	}
 	__syncthreads();
+#ifdef SCAN_PROFILE
+	const uint32_t prof_off = LDS_OFF_PROF + 128u * (tid >> 6);
+	if ((tid & 63) < 32)
+		lds_st(prof_off + 4u * (tid & 63), 0u);
+	uint64_t prof_t;
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t) : : "memory");
+#endif
 
 	// Candidate = passed the bitmap (0.3 % of survivors).  Three stages keep it cheap:
 	//  1. park: one DS write into a private slot of the lane -- no atomics and no ballots in
@@ -327,10 +355,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	};
 	auto park = [&](uint32_t code, uint32_t wlo, uint32_t whi) {
 		if (n_parked < PARK_SLOTS) {
-			const uint32_t o = slot_off + CAND_BYTES * n_parked;
-			lds_st(o, code);
-			lds_st(o + 4, wlo);
-			lds_st(o + 8, whi);
+			const u32x4 rec = {code, wlo, whi, 0u};
+			lds_st4(slot_off + CAND_BYTES * n_parked, rec);
 			n_parked++;
 		} else {                                  // all slots taken (adversarial input): verify in place
 			uint32_t stream, lap, nerr;
@@ -340,18 +366,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		}
 	};
 	auto drain = [&](uint32_t n) {
+		PROF_MARK(17);
 		bool hit = false;
 		uint32_t stream = 0, lap = 0, nerr = 0;
 		uint64_t offset = 0;
 		if (lane < n) {
-			const uint32_t o = ring_off + CAND_BYTES * ((q_head + lane) & (QRING - 1));
-			const uint32_t code = lds_ld(o);
-			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
+			const u32x4 rec = lds_ld4(ring_off + CAND_BYTES * ((q_head + lane) & (QRING - 1)));
+			const uint32_t code = rec.x;
+			const uint64_t w = ((uint64_t)rec.z << 32) | rec.y;
 			offset = code_word(code, stream) * 64 + (code & 63);
 			hit = verify_lap_any(a, w, lap, nerr);
 		}
 		push_hits(hit, stream, offset, lap, nerr);
 		q_head += n;
+		PROF_MARK(18);
 	};
 	auto compact = [&](bool final) {
 		for (uint32_t k = 0; k < PARK_SLOTS; k++) {
@@ -362,9 +390,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32),
 						__builtin_amdgcn_mbcnt_lo((uint32_t)have, 0));
 				const uint32_t from = slot_off + CAND_BYTES * k, to = ring_off + CAND_BYTES * (slot & (QRING - 1));
-				lds_st(to, lds_ld(from));
-				lds_st(to + 4, lds_ld(from + 4));
-				lds_st(to + 8, lds_ld(from + 8));
+				lds_st4(to, lds_ld4(from));
 			}
 			q_tail += __popcll(have);
 			while (q_tail - q_head >= 64)       // keeps the ring below 128 entries
@@ -459,12 +485,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
 		// survivor of every 32-offset half in flight (2 * UNROLL independent chains).  The LDS
-		// reads of all chains are issued before any result is used.  Lanes without a survivor in a
-		// chain do not take part in its reads: SCAN_READ_MODE 0 switches them off in the exec mask
-		// (a v_cmp, an s_and_saveexec, a skip branch and an s_or per group of reads), mode 1 parks them
-		// on one fixed address each (a v_cndmask per read; equal addresses are broadcast, so parked
-		// lanes cost no bank conflicts and the scalar instructions disappear).
-		for (;;) {
+		// reads of all chains are issued before any result is used.
+		// Lanes without a survivor in a chain (45 % of them, measured) read along: their ffbl is ~0, so
+		// they form some in-range table address from offset 31, and `m >> p` -- bit 0 set exactly for
+		// a lane that has a survivor -- masks their bitmap bit afterwards.  Switching them off in the
+		// exec mask instead (a v_cmp, an s_and_saveexec, a skip branch and an s_or per group of reads)
+		// was 3 % slower: the loop is bound by instruction issue, not by LDS bank conflicts
+		// (profiles/r02_cut).  The global bitmap of the >= 4-error variants is still read under exec.
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			PROF_PIN(m[u][0]);
+			PROF_PIN(m[u][1]);
+		}
+		PROF_MARK(0);
+		for (uint32_t pass = 1;; pass++) {
 			uint32_t any = 0;
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
@@ -479,18 +513,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int h = 0; h < 2; h++) {
 					p[u][h] = lowest_bit(m[u][h]);
 					q[u][h] = probe_addr(d[u][h], d[u][h + 1], d[u][h + 2], cls[u][h], kdiff, p[u][h]);
-#if SCAN_READ_MODE == 1
-					t1[u][h] = lds_ld(LDS_OFF_TABA + (m[u][h] ? q[u][h].offA : 0u));
-					t2[u][h] = lds_ld(LDS_OFF_TABB + (m[u][h] ? q[u][h].offB : 0u));
-#else
-					// lanes without a survivor keep whatever these registers held: their projection is
-					// garbage, but their bitmap word below stays 0
-					asm volatile("" : "=v"(t1[u][h]), "=v"(t2[u][h]));
-					if (m[u][h]) {
-						t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
-						t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
-					}
-#endif
+					t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
+					t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
 				}
 			uint32_t anybit = 0, bit[UNROLL][2], i2[UNROLL][2];
 #pragma unroll
@@ -498,32 +522,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
-					bw[u][h] = 0;
 					if (VARIANT == 8) {
-						// tables for >= 4 errors: the LDS bitmap passes more than half of the survivors,
-						// so probe the 2^26-bit bitmap in L2 / Infinity Cache right here instead
+						// tables for >= 5 errors: the LDS bitmap passes every survivor, so probe the
+						// 2^26-bit bitmap in L2 / Infinity Cache right here instead
 						i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+						bw[u][h] = 0;
 						if (m[u][h])
 							bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
 					} else {
-#if SCAN_READ_MODE == 1
-						// parked lanes read the spare zero word behind the tables: no candidate
-						bw[u][h] = lds_ld(LDS_OFF_BITMAP + (m[u][h] ? bitmap_off(proj[u][h]) : LDS_OFF_ZERO - LDS_OFF_BITMAP));
-#else
-						if (m[u][h])
-							bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
-#endif
+						bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
 					}
 				}
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
-					// only bit 0 of bit[][] counts (one shift here, the masking in the rare branch below)
-					if (VARIANT == 8)
-						bit[u][h] = bw[u][h] >> (i2[u][h] & 31);
-					else
-						bit[u][h] = bw[u][h] >> (proj[u][h] & 31);          // bw == 0 without a survivor
+					// only bit 0 of bit[][] counts: (bitmap word >> index) & (m >> p)
+					const uint32_t live = m[u][h] >> p[u][h];          // p = ~0 for m == 0: 0 >> 31
+					bit[u][h] = (bw[u][h] >> ((VARIANT == 8 ? i2[u][h] : proj[u][h]) & 31)) & live;
 					if (VARIANT == 9 && (bit[u][h] & 1)) {
 						// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
 						const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
@@ -541,11 +557,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31),
 							     alignbit(d[u][h + 1], d[u][h], p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], p[u][h]));
 			}
+			PROF_MARK(pass < 13 ? pass : 13);
 		}
 
 		// wave-uniform: compact (and verify) once enough lanes hold a candidate
+		PROF_MARK(16);
 		if (__popcll(__ballot(n_parked != 0)) >= 24 || __ballot(n_parked >= PARK_SLOTS))
 			compact(false);
+		PROF_MARK(17);
+#ifdef SCAN_PROFILE
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			PROF_PIN(nlo[u]);
+			PROF_PIN(nhi[u]);
+		}
+#endif
+		PROF_MARK(19);
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			tc[u] = nc[u];
@@ -555,311 +582,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	}
 	compact(true);
 	flush_hits();
-}
-
-#if SCAN_DESIGN == 1
-// ---- LAP_ANY, word-queue variant ---------------------------------------------------------------------
-// The lock-step loop above keeps < 50 % of its lanes busy (a lane has 4 +- 1.9 survivors per 32 offsets and
-// the loop runs until the slowest of 256 chains is done).  Here the pre-filter of a tile only WRITES what it
-// found -- one 32-byte record per stream word: survivor and class masks of both 32-offset halves and the
-// four stream dwords, two ds_write_b128 per lane, no compaction -- into a per-wave ring in LDS, and a second
-// loop keeps two chains per lane (slot 0: a lower half, slot 1: an upper half) and hands every lane whose
-// chain is used up the next queued one, in ballot-rank order, every WQ_ROUND passes.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u4_t;
-#ifndef WQ_ROUND
-#define WQ_ROUND 2
+#ifdef SCAN_PROFILE
+	if (lane < 32)
+		atomicAdd(&g_scan_prof[lane], (unsigned long long)lds_ld(prof_off + 4u * lane));
 #endif
-
-template <int VARIANT>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_wq_kernel(ScanArgs a)
-{
-	extern __shared__ uint32_t lds[];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t lane = tid & 63;
-	const uint32_t wave = tid >> 6;
-	const uint32_t wq_off = LDS_OFF_WQ + WQ_BYTES * WQ_RING * wave;
-	const uint32_t cand_off = LDS_OFF_WQCAND + CAND_BYTES * WQ_CAND * wave;
-	const uint32_t kdiff = a.t.kdiff;
-
-	uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, n_mine;
-	if (a.xcd_tiles) {
-		const uint32_t xcd = blockIdx.x & 7, lo_t = xcd * a.xcd_tiles;
-		const uint32_t hi_t = min((uint64_t)lo_t + a.xcd_tiles, a.n_tiles);
-		tile_step = gridDim.x >> 3;
-		first_tile = lo_t + (blockIdx.x >> 3);
-		n_mine = first_tile < hi_t ? (hi_t - first_tile + tile_step - 1) / tile_step : 0;
-	} else {
-		n_mine = first_tile < a.n_tiles ? (uint32_t)((a.n_tiles - first_tile + tile_step - 1) / tile_step) : 0;
-	}
-	{
-		char *ldsb = reinterpret_cast<char *>(lds);
-		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
-		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
-		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
-		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
-		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
-		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
-		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
-		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
-		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
-	}
-	__syncthreads();
-
-	auto code_word = [&](uint32_t code, uint32_t &stream) {
-		const uint32_t tile = first_tile + (code >> 12) * tile_step;
-		uint32_t t = tile;
-		stream = 0;
-		if (a.n_streams > 1) {
-			stream = tile / (uint32_t)a.tiles_per_stream;
-			t = tile - stream * (uint32_t)a.tiles_per_stream;
-		}
-		return (uint64_t)t * SCAN_THREADS + wave * 64 + ((code >> 6) & 63);
-	};
-	uint32_t pend = 0;
-	uint32_t h_off = 0, h_hi = 0, h_lap = 0;
-	auto flush_hits = [&]() {
-		if (pend == 0)
-			return;
-		uint32_t base = 0;
-		if (lane == 0)
-			base = atomicAdd(a.hit_count, pend);
-		base = __builtin_amdgcn_readfirstlane(base);
-		const uint32_t idx = base + lane;
-		if (lane < pend && idx < a.hit_cap) {
-			uint4 rec;
-			rec.x = h_off;
-			rec.y = h_hi & 0xffff;
-			rec.z = h_lap >> 8;
-			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
-			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
-		}
-		pend = 0;
-	};
-	auto push_hits = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t lap, uint32_t nerr) {
-		if (a.first) {
-			if (hit)
-				emit_hit(a, stream, offset, lap, nerr);
-			return;
-		}
-		const uint64_t m = __ballot(hit);
-		if (!m)
-			return;
-		const uint32_t c = (uint32_t)__popcll(m);
-		if (pend + c > 64)
-			flush_hits();
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-		const int dst = (int)((hit ? pend + rank : (pend ? 0u : c)) << 2);
-		const uint32_t r_off = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)offset);
-		const uint32_t r_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((uint32_t)(offset >> 32) | (stream << 16)));
-		const uint32_t r_lap = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((lap << 8) | nerr));
-		if (lane - pend < c) {
-			h_off = r_off;
-			h_hi = r_hi;
-			h_lap = r_lap;
-		}
-		pend += c;
-	};
-	uint32_t c_count = 0;
-	auto cand_verify = [&]() {
-		bool hit = false;
-		uint32_t stream = 0, lap = 0, nerr = 0;
-		uint64_t offset = 0;
-		if (lane < c_count) {
-			const uint32_t o = cand_off + CAND_BYTES * lane;
-			const uint32_t code = lds_ld(o);
-			const uint64_t w = ((uint64_t)lds_ld(o + 8) << 32) | lds_ld(o + 4);
-			offset = code_word(code, stream) * 64 + (code & 63);
-			hit = verify_lap_any(a, w, lap, nerr);
-		}
-		push_hits(hit, stream, offset, lap, nerr);
-		c_count = 0;
-	};
-	auto cand_push = [&](bool flag, uint32_t code, uint32_t wlo, uint32_t whi) {
-#pragma unroll
-		for (uint32_t half = 0; half < 2; half++) {
-			const bool mine = flag && (lane >> 5) == half;
-			const uint64_t mask = __ballot(mine);
-			if (!mask)
-				continue;
-			const uint32_t n = (uint32_t)__popcll(mask);
-			if (c_count + n > WQ_CAND)
-				cand_verify();
-			if (mine) {
-				const uint32_t slot = c_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-						__builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-				const uint32_t o = cand_off + CAND_BYTES * slot;
-				lds_st(o, code);
-				lds_st(o + 4, wlo);
-				lds_st(o + 8, whi);
-			}
-			c_count += n;
-		}
-	};
-
-	// tile cursor (as in the lock-step kernel)
-	struct Cursor { uint32_t stream; uint64_t t; };
-	Cursor cur = {a.n_streams, 0};
-	uint32_t handed = 0;
-	if (n_mine) {
-		cur.stream = a.n_streams > 1 ? first_tile / (uint32_t)a.tiles_per_stream : 0;
-		cur.t = first_tile - (uint64_t)cur.stream * a.tiles_per_stream;
-	}
-	auto advance = [&](Cursor &c) {
-		if (++handed >= n_mine) {
-			c.stream = a.n_streams;
-			return;
-		}
-		c.t += tile_step;
-		while (c.t >= a.tiles_per_stream && c.stream < a.n_streams) {
-			c.t -= a.tiles_per_stream;
-			c.stream++;
-		}
-	};
-	auto tile_full = [&](uint64_t tt) {
-		return (tt + 1) * SCAN_THREADS + 1 <= a.n_words && (tt + 1) * (SCAN_THREADS * 64ull) <= a.search_bits;
-	};
-	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
-		lo = hi = 0;
-		if (c.stream >= a.n_streams)
-			return;
-		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + c.t * SCAN_THREADS;
-		if (tile_full(c.t)) {
-			lo = tp[tid];
-			hi = tp[tid + 1];
-		} else {
-			const uint64_t w = c.t * SCAN_THREADS + tid;
-			lo = w < a.n_words ? tp[tid] : 0;
-			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
-		}
-	};
-
-	// ---- producer: the next tile's words are always in flight; produce() turns them into 64 records
-	Cursor tc = cur;
-	uint64_t lo, hi;
-	load_pair(cur, lo, hi);
-	advance(cur);
-	uint32_t produced = 0;                        // word records written so far (wave-uniform, multiple of 64)
-	auto produce = [&]() {
-		const Cursor mine = tc;
-		const uint64_t wlo = lo, whi = hi;
-		tc = cur;                                 // prefetch the tile after this one
-		load_pair(cur, lo, hi);
-		advance(cur);
-		const uint32_t d0 = (uint32_t)wlo, d1 = (uint32_t)(wlo >> 32), d2 = (uint32_t)whi, d3 = (uint32_t)(whi >> 32);
-		uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
-		if (!tile_full(mine.t)) {
-			const uint64_t first_off = (mine.t * SCAN_THREADS + tid) * 64;
-			const uint64_t valid = first_off >= a.search_bits ? 0ULL
-				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-			validA = (uint32_t)valid;
-			validB = (uint32_t)(valid >> 32);
-		}
-		uint32_t mA, cA, mB, cB;
-		barker32(d1, d2, validA, mA, cA);
-		barker32(d2, d3, validB, mB, cB);
-		const uint32_t o = wq_off + WQ_BYTES * ((produced & (WQ_RING - 1)) + lane);
-		*reinterpret_cast<lds_u4_t *>(o) = u32x4{mA, cA, d0, d1};
-		*reinterpret_cast<lds_u4_t *>(o + 16) = u32x4{d2, d3, mB, cB};
-		produced += 64;
-	};
-
-	// ---- consumer: slot 0 works on lower halves (record dwords 0..4), slot 1 on upper halves (3..7)
-	uint32_t qh[2] = {0, 0};                      // next record of each queue (wave-uniform)
-	uint32_t cm[2] = {0, 0}, ccls[2] = {0, 0}, ce0[2] = {0, 0}, ce1[2] = {0, 0}, ce2[2] = {0, 0}, ccb[2] = {0, 0};
-	auto refill = [&](const int s) {
-		const bool need = cm[s] == 0;
-		const uint64_t mask = __ballot(need);
-		uint32_t n = (uint32_t)__popcll(mask);
-		const uint32_t avail = produced - qh[s];
-		n = n < avail ? n : avail;
-		if (!n)
-			return;
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-		if (need && rank < n) {
-			const uint32_t w = qh[s] + rank;
-			const uint32_t o = wq_off + WQ_BYTES * (w & (WQ_RING - 1));
-			if (s == 0) {
-				const u32x4 v = *reinterpret_cast<lds_u4_t *>(o);
-				cm[0] = v.x; ccls[0] = v.y; ce0[0] = v.z; ce1[0] = v.w;
-				ce2[0] = lds_ld(o + 16);
-			} else {
-				const u32x4 v = *reinterpret_cast<lds_u4_t *>(o + 16);
-				ce1[1] = v.x; ce2[1] = v.y; cm[1] = v.z; ccls[1] = v.w;
-				ce0[1] = lds_ld(o + 12);
-			}
-			ccb[s] = (w << 6) | ((uint32_t)s << 5);        // tile iteration << 12 | word lane << 6 | half << 5
-		}
-		qh[s] += n;
-	};
-	auto pass = [&]() {
-		uint32_t p[2], t1[2], t2[2], bw[2], proj[2], i2[2];
-		Probe q[2];
-#pragma unroll
-		for (int s = 0; s < 2; s++) {
-			p[s] = lowest_bit(cm[s]);
-			q[s] = probe_addr(ce0[s], ce1[s], ce2[s], ccls[s], kdiff, p[s]);
-			t1[s] = lds_ld(LDS_OFF_TABA + q[s].offA);            // lanes between chains read along: harmless
-			t2[s] = lds_ld(LDS_OFF_TABB + q[s].offB);
-		}
-#pragma unroll
-		for (int s = 0; s < 2; s++) {
-			proj[s] = xor3(q[s].x, t1[s], t2[s]);
-			if (VARIANT == 8) {
-				i2[s] = (proj[s] * 0x9E3779B1u) >> a.t.bitmap2_shift;
-				bw[s] = cm[s] ? a.t.bitmap2[i2[s] >> 5] : 0u;
-			} else {
-				bw[s] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[s]));
-			}
-		}
-		uint32_t bit[2];
-#pragma unroll
-		for (int s = 0; s < 2; s++)
-			bit[s] = VARIANT == 8 ? bw[s] >> (i2[s] & 31) : bw[s] >> (proj[s] & 31);      // bit 0 counts
-		if (__ballot(((bit[0] | bit[1]) & 1) != 0)) {
-			// rare (0.3 % of the survivors): now look properly -- lanes between chains do not count
-			uint32_t todo = 0;
-#pragma unroll
-			for (int s = 0; s < 2; s++) {
-				uint32_t b = cm[s] ? bit[s] & 1 : 0u;
-				if (VARIANT == 9 && b) {
-					const uint32_t j2 = (proj[s] * 0x9E3779B1u) >> a.t.bitmap2_shift;
-					b = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
-				}
-				todo |= b << s;
-			}
-			while (__ballot(todo != 0)) {
-				const int s = (todo & 1) ? 0 : 1;
-				const uint32_t e0 = s ? ce0[1] : ce0[0], e1 = s ? ce1[1] : ce1[0], e2 = s ? ce2[1] : ce2[0];
-				const uint32_t pp = s ? p[1] : p[0];
-				cand_push(todo != 0, (s ? ccb[1] : ccb[0]) | (pp & 31), alignbit(e1, e0, pp), alignbit(e2, e1, pp));
-				todo &= todo - 1;
-			}
-		}
-#pragma unroll
-		for (int s = 0; s < 2; s++)
-			cm[s] &= cm[s] - 1;
-	};
-
-	for (;;) {
-		while (tc.stream < a.n_streams && produced - (qh[0] < qh[1] ? qh[0] : qh[1]) <= WQ_RING - 64)
-			produce();
-		refill(0);
-		refill(1);
-		if (!__ballot((cm[0] | cm[1]) != 0)) {
-			if (tc.stream >= a.n_streams && qh[0] == produced && qh[1] == produced)
-				break;
-			continue;                             // only empty chains came up: take the next ones
-		}
-#pragma unroll
-		for (int r = 0; r < WQ_ROUND; r++)
-			pass();
-	}
-	if (c_count)
-		cand_verify();
-	flush_hits();
 }
-#endif   // SCAN_DESIGN == 1
+
 
 // ---- known LAP --------------------------------------------------------------------------
 
@@ -1193,22 +921,30 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		int run_variant = 0;
 		if (c.scan.bitmap2 && c.table_errors >= 4)
 			run_variant = c.table_errors == 4 ? 9 : 8;
-#if SCAN_DESIGN == 1
-#define LAUNCH_VARIANT(V) do { \
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_wq_kernel<V>), \
-					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES_WQ)); \
-		hipLaunchKernelGGL(scan_lap_any_wq_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES_WQ, stream, a); } while (0)
-#else
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
 		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
+#ifdef SCAN_PROFILE
+		static unsigned long long zero_prof[32];
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), zero_prof, sizeof(zero_prof)));
 #endif
 		switch (run_variant) {
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
 		default: LAUNCH_VARIANT(0); break;
 		}
+#ifdef SCAN_PROFILE
+		{
+			unsigned long long prof[32], total = 0;
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_scan_prof), sizeof(prof)));
+			for (int k = 0; k < 32; k++) total += prof[k];
+			fprintf(stderr, "scan profile (%% of wave time):");
+			for (int k = 0; k < 20; k++) fprintf(stderr, " %d:%.1f", k, 100.0 * (double)prof[k] / (double)(total ? total : 1));
+			fprintf(stderr, "\n");
+		}
+#endif
 	} else {
 		a.syncword = host_gen_syncword(lap & 0xffffff);
 		a.lap = lap;

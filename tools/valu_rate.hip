@@ -69,6 +69,30 @@ __global__ __launch_bounds__(1024) void k_bitop3(uint32_t *out, uint32_t seed)
 	out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
 }
 
+// 64-bit shift: four independent chains, twice per body (8 instructions like the others)
+__global__ __launch_bounds__(1024) void k_lshr64(uint32_t *out, uint32_t seed)
+{
+	uint64_t A = threadIdx.x ^ seed, B = A * 3 + 1, C = A + 7, D = B ^ 0x55;
+	for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+		for (int u = 0; u < UNROLL / 8; u++)
+			asm volatile("v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3\n"
+				     "v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3\n"
+				     : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "v"(seed));
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(A ^ B ^ C ^ D) ^ (uint32_t)((A ^ B ^ C ^ D) >> 32);
+}
+// two-operand op with a 32-bit literal (8-byte encoding) and with the same constant in an SGPR
+#define OP8_LIT(ins, lit) asm volatile(ins " %0, " lit ", %0\n" ins " %1, " lit ", %1\n" ins " %2, " lit ", %2\n" ins " %3, " lit ", %3\n" \
+	ins " %4, " lit ", %4\n" ins " %5, " lit ", %5\n" ins " %6, " lit ", %6\n" ins " %7, " lit ", %7\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+#define OP8_SGPR(ins) asm volatile(ins " %0, %8, %0\n" ins " %1, %8, %1\n" ins " %2, %8, %2\n" ins " %3, %8, %3\n" \
+	ins " %4, %8, %4\n" ins " %5, %8, %5\n" ins " %6, %8, %6\n" ins " %7, %8, %7\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(seed));
+KERNEL(k_or_lit, OP8_LIT("v_or_b32", "0x12345"))
+KERNEL(k_or_sgpr, OP8_SGPR("v_or_b32"))
+KERNEL(k_or_inline, OP8_LIT("v_or_b32", "1"))
+
 template <typename K>
 static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
 {
@@ -108,6 +132,10 @@ int main()
 		run("v_mad_u32_u24", k_mul_lo, d_out, w);
 		run("v_fma_f32", k_fma, d_out, w);
 		run("v_perm_b32", k_perm, d_out, w);
+		run("v_lshrrev_b64", k_lshr64, d_out, w);
+		run("v_or_b32 literal", k_or_lit, d_out, w);
+		run("v_or_b32 sgpr", k_or_sgpr, d_out, w);
+		run("v_or_b32 inline", k_or_inline, d_out, w);
 		run("v_alignbyte_b32", k_alignbyte, d_out, w);
 		run("v_cndmask_b32", k_cndmask, d_out, w);
 		run("v_or3_b32", k_or3, d_out, w);
