@@ -24,8 +24,125 @@
 
 __constant__ ChainTables g_chain;
 
+// Per-workgroup LDS copies of the small tables the decoders index with per-lane values inside
+// their inner loops (whitening slice, CRC byte / word step, FEC 2/3 parity and correction): a DS read
+// instead of a divergent constant-memory load or a 10-step loop.  4.6 KiB, copied by
+// chain_lds_init() at kernel start from the image chain_upload() built on the host.
+struct __attribute__((aligned(16))) ChainLds {
+	uint32_t wh32[128];        // 32 whitening bits from phase idx (idx <= 126)
+	uint16_t crc[256];         // crc_byte(0, x): one byte through the reflected CRC-CCITT register
+	uint16_t crc_z[3][256];    // the same followed by 1, 2, 3 zero bytes (slicing: four bytes per step)
+	uint8_t  par23[1024];      // FEC 2/3 parity of 10 data bits
+	int8_t   fix23[32];
+	uint8_t  whiten_idx[64];
+	uint16_t adv32[2][256];    // the CRC register 32 zero bytes later, by its low / high byte (linear: XOR the two)
+};
+// the image every workgroup copies (built once on the host in chain_upload)
+__device__ __attribute__((aligned(16))) ChainLds g_chain_lds_image;
+
+// Table of trials_linear_kernel.  The CRC register is GF(2)-linear in seed, data and whitening, the seed has
+// eight free bits (the UAP, bits 8..15) and the whitening sequence from any phase is the GF(2) combination of
+// seven basis sequences selected by its own first seven bits (a 7-stage LFSR).  Row L (payload length in
+// bytes) holds what each of those fifteen bits contributes to the register after L bytes:
+//   [0..7]  register after L zero bytes from the seed with only bit 8 + b set
+//   [8..14] register after the first L bytes of the whitening sequence whose first seven bits are unit vector j
+//   [15]    0
+#define LIN_MAXLEN 344                      // payload lengths 0 .. 343 (DH5)
+__device__ __attribute__((aligned(16))) uint16_t g_lin[LIN_MAXLEN * 16];
+
+static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
+{
+	uint32_t x = (crc ^ byte) & 0xff;
+	x ^= (x << 4) & 0xff;
+	return ((crc >> 8) ^ (x << 8) ^ (x << 3) ^ (x >> 4)) & 0xffff;
+}
+
 int chain_upload(const HostTables &t)
 {
+	// the LDS image of the decoders
+	{
+		static ChainLds img;
+		memset(&img, 0, sizeof(img));
+		for (int i = 0; i < 128; i++)
+			for (int j = 0; j < 32; j++)
+				img.wh32[i] |= (uint32_t)t.whiten[((i < 127 ? i : 0) + j) % 127] << j;
+		for (int i = 0; i < 256; i++) {
+			uint32_t c = host_crc_byte(0, (uint32_t)i);
+			img.crc[i] = (uint16_t)c;
+			for (int k = 0; k < 3; k++) {
+				c = host_crc_byte(c, 0);
+				img.crc_z[k][i] = (uint16_t)c;
+			}
+		}
+		for (int i = 0; i < 1024; i++) {
+			uint32_t par = 0;
+			for (int bit = 0; bit < 10; bit++)
+				if ((i >> bit) & 1)
+					par ^= t.fec23_par[bit];
+			img.par23[i] = (uint8_t)par;
+		}
+		memcpy(img.fix23, t.fec23_fix, 32);
+		memcpy(img.whiten_idx, t.whiten_idx, 64);
+		for (int h = 0; h < 2; h++)
+			for (int i = 0; i < 256; i++) {
+				uint32_t c = (uint32_t)i << (8 * h);
+				for (int k = 0; k < 32; k++)
+					c = host_crc_byte(c, 0);
+				img.adv32[h][i] = (uint16_t)c;
+			}
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_lds_image), &img, sizeof(img)));
+	}
+	// the rows of trials_linear_kernel
+	{
+		static uint16_t lin[LIN_MAXLEN * 16];
+		memset(lin, 0, sizeof(lin));
+		for (int bit = 0; bit < 8; bit++) {
+			uint32_t crc = 1u << (8 + bit);
+			for (int L = 0; L < LIN_MAXLEN; L++) {
+				lin[L * 16 + bit] = (uint16_t)crc;
+				crc = host_crc_byte(crc, 0);
+			}
+		}
+		// the recurrence of the whitening sequence: w[k + 7] = XOR of the w[k + j] picked by `taps` (found, not assumed)
+		uint32_t taps = 0;
+		for (uint32_t m = 1; m < 128 && !taps; m++) {
+			bool ok = true;
+			for (int k = 0; k < 127 && ok; k++) {
+				uint32_t x = 0;
+				for (int j = 0; j < 7; j++)
+					if ((m >> j) & 1)
+						x ^= t.whiten[(k + j) % 127];
+				ok = x == t.whiten[(k + 7) % 127];
+			}
+			if (ok)
+				taps = m;
+		}
+		if (!taps) {
+			set_error("chain_upload: the whitening sequence is not a 7-stage LFSR sequence");
+			return BTBBX_E_ARG;
+		}
+		for (int e = 0; e < 7; e++) {
+			static uint8_t seq[8 * LIN_MAXLEN + 8];
+			for (int k = 0; k < 7; k++)
+				seq[k] = k == e;
+			for (int k = 7; k < 8 * LIN_MAXLEN; k++) {
+				uint32_t x = 0;
+				for (int j = 0; j < 7; j++)
+					if ((taps >> j) & 1)
+						x ^= seq[k - 7 + j];
+				seq[k] = (uint8_t)x;
+			}
+			uint32_t crc = 0;
+			for (int L = 1; L < LIN_MAXLEN; L++) {
+				uint32_t byte = 0;
+				for (int j = 0; j < 8; j++)
+					byte |= (uint32_t)seq[8 * (L - 1) + j] << j;
+				crc = host_crc_byte(crc, byte);
+				lin[L * 16 + 8 + e] = (uint16_t)crc;
+			}
+		}
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lin), lin, sizeof(lin)));
+	}
 	ChainTables c;
 	memset(&c, 0, sizeof(c));
 	for (int j = 0; j < 256; j++)
@@ -70,18 +187,6 @@ __device__ __forceinline__ uint32_t wh_start_const(uint32_t clock, uint32_t skip
 	return (g_chain.whiten_idx[clock & 63] + skip) % 127u;
 }
 
-// Per-workgroup LDS copies of the small tables the decoders index with per-lane values inside
-// their inner loops (whitening slice, CRC byte / word step, FEC 2/3 parity and correction): a DS read
-// instead of a divergent constant-memory load or a 10-step loop.  3.6 KiB, built by
-// chain_lds_init() at kernel start.
-struct ChainLds {
-	uint32_t wh32[128];        // 32 whitening bits from phase idx (idx <= 126)
-	uint16_t crc[256];         // crc_byte(0, x): one byte through the reflected CRC-CCITT register
-	uint16_t crc_z[3][256];    // the same followed by 1, 2, 3 zero bytes (slicing: four bytes per step)
-	uint8_t  par23[1024];      // FEC 2/3 parity of 10 data bits
-	int8_t   fix23[32];
-	uint8_t  whiten_idx[64];
-};
 __shared__ ChainLds g_lds;
 
 __device__ __forceinline__ uint64_t wh_bits(uint32_t idx, uint32_t n)
@@ -175,27 +280,11 @@ __device__ __forceinline__ bool fec23_block(uint32_t blk, uint32_t &data)
 // all threads of the workgroup; ends with a barrier
 __device__ void chain_lds_init()
 {
-	for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
-		g_lds.wh32[i] = (uint32_t)wh_bits_const(i < 127 ? i : 0, 32);
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-		uint32_t c = crc_byte_calc(0, i);
-		g_lds.crc[i] = (uint16_t)c;
-		for (int k = 0; k < 3; k++) {
-			c = crc_byte_calc(c, 0);
-			g_lds.crc_z[k][i] = (uint16_t)c;
-		}
-	}
-	for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
-		uint32_t par = 0;
-		for (int b = 0; b < 10; b++)
-			if ((i >> b) & 1)
-				par ^= g_chain.fec23_par[b];
-		g_lds.par23[i] = (uint8_t)par;
-	}
-	for (uint32_t i = threadIdx.x; i < 32; i += blockDim.x)
-		g_lds.fix23[i] = g_chain.fec23_fix[i];
-	for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
-		g_lds.whiten_idx[i] = g_chain.whiten_idx[i];
+	static_assert(sizeof(ChainLds) % 16 == 0, "the image is copied 16 bytes at a time");
+	const uint4 *src = reinterpret_cast<const uint4 *>(&g_chain_lds_image);
+	uint4 *dst = reinterpret_cast<uint4 *>(&g_lds);
+	for (uint32_t i = threadIdx.x; i < sizeof(ChainLds) / 16; i += blockDim.x)
+		dst[i] = src[i];
 	__syncthreads();
 }
 
@@ -657,107 +746,199 @@ __device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
 
 // ---- kernels --------------------------------------------------------------------------------
 
-// one wave per packet (four packets per workgroup), one lane per CLK1-6 candidate
-__global__ __launch_bounds__(256) void trials_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
-						      uint32_t n_packets, btbbx_trial *trials)
-{
-	// the wave's packet goes to LDS first: all 64 candidate clocks pick bits out of the same 50 words
-	__shared__ uint64_t pkt_lds[4][BTBBX_PKT_WORDS + 2];
-	uint32_t pkt = blockIdx.x * 4 + (threadIdx.x >> 6);
-	uint32_t clock = threadIdx.x & 63;
-	if (clock < BTBBX_PKT_WORDS + 2)
-		pkt_lds[threadIdx.x >> 6][clock] = (pkt < n_packets && clock < BTBBX_PKT_WORDS)
-			? packets[(uint64_t)pkt * BTBBX_PKT_WORDS + clock] : 0;
-	chain_lds_init();
-	if (pkt >= n_packets)
-		return;
-	const btbbx_pkt_in pi = in[pkt];
-	PState s;
-	s.w = pkt_lds[threadIdx.x >> 6];
-	s.length = (int)pi.length;
-	s.flags = pi.flags;
-	s.uap = pi.uap;
-	s.type = pi.type;
-	s.llid = pi.llid;
-	s.flow = pi.flow;
-	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
-	s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
-	s.out = nullptr;
-	s.written = 0;
-	uint32_t dis;
-	uint32_t hdr = header_fec13(s.w, dis);
-	uint32_t uap = do_try_clock(s, clock, hdr, dis);
-	int rv = do_crc_check<false>(s, clock);
-	btbbx_trial t;
-	t.uap = (uint8_t)uap;
-	t.type = (uint8_t)s.type;
-	t.rv = (int16_t)rv;
-	trials[(uint64_t)pkt * 64 + clock] = t;
-}
-
-// The throughput shape for large batches (BASELINE config 5: 10^6 detected packets).  Wrong candidate
-// clocks turn the 4 type bits into noise, so the 64 trials of one packet spread over all sixteen
-// decoders: in trials_kernel a wave executes up to nine different paths one after the other with a
-// few lanes each, and the long ones (the CRC over 187 / 343 bytes of DH3 / DH5) run at ~6 % lane use.
-// Here a workgroup takes TB_PACKETS packets = 64 x TB_PACKETS trials:
-//   1. try_clock for every trial, lane = clock (dense, one path): UAP and type;
-//   2. a counting sort of the trial numbers by type, in LDS;
-//   3. crc_check over the sorted list: a wave's 64 consecutive entries are trials of ONE type (except
-//      at the few type boundaries), so every decoder runs with full lanes;
-//   4. results back in (packet, clock) order, coalesced.
-// Trials are independent of each other (the one cross-trial dependency of the reference, EV4 reading
-// the llid / flow a previous trial left, cannot change a result -- see do_EV4), so the order in which
-// they run is free.
-#ifndef TB_PACKETS
-#define TB_PACKETS 16          /* measured: 64 -> 4.09 ms, 32 -> 2.49, 16 -> 2.13, 8 -> 4.20 per 2^20 packets (occupancy vs bucket size) */
+// The throughput shape for large batches (BASELINE config 5: 10^6 detected packets).  What a trial's crc_check
+// spends its time on when it is run as written (do_crc_check above) -- FEC 2/3 over up to 183 blocks, whitening, a CRC over up to 343 bytes
+// -- does not depend on the clock candidate except through two XORs:
+//   * FEC 2/3 is undone BEFORE whitening (:898-958), so the decoded bits, and which block fails first, are
+//     properties of the packet;
+//   * the CRC register is GF(2)-linear:  reg(seed, data ^ whitening, L bytes)
+//         = A^L(seed)  ^  reg(0, data, L)  ^  reg(0, whitening, L),
+//     the first from g_il (eight 16-bit terms selected by the UAP), the last from g_pw.
+// So a workgroup first works out, once per packet, the decoded bytes of the two FEC 2/3 layouts (payload at
+// 122, DV data at 202), their first failing block, the HV1 verdict, and reg(0, data, 4i) for every fourth
+// byte count of the three data layouts (raw, FEC at 122, FEC at 202) -- and a DM / DH / FHS trial is then a
+// payload header, a length, a handful of table reads and a compare.  EV4 (which scans for the first byte
+// count whose CRC is zero) still walks bytes, but bytes that are already decoded.
+#ifndef TL_THREADS
+#define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
 #endif
-#define TB_TRIALS  (TB_PACKETS * 64)
-#ifndef TB_WAVES_ATTR
-#define TB_WAVES_ATTR
+#define TL_PACKETS (TL_THREADS / 16)
+#ifndef TL_WGS_PER_CU
+#define TL_WGS_PER_CU 1
 #endif
-__global__ __launch_bounds__(256) TB_WAVES_ATTR void trials_bucket_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+#define TL_TRIALS  (TL_PACKETS * 64)
+#define TL_A_BLOCKS 183                     // DM5: 228 bytes = 1824 bits
+#define TL_A_BYTES  232                     // >= 229, multiple of 4
+#define TL_B_BLOCKS 10                      // DV: 12 bytes
+#define TL_B_BYTES  16
+#ifdef TL_PROFILE
+__device__ unsigned long long g_tl_prof[8];
+// per-workgroup counters in LDS (global atomics here would sit in the same in-order queue as the loads the
+// kernel waits for, and the profile would show their latency instead of the kernel's)
+#define TL_PROF_START __shared__ uint32_t tl_acc[8]; if (threadIdx.x < 8) tl_acc[threadIdx.x] = 0; uint64_t tl_t = __builtin_readcyclecounter()
+#define TL_PROF(k) do { const uint64_t n_ = __builtin_readcyclecounter(); if (tid == 0) tl_acc[k] += (uint32_t)(n_ - tl_t); tl_t = n_; } while (0)
+#define TL_PROF_END do { __syncthreads(); if (tid < 8) atomicAdd(&g_tl_prof[tid], (unsigned long long)tl_acc[tid]); } while (0)
+#else
+#define TL_PROF_START do { } while (0)
+#define TL_PROF(k) do { } while (0)
+#define TL_PROF_END do { } while (0)
+#endif
+__global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 							     uint32_t n_packets, btbbx_trial *trials)
 {
-	// 51 words per row: in step 3 the lanes of a wave read the same word of 64 DIFFERENT packets, and an
-	// odd pitch (in 8-byte units) puts those on 32 different bank pairs (with 52 it was 8-way conflicts)
-	__shared__ uint64_t pk[TB_PACKETS][BTBBX_PKT_WORDS + 1];
-	__shared__ btbbx_pkt_in pin[TB_PACKETS];
-	__shared__ uint32_t hdr_ut[TB_PACKETS];         // per packet: U(header) | type << 8 | FEC 1/3 ok << 16
-	__shared__ uint16_t clk_ut[64];                 // per clock:  U(whitening bits) | their type bits << 8
-	__shared__ uint16_t order[TB_TRIALS];           // trial numbers, grouped by type
-	__shared__ uint16_t t_slot[TB_TRIALS];          // rank of a trial among the trials of its type
-	__shared__ uint8_t t_uap[TB_TRIALS], t_type[TB_TRIALS], t_ret[TB_TRIALS];
-	__shared__ int16_t t_rv[TB_TRIALS];
+	__shared__ uint64_t pk[TL_PACKETS][BTBBX_PKT_WORDS + 1];
+	__shared__ __attribute__((aligned(8))) btbbx_pkt_in pin[TL_PACKETS];
+	__shared__ uint32_t hdr_ut[TL_PACKETS];
+	__shared__ uint16_t clk_ut[64];
+	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];   // register after the 20 whitening bytes of an FHS attempt
+	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
+	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
+	__shared__ uint8_t t_uap[TL_TRIALS], t_type[TL_TRIALS], t_ret[TL_TRIALS];
+	__shared__ int16_t t_rv[TL_TRIALS];
 	__shared__ uint32_t type_count[16], type_base[16];
+	// per packet
+	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
+	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];       // ... DV data at 202
+	__shared__ uint32_t a_bytes[TL_PACKETS][TL_A_BYTES / 4], b_bytes[TL_PACKETS][TL_B_BYTES / 4];
+	__shared__ uint32_t a_fail[TL_PACKETS], b_fail[TL_PACKETS]; // first undecodable block
+	__shared__ uint16_t p4a[TL_PACKETS][TL_A_BYTES / 4], p4b[TL_PACKETS][TL_B_BYTES / 4], p4c[TL_PACKETS][LIN_MAXLEN / 4];
+	__shared__ int8_t hv_rv[TL_PACKETS];
+	__shared__ uint16_t chunk_reg[TL_PACKETS][20];
 	const uint32_t tid = threadIdx.x, lane = tid & 63;
-	const uint32_t first = blockIdx.x * TB_PACKETS;
-	const uint32_t mine = n_packets - first < TB_PACKETS ? n_packets - first : TB_PACKETS;
-
-	for (uint32_t i = tid; i < TB_PACKETS * (BTBBX_PKT_WORDS + 1); i += 256) {
-		const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
-		pk[p][w] = (p < mine && w < BTBBX_PKT_WORDS) ? packets[(uint64_t)(first + p) * BTBBX_PKT_WORDS + w] : 0;
-	}
-	if (tid < mine)
-		pin[tid] = in[first + tid];
-	if (tid < 16)
-		type_count[tid] = 0;
+	TL_PROF_START;
+	// tables once per workgroup (the workgroups are persistent: each takes every gridDim.x-th batch)
+	for (uint32_t i = tid; i < LIN_MAXLEN * 2; i += TL_THREADS)
+		reinterpret_cast<uint4 *>(lin)[i] = reinterpret_cast<const uint4 *>(g_lin)[i];
 	chain_lds_init();                                       // ends with a barrier
+	if (tid >= 64 && tid < 128) {
+		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
+		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
+		const uint32_t v = (uint32_t)wh_bits(wh_start(tid - 64, 18), 7);
+		uint32_t x = 0;
+		for (int j = 0; j < 7; j++)
+			if ((v >> j) & 1)
+				x ^= lin[20 * 16 + 8 + j];
+		pw20[tid - 64] = (uint16_t)x;
+	}
+	const uint32_t n_batches = (n_packets + TL_PACKETS - 1) / TL_PACKETS;
+	// a batch is 16 x 51 packet words + 16 x 2 words of btbbx_pkt_in, four per thread; the next batch's words fly
+	// while this one is worked on (all of them the same kind of guarded load: anything the compiler has to merge
+	// with an old value, or may re-issue at its use, ends up waited for right behind the prefetch)
+	constexpr uint32_t PK_ELEMS = TL_PACKETS * (BTBBX_PKT_WORDS + 1), IN_ELEMS = TL_PACKETS * sizeof(btbbx_pkt_in) / 8;
+	constexpr uint32_t PER_THREAD = (PK_ELEMS + IN_ELEMS + TL_THREADS - 1) / TL_THREADS;
+	static_assert(sizeof(btbbx_pkt_in) == 16, "two words per btbbx_pkt_in");
+	uint64_t pre[PER_THREAD];
+	// every load unconditional, from a clamped address (validity is applied when the words go to LDS)
+	auto fetch = [&](uint32_t b) {
+		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
+#pragma unroll
+		for (uint32_t k = 0; k < PER_THREAD; k++) {
+			const uint32_t i = tid + TL_THREADS * k;
+			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1), e = i - PK_ELEMS;
+			const uint64_t *src = packets;
+			if (i < PK_ELEMS) {
+				if (p < have && w < BTBBX_PKT_WORDS)
+					src = packets + (uint64_t)(f + p) * BTBBX_PKT_WORDS + w;
+			} else if (e < 2 * have) {
+				src = reinterpret_cast<const uint64_t *>(in) + (uint64_t)f * 2 + e;
+			}
+			pre[k] = *src;
+		}
+	};
+	// the prefetched words of batch b go to LDS (and the per-batch counters are reset)
+	auto stage_in = [&](uint32_t b) {
+		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
+#pragma unroll
+		for (uint32_t k = 0; k < PER_THREAD; k++) {
+			const uint32_t i = tid + TL_THREADS * k;
+			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
+			if (i < PK_ELEMS)
+				pk[p][w] = (p < have && w < BTBBX_PKT_WORDS) ? pre[k] : 0;
+			else if (i < PK_ELEMS + IN_ELEMS)
+				reinterpret_cast<uint64_t *>(pin)[i - PK_ELEMS] = pre[k];
+		}
+		if (tid < 16)
+			type_count[tid] = 0;
+		if (tid < TL_PACKETS) {
+			a_fail[tid] = TL_A_BLOCKS;
+			b_fail[tid] = TL_B_BLOCKS;
+		}
+	};
+	fetch(blockIdx.x);
+	stage_in(blockIdx.x);
+	fetch(blockIdx.x + gridDim.x);
+	for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+	const uint32_t first = batch * TL_PACKETS;
+	const uint32_t mine = n_packets - first < TL_PACKETS ? n_packets - first : TL_PACKETS;
 
-	// 1a. once per packet (lane = packet) and once per clock (lane = clock): uap_from_hec (:693-705) and the
-	// type field are GF(2)-linear in the 18 header bits and unwhitening XORs a clock-dependent constant onto
-	// them, so try_clock(c) = U(header) ^ U(whitening bits of c) -- as in uap_table_kernel
+	__syncthreads();                                        // this batch is in LDS, the previous batch's results are read
+	TL_PROF(0);
+
+	// 1. try_clock (:1178-1195).  uap_from_hec (:693-705) and the type field are GF(2)-linear in the 18 header
+	// bits and unwhitening XORs a clock-dependent constant onto them, so try_clock(c) = U(header) ^ U(whitening
+	// bits of c): one U per packet here, one per clock in clk_ut (as in uap_table_kernel), one XOR per trial below.
+	// Wrong candidate clocks turn the 4 type bits into noise, so the 64 trials of a packet spread over all
+	// sixteen decoders: the trial numbers are counting-sorted by type (LDS atomics) and step 3 walks them in
+	// that order, a wave's 64 consecutive entries being trials of ONE type except at the few type boundaries.
+	// (Trials are independent of each other -- the one cross-trial dependency of the reference, EV4 reading
+	// the llid / flow a previous trial left, cannot change a result, see do_EV4 -- so their order is free.)
 	if (tid < mine) {
 		uint32_t dis;
 		const uint32_t hdr = header_fec13(pk[tid], dis);
 		hdr_ut[tid] = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
-	} else if (tid >= 64 && tid < 128) {
-		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
-		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
+	}
+	// 2a. FEC 2/3 of both layouts: sixteen threads per packet (one quarter of a wave), sixteen blocks of the
+	// payload layout per round, and no further round once a block of the packet has failed -- nothing behind
+	// the first undecodable block can matter to any trial, and in the noise behind a short packet half of
+	// all blocks fail.  HV1 verdict (:1131-1150).
+	static_assert(TL_THREADS == 16 * TL_PACKETS, "sixteen threads per packet");
+	{
+		const uint32_t p = tid >> 4, sub = tid & 15;
+		if (p < mine) {
+			uint32_t d;
+			if (sub < TL_B_BLOCKS) {
+				if (!fec23_block((uint32_t)pk_bits(pk[p], 202 + 15 * sub, 15), d))
+					atomicMin(&b_fail[p], sub);
+				b10[p][sub] = (uint16_t)d;
+			}
+			for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
+				const uint32_t k = k0 + sub;
+				if (k < TL_A_BLOCKS) {
+					if (!fec23_block((uint32_t)pk_bits(pk[p], 122 + 15 * k, 15), d))
+						atomicMin(&a_fail[p], k);
+					a10[p][k] = (uint16_t)d;
+				}
+				// the sixteen lanes are in one wave and a wave's LDS operations complete in order: its
+				// atomics above are done when this read is served
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				if (*(volatile uint32_t *)&a_fail[p] < k0 + 16)
+					break;
+			}
+		}
+	}
+	if (tid >= 128 && tid < 128 + mine) {
+		const uint32_t p = tid - 128;
+		int rv = 1;
+		if ((int)pin[p].length - 122 >= 240) {
+			uint32_t total = 0;
+			for (int i = 0; i < 4; i++) {
+				uint32_t dis;
+				(void)fec13(pk_bits(pk[p], 122 + 60 * i, 60), 20, dis);
+				total += dis;
+			}
+			rv = total < 20 ? 2 : 0;
+		}
+		hv_rv[p] = (int8_t)rv;
 	}
 	__syncthreads();
-	// 1b. every trial: UAP, type, and its rank among the trials of that type (one LDS atomic)
+	TL_PROF(1);
+	// 32-bit words of the payload layout that lie in front of the packet's first undecodable block (+ the one it starts in)
+	auto a_words = [&](uint32_t p) {
+		const uint32_t blocks = a_fail[p] < TL_A_BLOCKS ? a_fail[p] : TL_A_BLOCKS, n = (blocks * 10 + 31) / 32 + 1;
+		return n < TL_A_BYTES / 4 ? n : (uint32_t)(TL_A_BYTES / 4);
+	};
 	const uint32_t total = mine * 64;
-	for (uint32_t i = tid; i < total; i += 256) {
+	for (uint32_t i = tid; i < total; i += TL_THREADS) {
 		const uint32_t p = i >> 6;
 		const uint32_t h = hdr_ut[p];
 		uint32_t uap = pin[p].uap, type = pin[p].type, ret = 0;     // FEC 1/3 failure: nothing changes
@@ -771,7 +952,25 @@ __global__ __launch_bounds__(256) TB_WAVES_ATTR void trials_bucket_kernel(const 
 		t_ret[i] = (uint8_t)ret;
 		t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
 	}
+	// 2b. the decoded bits as bytes (four per thread and step), as far as they decode
+	for (uint32_t i = tid; i < mine * (TL_A_BYTES / 4 + TL_B_BYTES / 4); i += TL_THREADS) {
+		const uint32_t p = i / (TL_A_BYTES / 4 + TL_B_BYTES / 4), q = i % (TL_A_BYTES / 4 + TL_B_BYTES / 4);
+		const bool isb = q >= TL_A_BYTES / 4;
+		const uint32_t word = isb ? q - TL_A_BYTES / 4 : q;
+		if (!isb && word >= a_words(p))
+			continue;
+		const uint16_t *src = isb ? b10[p] : a10[p];
+		const uint32_t nblk = isb ? TL_B_BLOCKS : TL_A_BLOCKS;
+		// bits 32 word .. 32 word + 31 of the 10-bit groups
+		const uint32_t bit = 32 * word, k0 = bit / 10, sh = bit % 10;
+		uint64_t acc = 0;
+		for (uint32_t j = 0; j < 5; j++)
+			acc |= (uint64_t)(k0 + j < nblk ? src[k0 + j] : 0) << (10 * j);
+		const uint32_t v = (uint32_t)(acc >> sh);
+		if (isb) b_bytes[p][word] = v; else a_bytes[p][word] = v;
+	}
 	__syncthreads();
+	TL_PROF(2);
 	if (tid == 0) {
 		uint32_t run = 0;
 		for (uint32_t t = 0; t < 16; t++) {
@@ -779,37 +978,221 @@ __global__ __launch_bounds__(256) TB_WAVES_ATTR void trials_bucket_kernel(const 
 			run += type_count[t];
 		}
 	}
+	// 2c. reg(0, data, 4 i) for the three layouts (raw: 86 words, FEC at 122: 58, FEC at 202: 4), in chunks of
+	// eight words = twenty chunks per packet: (i) every chunk's own register from 0, all in parallel; (ii) per
+	// layout the chunk starts, start' = adv32(start) ^ chunk (a dozen dependent steps instead of 86);
+	// (iii) every chunk again from its start, storing the register in front of each word
+	// task t -> (packet, chunk slot r, layout, chunk j, words): raw and DV chunks first (12 per packet), then the
+	// payload-layout chunks, of which a packet needs only those in front of its first failing block
+	auto chunk_of = [&](uint32_t t, uint32_t &p, uint32_t &r, uint32_t &layout, uint32_t &j, uint32_t &nwords) {
+		if (t < mine * 12) {
+			p = t / 12;
+			j = t % 12;
+			if (j < 11) { layout = 0; r = j; nwords = j < 10 ? 8 : LIN_MAXLEN / 4 - 80; }
+			else { layout = 2; r = 19; j = 0; nwords = TL_B_BYTES / 4; }
+		} else {
+			const uint32_t u = t - mine * 12;
+			p = u / 8;
+			j = u % 8;
+			layout = 1;
+			r = 11 + j;
+			const uint32_t need = a_words(p);
+			nwords = need > 8 * j ? (need - 8 * j < 8 ? need - 8 * j : 8) : 0;
+		}
+	};
+	auto data_word = [&](uint32_t p, uint32_t layout, uint32_t i) {
+		return layout == 0 ? (uint32_t)pk_bits(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
+	};
+	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
+		uint32_t p, r, layout, j, nwords, crc = 0;
+		chunk_of(t, p, r, layout, j, nwords);
+		if (!nwords)
+			continue;
+		uint32_t w8[8];
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++)                   // all eight words first: one LDS round trip, not eight
+			w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++)
+			if (i < nwords)
+				crc = crc_word(crc, w8[i]);
+		chunk_reg[p][r] = (uint16_t)crc;
+	}
 	__syncthreads();
-	// 2. the trial numbers in type order
-	for (uint32_t i = tid; i < total; i += 256)
+	if (tid >= 64 && tid < 64 + 3 * mine) {
+		const uint32_t p = (tid - 64) / 3, layout = (tid - 64) % 3;
+		const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
+		const uint32_t n = layout == 0 ? 11 : layout == 1 ? (a_words(p) + 7) / 8 : 1;
+		uint32_t start = 0;
+		for (uint32_t j = 0; j < n; j++) {
+			const uint32_t c = chunk_reg[p][r0 + j];
+			chunk_reg[p][r0 + j] = (uint16_t)start;
+			start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
+		uint32_t p, r, layout, j, nwords;
+		chunk_of(t, p, r, layout, j, nwords);
+		if (!nwords)
+			continue;
+		uint32_t crc = chunk_reg[p][r];
+		uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
+		uint32_t w8[8];
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++)
+			w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
+#pragma unroll
+		for (uint32_t i = 0; i < 8; i++)
+			if (i < nwords) {
+				dst[8 * j + i] = (uint16_t)crc;
+				crc = crc_word(crc, w8[i]);
+			}
+	}
+	__syncthreads();
+	TL_PROF(3);
+	for (uint32_t i = tid; i < total; i += TL_THREADS)
 		order[type_base[t_type[i] & 15] + t_slot[i]] = (uint16_t)i;
 	__syncthreads();
-	// 3. crc_check in type order: a wave's 64 consecutive entries are (nearly always) one decoder
-	for (uint32_t k = tid; k < total; k += 256) {
-		const uint32_t i = order[k], p = i >> 6, clock = i & 63;
-		PState s;
-		s.w = pk[p];
-		s.length = (int)pin[p].length;
-		s.flags = pin[p].flags;
-		s.uap = t_uap[i];
-		s.type = t_type[i];
-		s.llid = pin[p].llid;
-		s.flow = pin[p].flow;
-		s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
-		s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
-		s.out = nullptr;
-		s.written = 0;
-		t_rv[i] = (int16_t)do_crc_check<false>(s, clock);
+	TL_PROF(4);
+
+	// 3. crc_check (:708-769) in type order
+	for (uint32_t kk = tid; kk < total; kk += TL_THREADS) {
+		const uint32_t i = order[kk], p = i >> 6, clock = i & 63;
+		const uint32_t type = t_type[i], uap = t_uap[i];
+		const bool wht = pin[p].flags & F_WHITENED;
+		const int size = (int)pin[p].length - 122;
+		const uint32_t seed = crc_seed(uap);
+		// what seed and whitening contribute to the register after L bytes: the terms of row L that the
+		// seed's eight bits and the seven first whitening bits of this clock select
+		const uint32_t sel = (seed >> 8) | (wht ? (uint32_t)wh_bits(wh_start(clock, 18), 7) << 8 : 0u);
+		auto seed_row20 = [&](uint32_t sd) {                   // the seed's terms of row 20 alone (FHS tries other clocks)
+			const uint4 r0 = reinterpret_cast<const uint4 *>(lin)[40];
+			const uint32_t r[4] = {r0.x, r0.y, r0.z, r0.w};
+			uint32_t x = 0;
+#pragma unroll
+			for (int bit = 0; bit < 8; bit++)
+				x ^= (0u - ((sd >> (8 + bit)) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
+			return x & 0xffff;
+		};
+		auto lin_terms = [&](uint32_t L) {
+			uint32_t x = 0;
+#pragma unroll 1
+			for (int half = 0; half < 2; half++) {             // (one 16-byte row half at a time: VGPR ceiling)
+				const uint4 q = reinterpret_cast<const uint4 *>(lin)[2 * L + half];
+				const uint32_t r[4] = {q.x, q.y, q.z, q.w};
+				const uint32_t sl = sel >> (8 * half);
+#pragma unroll
+				for (int bit = 0; bit < 8; bit++)
+					x ^= (0u - ((sl >> bit) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
+			}
+			return x & 0xffff;
+		};
+		// reg(0, data, L) from the every-fourth-byte table and up to three more bytes
+		auto data_reg = [&](int layout, uint32_t L) {
+			const uint32_t q = L >> 2, r = L & 3;
+			uint32_t crc, w;
+			if (layout == 0) { crc = p4c[p][q]; w = r ? (uint32_t)pk_bits(pk[p], 122 + 32 * q, 32) : 0; }
+			else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
+			else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
+			for (uint32_t j = 0; j < r; j++)
+				crc = crc_byte(crc, (w >> (8 * j)) & 0xff);
+			return crc;
+		};
+		auto crc_is_zero = [&](int layout, uint32_t L) {
+			return (data_reg(layout, L) ^ lin_terms(L)) == 0;
+		};
+		int rv = 1;
+		switch (type) {
+		case 2: {                                               // fhs (:783-818)
+			if (size < 240) { rv = 1; break; }
+			if (a_fail[p] < 16) { rv = 0; break; }
+			const uint32_t x = p4a[p][5] ^ seed_row20(seed);        // zero register <=> x == reg(0, whitening of the attempt, 20)
+			rv = 0;
+			if (!wht) {
+				if (x == 0) rv = 1000;
+			} else {
+				if (x == pw20[clock]) rv = 1000;
+				for (uint32_t c = 32; c < 64 && rv == 0; c++)
+					if (x == pw20[c]) rv = 1000;
+			}
+			break;
+		}
+		case 3: case 8: case 10: case 14:                       // DM (:898-958)
+		case 4: case 11: case 15: {                             // DH (:962-1011)
+			const bool fec = type == 3 || type == 8 || type == 10 || type == 14;
+			const int layout = !fec ? 0 : (type == 8 ? 2 : 1);
+			const int psize = type == 8 ? size - 80 : size;
+			const int hb = (type == 3 || type == 8 || type == 4) ? 1 : 2;
+			const int hbits = 8 * hb;
+			const uint32_t fail = layout == 2 ? b_fail[p] : a_fail[p];
+			rv = 0;
+			if (psize < hbits) break;                           // decode_payload_header (:821-895) gives up
+			uint32_t raw;
+			if (fec) {
+				if (psize < (hb == 2 ? 30 : 15)) break;
+				if (fail < (uint32_t)hb) break;
+				raw = (layout == 2 ? b_bytes[p][0] : a_bytes[p][0]) & ((1u << hbits) - 1);
+			} else {
+				raw = (uint32_t)pk_bits(pk[p], 122, hbits);
+			}
+			const uint32_t ph = raw ^ (wht ? (uint32_t)wh_bits(wh_start(clock, 18), hbits) : 0u);
+			int plen = hb == 2 ? (int)((ph >> 3) & 0x3ff) + 4 : (int)((ph >> 3) & 0x1f) + 3;
+			int cap;
+			switch (type) {
+			case 3:  cap = 20;  break;
+			case 4:  cap = 30;  break;
+			case 8:  cap = 12;  break;
+			case 10: cap = 125; break;
+			case 11: cap = 187; break;
+			case 14: cap = 228; break;
+			default: cap = 343; break;
+			}
+			if (plen > cap) plen = cap;
+			const int nbits = plen * 8;
+			if (nbits > psize) { rv = 1; break; }
+			if (fec && fail < (uint32_t)(nbits + 9) / 10) break; // a block of the payload does not decode
+			rv = crc_is_zero(layout, (uint32_t)plen) ? 10 : 2;
+			break;
+		}
+		case 12: {                                              // EV4 (:1044-1097)
+			// iterations b = 0 .. B-1 of the reference's block loop get past its two checks
+			uint32_t B = size >= 15 ? (uint32_t)size / 15 : 0;
+			if (B > 98) B = 98;
+			if (B > a_fail[p]) B = a_fail[p];
+			const uint32_t lmax = B ? 5 * (B - 1) / 4 : 0;        // bytes L-1 with ceil(4 L / 5) <= B - 1 are reached
+			uint32_t crc = seed, idx = wh_start(clock, 18);
+			rv = B == 98 ? 2 : 1;
+			for (uint32_t L = 1; L <= lmax; L++) {
+				const uint32_t byte = (a_bytes[p][(L - 1) >> 2] >> (8 * ((L - 1) & 3))) & 0xff;
+				crc = crc_byte(crc, byte ^ (wht ? (uint32_t)wh_bits(idx, 8) : 0u));
+				idx = idx + 8 >= 127 ? idx + 8 - 127 : idx + 8;
+				if (L >= 2 && crc == 0) { rv = 10; break; }
+			}
+			break;
+		}
+		case 5: rv = hv_rv[p]; break;                           // HV1
+		default: rv = 1; break;                                 // EV3 / EV5 always map to 1, the rest is not checked
+		}
+		if (rv == 0 && type != 2 && type != 3 && type != 5)
+			rv = 1;
+		t_rv[i] = (int16_t)rv;
 	}
 	__syncthreads();
-	// 4. out, in (packet, clock) order
-	for (uint32_t i = tid; i < total; i += 256) {
-		btbbx_trial t;
-		t.uap = t_ret[i];
-		t.type = t_type[i];
-		t.rv = t_rv[i];
-		trials[(uint64_t)first * 64 + i] = t;
+	TL_PROF(5);
+	// The next batch moves in and the one after that is requested BEFORE this batch's results are stored: gfx9
+	// counts loads and stores in one in-order counter, so a wait for prefetched words that comes after the
+	// stores also waits for the stores (47 % of the kernel when it was written the other way round).
+	stage_in(batch + gridDim.x);
+	fetch(batch + 2 * gridDim.x);
+	// 4. out, in (packet, clock) order (the t_* arrays are not touched before the barrier at the loop top)
+	static_assert(sizeof(btbbx_trial) == 4, "one dword per trial");
+	for (uint32_t i = tid; i < total; i += TL_THREADS)
+		reinterpret_cast<uint32_t *>(trials)[(uint64_t)first * 64 + i] =
+			(uint32_t)t_ret[i] | ((uint32_t)t_type[i] << 8) | ((uint32_t)(uint16_t)t_rv[i] << 16);
+	TL_PROF(6);
 	}
+	TL_PROF_END;
 }
 
 // Small batches (a handful of packets from a live receiver): one workgroup per (packet, clock),
@@ -1334,15 +1717,28 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 		return rc;
 	if (!n_packets)
 		return BTBBX_OK;
-	if (n_packets <= 256)        // latency shape while 64 n waves are only a few rounds over the chip
+	if (n_packets <= 256) {      // latency shape while 64 n waves are only a few rounds over the chip
 		hipLaunchKernelGGL(trials_wide_kernel, dim3(n_packets * 64), dim3(64), 0, (hipStream_t)hip_stream,
 				   d_packets, d_in, n_packets, d_trials);
-	else if (n_packets < 4096)   // a wave per packet still fills the chip
-		hipLaunchKernelGGL(trials_kernel, dim3((n_packets + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream,
-				   d_packets, d_in, n_packets, d_trials);
-	else                         // trials bucketed by packet type: every decoder runs with full lanes
-		hipLaunchKernelGGL(trials_bucket_kernel, dim3((n_packets + TB_PACKETS - 1) / TB_PACKETS), dim3(256), 0,
+	} else {                     // per-packet FEC / CRC prefix work once, O(1) per DM / DH / FHS trial
+		const uint32_t batches = (n_packets + TL_PACKETS - 1) / TL_PACKETS;
+		const uint32_t resident = (uint32_t)ctx().num_cus * TL_WGS_PER_CU;
+		hipLaunchKernelGGL(trials_linear_kernel, dim3(batches < resident ? batches : resident), dim3(TL_THREADS), 0,
 				   (hipStream_t)hip_stream, d_packets, d_in, n_packets, d_trials);
+	}
+#ifdef TL_PROFILE
+	if (n_packets > 256) {
+		unsigned long long prof[8], tot = 0;
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_tl_prof), sizeof(prof));
+		for (int k = 0; k < 8; k++) tot += prof[k];
+		fprintf(stderr, "trials profile:");
+		for (int k = 0; k < 7; k++) fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)prof[k] / (double)(tot ? tot : 1));
+		fprintf(stderr, "\n");
+		static unsigned long long z[8];
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_prof), z, sizeof(z));
+	}
+#endif
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
