@@ -1661,13 +1661,16 @@ int launch_trials_merge(const void *d_state, const btbbx_pkt_in *d_in, btbbx_pkt
 size_t trials_state_bytes() { return 64 * sizeof(TrialState); }
 
 // cut packets out of the packed streams
-__global__ __launch_bounds__(64) void gather_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
-						     const btbbx_hit *hits, uint32_t n_packets, uint32_t max_length,
-						     uint64_t *packets, uint32_t *lengths)
+// five packets per 256-thread workgroup: thread -> (packet, output word); the output rows of a workgroup are
+// contiguous (5 x 400 bytes), so its stores coalesce across packets
+#define GATHER_PACKETS (256 / BTBBX_PKT_WORDS)
+__global__ __launch_bounds__(256) void gather_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
+						      const btbbx_hit *hits, uint32_t n_packets, uint32_t max_length,
+						      uint64_t *packets, uint32_t *lengths)
 {
-	uint32_t pkt = blockIdx.x;
-	uint32_t i = threadIdx.x;           // output word
-	if (pkt >= n_packets || i >= BTBBX_PKT_WORDS)
+	uint32_t pkt = blockIdx.x * GATHER_PACKETS + threadIdx.x / BTBBX_PKT_WORDS;
+	uint32_t i = threadIdx.x % BTBBX_PKT_WORDS;          // output word
+	if (pkt >= n_packets || threadIdx.x >= GATHER_PACKETS * BTBBX_PKT_WORDS)
 		return;
 	const btbbx_hit h = hits[pkt];
 	const uint64_t *base = words + (uint64_t)h.stream * pitch_words;
@@ -1703,8 +1706,8 @@ extern "C" int btbbx_gather_packets_device(const uint64_t *d_words, uint64_t n_w
 		return rc;
 	if (!n_packets)
 		return BTBBX_OK;
-	hipLaunchKernelGGL(gather_kernel, dim3(n_packets), dim3(64), 0, (hipStream_t)hip_stream,
-			   d_words, n_words, pitch_words, d_hits, n_packets, max_length, d_packets, d_lengths);
+	hipLaunchKernelGGL(gather_kernel, dim3((n_packets + GATHER_PACKETS - 1) / GATHER_PACKETS), dim3(256), 0,
+			   (hipStream_t)hip_stream, d_words, n_words, pitch_words, d_hits, n_packets, max_length, d_packets, d_lengths);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
