@@ -67,6 +67,31 @@ def test_trial_tables():
     assert hist.get(10, 0) > 30 and hist.get(1000, 0) > 5 and hist.get(0, 0) > 0 and hist.get(2, 0) > 0
 
 
+def test_trial_tables_large_batch():
+    """More packets than one workgroup batch holds, every trial against the oracle: the kernel for large
+    batches works the FEC 2/3 and CRC prefix of a packet out once and evaluates a trial from tables, so
+    truncated captures, junk behind short packets and unwhitened packets all take their own paths."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(47))
+    pk = _pkt.random_packets(rng, 1500, max_sym_errors=4)
+    syms = [np.ascontiguousarray(s[:bt.MAX_SYMBOLS]) for s, _ in pk]
+    words, lengths = bt.packets_to_words(syms)
+    pin = np.zeros(len(syms), bt.PKTIN_DTYPE)
+    pin["length"] = lengths
+    pin["flags"] = 1
+    pin["type"] = rng.integers(0, 16, len(syms))
+    pin["uap"] = rng.integers(0, 256, len(syms))
+    pin["flags"][::11] = 0
+    got = bt.run_trials(words, pin)
+    bad = []
+    for i, s in enumerate(syms):
+        want = _oracle_trials(orc, s, int(pin["type"][i]), int(pin["uap"][i]), int(pin["flags"][i]) & 1)
+        g = [(int(t["uap"]), int(t["type"]), int(t["rv"])) for t in got[i]]
+        if g != want:
+            bad.append((i, pk[i][1], len(s), [(j, g[j], want[j]) for j in range(64) if g[j] != want[j]][:3]))
+    assert not bad, bad[:5]
+
+
 def _oracle_decode(orc, sym, clkn, uap, clk_valid=True):
     p = orc.orc_packet_new()
     orc.orc_packet_init_found(p, 0, 0)
