@@ -772,12 +772,12 @@ __device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
 #define TL_B_BLOCKS 10                      // DV: 12 bytes
 #define TL_B_BYTES  16
 #ifdef TL_PROFILE
-__device__ unsigned long long g_tl_prof[8];
+__device__ unsigned long long g_tl_prof[16];
 // per-workgroup counters in LDS (global atomics here would sit in the same in-order queue as the loads the
 // kernel waits for, and the profile would show their latency instead of the kernel's)
-#define TL_PROF_START __shared__ uint32_t tl_acc[8]; if (threadIdx.x < 8) tl_acc[threadIdx.x] = 0; uint64_t tl_t = __builtin_readcyclecounter()
+#define TL_PROF_START __shared__ uint32_t tl_acc[16]; if (threadIdx.x < 16) tl_acc[threadIdx.x] = 0; uint64_t tl_t = __builtin_readcyclecounter()
 #define TL_PROF(k) do { const uint64_t n_ = __builtin_readcyclecounter(); if (tid == 0) tl_acc[k] += (uint32_t)(n_ - tl_t); tl_t = n_; } while (0)
-#define TL_PROF_END do { __syncthreads(); if (tid < 8) atomicAdd(&g_tl_prof[tid], (unsigned long long)tl_acc[tid]); } while (0)
+#define TL_PROF_END do { __syncthreads(); if (tid < 16) atomicAdd(&g_tl_prof[tid], (unsigned long long)tl_acc[tid]); } while (0)
 #else
 #define TL_PROF_START do { } while (0)
 #define TL_PROF(k) do { } while (0)
@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		chunk_reg[p][r] = (uint16_t)crc;
 	}
 	__syncthreads();
+	TL_PROF(8);
 	if (tid >= 64 && tid < 64 + 3 * mine) {
 		const uint32_t p = (tid - 64) / 3, layout = (tid - 64) % 3;
 		const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
@@ -1031,6 +1032,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		}
 	}
 	__syncthreads();
+	TL_PROF(9);
 	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
 		uint32_t p, r, layout, j, nwords;
 		chunk_of(t, p, r, layout, j, nwords);
@@ -1731,14 +1733,14 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 	}
 #ifdef TL_PROFILE
 	if (n_packets > 256) {
-		unsigned long long prof[8], tot = 0;
+		unsigned long long prof[16], tot = 0;
 		(void)hipDeviceSynchronize();
 		(void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_tl_prof), sizeof(prof));
-		for (int k = 0; k < 8; k++) tot += prof[k];
+		for (int k = 0; k < 16; k++) tot += prof[k];
 		fprintf(stderr, "trials profile:");
-		for (int k = 0; k < 7; k++) fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)prof[k] / (double)(tot ? tot : 1));
+		for (int k = 0; k < 10; k++) fprintf(stderr, " %d:%.1f%%", k, 100.0 * (double)prof[k] / (double)(tot ? tot : 1));
 		fprintf(stderr, "\n");
-		static unsigned long long z[8];
+		static unsigned long long z[16];
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_prof), z, sizeof(z));
 	}
 #endif
