@@ -230,6 +230,14 @@ int btbbx_uap_table_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, 
 int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uint32_t n_packets,
 			btbbx_pkt_out *d_out, void *hip_stream);
 
+/* The same for packets that still lie in the packed streams: packet i is what
+ * btbbx_gather_packets_device would cut out for d_hits[i] (same max_length, same captured
+ * length, zeros behind it), decoded without the intermediate 400-byte row.  d_in[i].length is
+ * ignored; d_lengths (may be NULL) receives the captured lengths. */
+int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+			     const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, uint32_t n_packets,
+			     uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream);
+
 /* ---- hop selection and CLK1-27 reversal ------------------------- */
 #define BTBBX_SEQUENCE_LENGTH 134217728u   /* values of CLK1-27, bluetooth_piconet.h:102 */
 

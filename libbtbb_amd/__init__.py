@@ -116,6 +116,7 @@ SIGNATURES = {
     "btbbx_gather_packets_device": (C.c_int, [_vp, _u64, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_trials_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "btbbx_decode_hits_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_uap_table_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
     "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
@@ -385,6 +386,40 @@ def run_decode(packet_words, pkt_in):
     check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
     check(lib().btbbx_sync(None))
     return d_out.download(PKTOUT_DTYPE, n)
+
+
+def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gather=False):
+    """Decode the packets that start at `hits` (HIT_DTYPE: stream, offset) of the packed streams
+    stream_words[n_streams, n_words] -> (PKTOUT_DTYPE array, captured lengths).  via_gather=True takes
+    the two-step route (btbbx_gather_packets_device + btbbx_decode_device) for comparison."""
+    stream_words = np.ascontiguousarray(stream_words, dtype=np.uint64)
+    n_streams, n_words = stream_words.shape
+    n = len(hits)
+    d_w = DeviceBuffer(stream_words.nbytes).upload(stream_words)
+    d_h = DeviceBuffer(max(hits.nbytes, 16)).upload(hits)
+    d_out = DeviceBuffer(n * PKTOUT_DTYPE.itemsize).zero()
+    d_len = DeviceBuffer(n * 4).zero()
+    pkt_in = np.array(pkt_in, copy=True)
+    try:
+        if via_gather:
+            d_pk = DeviceBuffer(n * PKT_WORDS * 8).zero()
+            check(lib().btbbx_gather_packets_device(d_w.ptr, n_words, n_words, d_h.ptr, n, max_length, d_pk.ptr,
+                                                    d_len.ptr, None), "btbbx_gather_packets_device")
+            check(lib().btbbx_sync(None))
+            lengths = d_len.download(np.uint32, n)
+            pkt_in["length"] = lengths
+            d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
+            check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
+            d_pk.free()
+        else:
+            d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
+            check(lib().btbbx_decode_hits_device(d_w.ptr, n_words, n_words, d_h.ptr, d_in.ptr, n, max_length, d_out.ptr,
+                                                 d_len.ptr, None), "btbbx_decode_hits_device")
+        check(lib().btbbx_sync(None))
+        return d_out.download(PKTOUT_DTYPE, n), d_len.download(np.uint32, n)
+    finally:
+        for b in (d_w, d_h, d_out, d_len, d_in):
+            b.free()
 
 
 # ---- hop selection / CLK1-27 reversal -------------------------------------------------------

@@ -291,7 +291,11 @@ __device__ void chain_lds_init()
 // ---- packet state -----------------------------------------------------------------------------
 
 struct PState {
-	const uint64_t *w;       // 50 packed words
+	const uint64_t *w;       // 50 packed words (a gathered packet), or -- `direct` -- the stream word the packet starts in
+	// direct mode (decode_hits_kernel): the packet is bits [sh, sh + length) of w[0 .. wlimit)
+	uint32_t sh = 0;         // bit of w[0] the packet starts at
+	uint32_t wlimit = 0;     // stream words that exist from w on
+	bool direct = false;
 	int length;              // pkt->length
 	uint32_t flags;
 	uint32_t uap, type;
@@ -312,6 +316,24 @@ struct PState {
 #define D_PLEN  2u           // payload_length
 #define D_PHL   4u           // payload_header_length
 #define D_LF    8u           // llid, flow
+
+// n (1..64) symbols of the packet from symbol pos.  A gathered packet is 50 words with zeros behind the captured
+// length; in direct mode the same view is taken of the stream itself: symbols at and behind `length` (which the
+// reference's decoders do read, :898-958) and words behind the end of the stream read as 0.
+__device__ __forceinline__ uint64_t s_bits(const PState &s, uint32_t pos, uint32_t n)
+{
+	if (!s.direct)
+		return pk_bits(s.w, pos, n);
+	if ((int)pos >= s.length)
+		return 0;
+	const uint32_t q = pos + s.sh, i = q >> 6, sft = q & 63;
+	uint64_t v = (i < s.wlimit ? s.w[i] : 0ULL) >> sft;
+	if (sft + n > 64)
+		v |= (i + 1 < s.wlimit ? s.w[i + 1] : 0ULL) << (64 - sft);
+	const uint32_t have = (uint32_t)s.length - pos;         // symbols left in front of `length`
+	const uint32_t keep = n < have ? n : have;
+	return keep == 64 ? v : v & ((1ULL << keep) - 1);
+}
 
 // streams payload bits into the CRC (whole bytes) and, when WRITE, into the output words
 template <bool WRITE>
@@ -364,11 +386,11 @@ __device__ __forceinline__ uint64_t wh(const PState &s, uint32_t idx, uint32_t n
 }
 
 // all FEC-2/3 blocks of `nblocks` decodable?
-__device__ __forceinline__ bool fec23_ok(const uint64_t *w, uint32_t pos, uint32_t nblocks)
+__device__ __forceinline__ bool fec23_ok(const PState &s, uint32_t pos, uint32_t nblocks)
 {
 	for (uint32_t k = 0; k < nblocks; k++) {
 		uint32_t d;
-		if (!fec23_block((uint32_t)pk_bits(w, pos + 15 * k, 15), d))
+		if (!fec23_block((uint32_t)s_bits(s, pos + 15 * k, 15), d))
 			return false;
 	}
 	return true;
@@ -386,7 +408,7 @@ __device__ int do_fhs(PState &s, uint32_t clock)
 	uint64_t corr[3] = {0, 0, 0};
 	for (uint32_t k = 0; k < 16; k++) {
 		uint32_t d;
-		if (!fec23_block((uint32_t)pk_bits(s.w, 122 + 15 * k, 15), d))
+		if (!fec23_block((uint32_t)s_bits(s, 122 + 15 * k, 15), d))
 			return 0;
 		uint32_t bit = 10 * k;
 		corr[bit >> 6] |= (uint64_t)d << (bit & 63);
@@ -434,13 +456,13 @@ __device__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int h
 		if (size < (header_bytes == 2 ? 30 : 15))
 			return false;
 		uint32_t d0, d1 = 0;
-		if (!fec23_block((uint32_t)pk_bits(s.w, pos, 15), d0))
+		if (!fec23_block((uint32_t)s_bits(s, pos, 15), d0))
 			return false;
-		if (header_bytes == 2 && !fec23_block((uint32_t)pk_bits(s.w, pos + 15, 15), d1))
+		if (header_bytes == 2 && !fec23_block((uint32_t)s_bits(s, pos + 15, 15), d1))
 			return false;
 		raw = (d0 | (d1 << 10)) & ((1u << hbits) - 1);
 	} else {
-		raw = (uint32_t)pk_bits(s.w, pos, hbits);
+		raw = (uint32_t)s_bits(s, pos, hbits);
 	}
 	uint32_t ph = raw ^ (uint32_t)wh(s, wh_start(clock, 18), hbits);
 	s.ph16 = (s.ph16 & ~((1u << hbits) - 1)) | ph;
@@ -488,14 +510,14 @@ __device__ int do_DM(PState &s, uint32_t clock)
 	if (nbits > size)
 		return 1;
 	uint32_t nblocks = (nbits + 9) / 10;
-	if (WRITE && !fec23_ok(s.w, pos, nblocks))      // the reference writes nothing on failure
+	if (WRITE && !fec23_ok(s, pos, nblocks))      // the reference writes nothing on failure
 		return 0;
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
 	int left = nbits;
 	for (uint32_t k = 0; k < nblocks; k++) {
 		uint32_t d;
-		if (!fec23_block((uint32_t)pk_bits(s.w, pos + 15 * k, 15), d))
+		if (!fec23_block((uint32_t)s_bits(s, pos + 15 * k, 15), d))
 			return 0;
 		uint32_t n = left < 10 ? left : 10;
 		sink.push((d ^ (uint32_t)wh(s, idx, 10)) & ((1u << n) - 1), n);
@@ -532,7 +554,7 @@ __device__ int do_DH(PState &s, uint32_t clock)
 	uint32_t idx = wh_start(clock, 18);
 	for (int done = 0; done < nbits; done += 32) {
 		uint32_t n = nbits - done < 32 ? nbits - done : 32;
-		sink.push(pk_bits(s.w, pos + done, n) ^ wh(s, idx, n), n);
+		sink.push(s_bits(s, pos + done, n) ^ wh(s, idx, n), n);
 		idx = (idx + n) % 127u;
 	}
 	sink.flush();
@@ -547,7 +569,7 @@ template <bool WRITE>
 __device__ int do_EV35(PState &s, uint32_t clock, int maxlength)
 {
 	int size = s.length - 122;
-	uint32_t first8 = (uint32_t)pk_bits(s.w, 122, 8);
+	uint32_t first8 = (uint32_t)s_bits(s, 122, 8);
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
 	int rv = 2;
@@ -590,7 +612,7 @@ __device__ int do_EV4(PState &s, uint32_t clock)
 		int syms = 15 * b, bits = 10 * b;
 		if (syms + 15 > size) { rv = 1; break; }
 		uint32_t d;
-		if (!fec23_block((uint32_t)pk_bits(s.w, 122 + syms, 15), d)) { rv = syms < 45 ? 0 : 1; break; }
+		if (!fec23_block((uint32_t)s_bits(s, 122 + syms, 15), d)) { rv = syms < 45 ? 0 : 1; break; }
 		uint64_t ten = d ^ (uint32_t)wh(s, wh_start(clock, 18 + bits), 10);
 		acc |= ten << nacc;
 		nacc += 10;
@@ -640,7 +662,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 		uint32_t data[4], total = 0;
 		for (int i = 0; i < 4; i++) {       // 80 triples = 4 x 20
 			uint32_t dis;
-			data[i] = fec13(pk_bits(s.w, 122 + 60 * i, 60), 20, dis);
+			data[i] = fec13(s_bits(s, 122 + 60 * i, 60), 20, dis);
 			total += dis;
 		}
 		if (!(total < 20))
@@ -658,7 +680,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 			if (s.written < 80) s.written = 80;
 		}
 	} else if (s.type == 6) {
-		if (!fec23_ok(s.w, 122, 16))
+		if (!fec23_ok(s, 122, 16))
 			return 0;
 		s.plen = 20;
 		s.dirty |= D_PLEN;
@@ -667,7 +689,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 			Sink<true> sink(0, s.out);
 			for (uint32_t k = 0; k < 16; k++) {
 				uint32_t d;
-				fec23_block((uint32_t)pk_bits(s.w, 122 + 15 * k, 15), d);
+				fec23_block((uint32_t)s_bits(s, 122 + 15 * k, 15), d);
 				sink.push(d ^ (uint32_t)wh(s, idx, 10), 10);
 				idx = (idx + 10) % 127u;
 			}
@@ -681,7 +703,7 @@ __device__ int do_HV(PState &s, uint32_t clock)
 		if (WRITE) {
 			Sink<true> sink(0, s.out);
 			for (int done = 0; done < 240; done += 30) {
-				sink.push(pk_bits(s.w, 122 + done, 30) ^ wh(s, idx, 30), 30);
+				sink.push(s_bits(s, 122 + done, 30) ^ wh(s, idx, 30), 30);
 				idx = (idx + 30) % 127u;
 			}
 			sink.flush();
@@ -718,6 +740,10 @@ __device__ __forceinline__ uint32_t header_fec13(const uint64_t *w, uint32_t &di
 {
 	return fec13(pk_bits(w, 68, 54), 18, disagree);
 }
+__device__ __forceinline__ uint32_t header_fec13(const PState &s, uint32_t &disagree)
+{
+	return fec13(s_bits(s, 68, 54), 18, disagree);
+}
 
 // try_clock (:1178-1195); returns the reference's return value
 __device__ __forceinline__ uint32_t do_try_clock(PState &s, uint32_t clock, uint32_t hdr, uint32_t disagree)
@@ -732,15 +758,15 @@ __device__ __forceinline__ uint32_t do_try_clock(PState &s, uint32_t clock, uint
 }
 
 // btbb_header_present (:1371-1408)
-__device__ __forceinline__ int do_header_present(const uint64_t *w, int length)
+__device__ __forceinline__ int do_header_present(const PState &s)
 {
-	if (length < 122)
+	if (s.length < 122)
 		return 0;
-	uint32_t msb = (uint32_t)pk_bits(w, 63, 1);
-	uint32_t tr = (uint32_t)pk_bits(w, 64, 4);
+	uint32_t msb = (uint32_t)s_bits(s, 63, 1);
+	uint32_t tr = (uint32_t)s_bits(s, 64, 4);
 	uint32_t want = msb ? 0xAu : 0x5u;          // !m, m, !m, m  (LSB first)
 	uint32_t errs = __popc(tr ^ want), dis;
-	(void)fec13(pk_bits(w, 68, 54), 18, dis);
+	(void)fec13(s_bits(s, 68, 54), 18, dis);
 	return (errs + dis) < 5;
 }
 
@@ -1287,11 +1313,11 @@ __global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets,
 //  replay_kernel / trials_state_kernel + trials_merge_kernel below)
 
 // header_present + decode_header / decode_payload of one packet (w = its 50 packed words)
-__device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
+// `s` arrives with its view of the packet set (w, length and, for a packet read straight from the stream, sh /
+// wlimit / direct); everything else of the entry state comes from pi and *o
+__device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
 {
-	PState s;
-	s.w = w;
-	s.length = (int)pi.length;
+
 	s.flags = pi.flags;
 	s.uap = pi.uap;
 	s.type = pi.type;
@@ -1308,14 +1334,14 @@ __device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_
 	s.written = 0;
 
 	int header_rv = 0, payload_rv = 0;
-	o->header_present = (uint8_t)do_header_present(s.w, s.length);
+	o->header_present = (uint8_t)do_header_present(s);
 
 	{
 		bool go = true;
 		if (mode & DEC_HEADER) {
 			// btbb_decode_header (:1198-1221)
 			uint32_t dis;
-			uint32_t hdr = header_fec13(s.w, dis);
+			uint32_t hdr = header_fec13(s, dis);
 			go = false;
 			if ((s.flags & F_CLK6_VALID) && dis < 4) {
 				uint32_t clear = hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18);
@@ -1368,6 +1394,14 @@ __device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_
 	o->payload_header = s.ph16;
 }
 
+__device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
+{
+	PState s;
+	s.w = w;
+	s.length = (int)pi.length;
+	decode_view(s, pi, o, mode);
+}
+
 __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 						     uint32_t n_packets, btbbx_pkt_out *outs, uint32_t mode)
 {
@@ -1376,6 +1410,38 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 	if (pkt >= n_packets)
 		return;
 	decode_one(packets + (uint64_t)pkt * BTBBX_PKT_WORDS, in[pkt], outs + pkt, mode);
+}
+
+// Decode straight from the packed streams: what gather_kernel + decode_kernel do, without the 400-byte row that
+// the first writes and the second reads back (profiles/r02_v4/pmc_secondary.json: the two moved 2.0 GB per
+// 1.29 M packets, of which the packets themselves are 0.5 GB).  One lane per hit; the captured length is the
+// gather's: min(max_length, 3125, symbols left in the stream), and d_in[i].length is ignored.
+__global__ __launch_bounds__(64) void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
+							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
+							  uint32_t max_length, btbbx_pkt_out *outs, uint32_t *lengths, uint32_t mode)
+{
+	chain_lds_init();
+	const uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pkt >= n_packets)
+		return;
+	const btbbx_hit h = hits[pkt];
+	const uint64_t total_bits = n_words * 64;
+	const uint64_t avail = h.offset < total_bits ? total_bits - h.offset : 0;
+	uint32_t len = avail < max_length ? (uint32_t)avail : max_length;
+	if (len > BTBBX_MAX_SYMBOLS)
+		len = BTBBX_MAX_SYMBOLS;
+	const uint64_t first_word = h.offset >> 6;
+	PState s;
+	s.w = words + (uint64_t)h.stream * pitch_words + first_word;
+	s.sh = (uint32_t)(h.offset & 63);
+	s.wlimit = first_word < n_words ? (uint32_t)(n_words - first_word < 64 ? n_words - first_word : 64) : 0;
+	s.direct = true;
+	s.length = (int)len;
+	btbbx_pkt_in pi = in[pkt];
+	pi.length = len;
+	decode_view(s, pi, outs + pkt, mode);
+	if (lengths)
+		lengths[pkt] = len;
 }
 
 // 64 symbols, one per byte (bit 0 counts), -> one packed word
@@ -1505,7 +1571,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const uint64_t *packet, cons
 		o->payload[lane] = word;
 	}
 	if (lane == 0) {
-		o->header_present = (uint8_t)do_header_present(s.w, s.length);
+		o->header_present = (uint8_t)do_header_present(s);
 		o->header_rv = f_hrv;
 		o->payload_rv = f_prv;
 		o->payload_length = f_plen;
@@ -1808,4 +1874,24 @@ extern "C" int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in
 				   btbbx_pkt_out *d_out, void *hip_stream)
 {
 	return launch_decode(d_packets, d_in, n_packets, d_out, DEC_HEADER | DEC_PAYLOAD, nullptr, (hipStream_t)hip_stream);
+}
+
+extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+					const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, uint32_t n_packets,
+					uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!n_packets)
+		return BTBBX_OK;
+	if (!d_words || !d_hits || !d_in || !d_out) {
+		set_error("btbbx_decode_hits_device: null pointer");
+		return BTBBX_E_ARG;
+	}
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((n_packets + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream,
+			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, max_length, d_out, d_lengths,
+			   DEC_HEADER | DEC_PAYLOAD);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
 }

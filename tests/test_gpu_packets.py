@@ -146,6 +146,58 @@ def test_batch_decode():
     assert good > 30
 
 
+def test_decode_from_the_streams_equals_gather_then_decode():
+    """btbbx_decode_hits_device reads the packets where they lie: same btbbx_pkt_out, byte for byte, as cutting
+    them out first -- for every bit alignment, for captures cut short by the end of the stream (the decoders
+    read zeros behind the captured length in both) and for hits in the very last words; and the oracle on the
+    same symbols agrees."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(53))
+    n_streams, n_words = 3, 4096
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    pk = _pkt.random_packets(rng, 150, max_sym_errors=2)
+    hits = np.zeros(0, bt.HIT_DTYPE)
+    rows = []
+    pos = [64 + int(rng.integers(0, 64)) for _ in range(n_streams)]
+    for i, (s, meta) in enumerate(pk):
+        st = i % n_streams
+        s = s[:bt.MAX_SYMBOLS]
+        if pos[st] + len(s) + 200 > n_words * 64:
+            continue
+        sym[st, pos[st]:pos[st] + len(s)] = s
+        rows.append((st, pos[st], meta))
+        pos[st] += len(s) + int(rng.integers(1, 190))
+    # hits whose capture window runs into the end of the stream, down to a window of a few symbols
+    for st in range(n_streams):
+        for back in (3124, 3000, 1500, 400, 130, 121, 70, 1):
+            rows.append((st, n_words * 64 - back, dict(lap=0, uap=int(rng.integers(0, 256)), clk6=int(rng.integers(0, 64)), type=-1)))
+    hits = np.zeros(len(rows), bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(len(rows), bt.PKTIN_DTYPE)
+    pin["clkn"] = [r[2]["clk6"] for r in rows]
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    direct, len_d = bt.run_decode_hits(words, hits, pin)
+    two_step, len_g = bt.run_decode_hits(words, hits, pin, via_gather=True)
+    assert np.array_equal(len_d, len_g)
+    assert len_d.min() == 1 and (len_d == bt.MAX_SYMBOLS).sum() > 50
+    assert direct.tobytes() == two_step.tobytes()
+    good = 0
+    for i, (st, off, meta) in enumerate(rows):
+        s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
+        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        o = direct[i]
+        assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, off, meta)
+        if h:
+            assert int(o["payload_length"]) == stt["payload_length"], (i, meta)
+            bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+            assert (bits == stt["payload"]).all(), (i, meta)
+            good += r in (10, 1000)
+    assert good > 20
+
+
 class DropIn:
     """The same packet in the product (C ABI) and in the oracle."""
 
