@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 // the first writes and the second reads back (profiles/r02_v4/pmc_secondary.json: the two moved 2.0 GB per
 // 1.29 M packets, of which the packets themselves are 0.5 GB).  One lane per hit; the captured length is the
 // gather's: min(max_length, 3125, symbols left in the stream), and d_in[i].length is ignored.
-__global__ __launch_bounds__(64) void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
+__global__ __launch_bounds__(256) void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
 							  uint32_t max_length, btbbx_pkt_out *outs, uint32_t *lengths, uint32_t mode)
 {
@@ -1889,7 +1889,7 @@ extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_word
 		set_error("btbbx_decode_hits_device: null pointer");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((n_packets + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream,
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((n_packets + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
 			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, max_length, d_out, d_lengths,
 			   DEC_HEADER | DEC_PAYLOAD);
 	HIP_TRY(hipGetLastError());
