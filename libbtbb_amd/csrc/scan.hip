@@ -595,14 +595,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // (window bit 52 + k of offset p is bit p + 20 + k of dh:dm), a carry-save adder tree to a 4-bit
 // count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
 // 79 / 4096 = 1.9 % of the offsets of a random stream.
-__device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, uint32_t ac_top12, int limit)
+__device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
 	if (limit >= 12)
 		return 0xffffffffu;
 	uint32_t m[12];
 #pragma unroll
 	for (int k = 0; k < 12; k++)
-		m[k] = alignbit(dh, dm, 20 + k) ^ (((ac_top12 >> k) & 1) ? 0xffffffffu : 0u);
+		m[k] = alignbit(dh, dm, 20 + k) ^ flip[4 + k];
 #define FA_SUM(a, b, c) BITOP3((a), (b), (c), 0x96)
 #define FA_CARRY(a, b, c) BITOP3((a), (b), (c), 0xe8)
 	const uint32_t s0 = FA_SUM(m[0], m[1], m[2]), c0 = FA_CARRY(m[0], m[1], m[2]);
@@ -632,14 +632,14 @@ __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, uint3
 // The same over the top sixteen sync-word bits (48..63): five more adders, but for limit >= 2 it
 // leaves a tenth of the survivors (0.2 % instead of 1.9 % at limit 2), which is worth more than it
 // costs; for limit <= 1 the twelve-plane filter is already sparse enough and cheaper.
-__device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, uint32_t ac_top16, int limit)
+__device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
 	if (limit >= 16)
 		return 0xffffffffu;
 	uint32_t m[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++)
-		m[k] = alignbit(dh, dm, 16 + k) ^ (((ac_top16 >> k) & 1) ? 0xffffffffu : 0u);
+		m[k] = alignbit(dh, dm, 16 + k) ^ flip[k];
 #define FA_SUM(a, b, c) BITOP3((a), (b), (c), 0x96)
 #define FA_CARRY(a, b, c) BITOP3((a), (b), (c), 0xe8)
 	// weight 1
@@ -688,7 +688,15 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	const uint32_t lane = tid & 63;
 	KnownHit *ring = ring_mem[tid >> 6];
 	const uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
-	const uint32_t ac_top16 = ac_hi >> 16, ac_top12 = ac_hi >> 20;
+	// the planes of the filter are XORed with all-ones where the sync word has a 1: sixteen masks, kept in
+	// VGPRs on purpose -- they are wave-uniform, and a VALU instruction with an SGPR source issues at half rate
+	// (tools/valu_rate.hip: 4.2 against 2.5 cycles)
+	uint32_t flip[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		flip[k] = ((ac_hi >> (16 + k)) & 1) ? 0xffffffffu : 0u;
+		asm volatile("" : "+v"(flip[k]));
+	}
 	const int limit = a.max_err < 0 ? -1 : a.max_err;
 	if (limit < 0)
 		return;
@@ -754,11 +762,11 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 		uint32_t mA, mB;
 		if (wide) {
-			mA = top16_filter(d1, d2, ac_top16, limit);
-			mB = top16_filter(d2, d3, ac_top16, limit);
+			mA = top16_filter(d1, d2, flip, limit);
+			mB = top16_filter(d2, d3, flip, limit);
 		} else {
-			mA = top12_filter(d1, d2, ac_top12, limit);
-			mB = top12_filter(d2, d3, ac_top12, limit);
+			mA = top12_filter(d1, d2, flip, limit);
+			mB = top12_filter(d2, d3, flip, limit);
 		}
 		mA &= (uint32_t)valid;
 		mB &= (uint32_t)(valid >> 32);
