@@ -318,7 +318,9 @@ def test_device_hit_sort():
     """btbbx_sort_hits_device orders (stream, offset) like the host routine, keeps every record."""
     lib = bt.lib()
     rng = np.random.default_rng(7)
-    for n, streams, maxoff in ((1, 1, 10), (2, 2, 100), (777, 3, 1 << 20), (100000, 79, 1 << 33), (2500000, 1, 1 << 40)):
+    # (the sort key holds only as many offset and stream bits as the list needs: 1 .. 64 of them)
+    for n, streams, maxoff in ((1, 1, 10), (2, 2, 100), (777, 3, 1 << 20), (100000, 79, 1 << 33), (2500000, 1, 1 << 40),
+                               (3, 1, 1), (1000, 40000, 1 << 4), (5000, 65536, 1 << 47)):
         h = np.zeros(n, bt.HIT_DTYPE)
         h["offset"] = rng.integers(0, maxoff, n, dtype=np.uint64)
         h["stream"] = rng.integers(0, streams, n)
