@@ -92,6 +92,14 @@ __global__ __launch_bounds__(1024) void k_lshr64(uint32_t *out, uint32_t seed)
 KERNEL(k_or_lit, OP8_LIT("v_or_b32", "0x12345"))
 KERNEL(k_or_sgpr, OP8_SGPR("v_or_b32"))
 KERNEL(k_or_inline, OP8_LIT("v_or_b32", "1"))
+#define OP8_SDWA(ins) asm volatile(ins " %0, %8, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+	ins " %1, %8, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" ins " %2, %8, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+	ins " %3, %8, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" ins " %4, %8, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+	ins " %5, %8, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" ins " %6, %8, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+	ins " %7, %8, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(seed));
+KERNEL(k_lshr_sdwa, OP8_SDWA("v_lshrrev_b32_sdwa"))
+KERNEL(k_and_sdwa, OP8_SDWA("v_and_b32_sdwa"))
 
 template <typename K>
 static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
@@ -136,6 +144,8 @@ int main()
 		run("v_or_b32 literal", k_or_lit, d_out, w);
 		run("v_or_b32 sgpr", k_or_sgpr, d_out, w);
 		run("v_or_b32 inline", k_or_inline, d_out, w);
+		run("v_lshrrev_b32_sdwa", k_lshr_sdwa, d_out, w);
+		run("v_and_b32_sdwa", k_and_sdwa, d_out, w);
 		run("v_alignbyte_b32", k_alignbyte, d_out, w);
 		run("v_cndmask_b32", k_cndmask, d_out, w);
 		run("v_or3_b32", k_or3, d_out, w);
