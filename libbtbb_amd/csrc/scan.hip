@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 					t1[u][h] = lds_ld(LDS_OFF_TABA + q[u][h].offA);
 					t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
 				}
-			uint32_t anybit = 0, bit[UNROLL][2], i2[UNROLL][2];
+			uint32_t anybit = 0, bit[UNROLL][2], live[UNROLL][2], i2[UNROLL][2];
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
@@ -537,15 +537,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
-					// only bit 0 of bit[][] counts: (bitmap word >> index) & (m >> p)
-					const uint32_t live = m[u][h] >> p[u][h];          // p = ~0 for m == 0: 0 >> 31
-					bit[u][h] = (bw[u][h] >> ((VARIANT == 8 ? i2[u][h] : proj[u][h]) & 31)) & live;
-					if (VARIANT == 9 && (bit[u][h] & 1)) {
-						// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
-						const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
-						bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
+					// only bit 0 counts: (bitmap word >> index) & (m >> p), p = ~0 for m == 0: 0 >> 31
+					live[u][h] = m[u][h] >> p[u][h];
+					bit[u][h] = bw[u][h] >> ((VARIANT == 8 ? i2[u][h] : proj[u][h]) & 31);
+					if (VARIANT == 9) {
+						bit[u][h] &= live[u][h];
+						if (bit[u][h] & 1) {
+							// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
+							const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+							bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
+						}
 					}
-					anybit |= bit[u][h];
+					anybit = BITOP3(bit[u][h], live[u][h], anybit, 0xea);   // anybit |= bit & live, one instruction
 					m[u][h] &= m[u][h] - 1;
 				}
 			if (anybit & 1) {
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 					for (int h = 0; h < 2; h++)
-						if (bit[u][h] & 1)  // rare: rebuild the window of this offset and keep it with the code
+						if (bit[u][h] & live[u][h] & 1)  // rare: rebuild the window of this offset and keep it with the code
 							park(((it + u) << 12) | (lane << 6) | (h << 5) | (p[u][h] & 31),
 							     alignbit(d[u][h + 1], d[u][h], p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], p[u][h]));
 			}
