@@ -39,6 +39,7 @@ struct ScanArgs {
 	uint64_t tiles_per_stream;
 	uint64_t n_tiles;
 	uint32_t xcd_tiles;      // LAP_ANY: tiles per XCD share (0 = plain round robin over workgroups)
+	uint32_t full_tiles;     // LAP_ANY: leading tiles of a stream whose words, halo word and offsets are all in range
 	uint32_t n_streams;
 	uint32_t lap;            // known-LAP mode
 	uint64_t syncword;       // known-LAP mode
@@ -421,8 +422,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		}
 	};
 	// a tile whose 1024 words + halo word and 65536 offsets are all in range needs no masks
-	auto tile_full = [&](uint64_t tt) {
-		return (tt + 1) * SCAN_THREADS + 1 <= a.n_words && (tt + 1) * (SCAN_THREADS * 64ull) <= a.search_bits;
+	auto tile_full = [&](uint64_t tt) {                         // (one scalar compare; the launcher did the 64-bit arithmetic)
+		return tt < a.full_tiles;
 	};
 	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
 		lo = hi = 0;
@@ -921,6 +922,11 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	if (lap == BTBBX_LAP_ANY) {
 		a.tiles_per_stream = (search_words + SCAN_THREADS - 1) / SCAN_THREADS;
 		a.n_tiles = a.tiles_per_stream * n_streams;
+		{	// tile t is full iff (t + 1) * 1024 + 1 <= n_words and (t + 1) * 65536 <= search_bits
+			const uint64_t by_words = n_words ? (n_words - 1) / SCAN_THREADS : 0, by_bits = search_bits / (SCAN_THREADS * 64ull);
+			const uint64_t full = by_words < by_bits ? by_words : by_bits;
+			a.full_tiles = full > 0xffffffffull ? 0xffffffffu : (uint32_t)full;
+		}
 		uint64_t grid = a.n_tiles < (uint64_t)c.num_cus ? a.n_tiles : (uint64_t)c.num_cus;
 		a.xcd_tiles = (grid % 8 == 0 && a.n_tiles >= grid) ? (uint32_t)((a.n_tiles + 7) / 8) : 0;
 		if ((a.n_tiles + grid - 1) / grid >= (1u << 20) || (a.n_tiles >> 32)) {
