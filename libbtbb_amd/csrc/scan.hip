@@ -403,38 +403,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	};
 
 	// tile cursor without divisions: uniform (stream, tile-in-stream) stepped per tile
-	struct Cursor { uint32_t stream; uint64_t t; };
+	// (32-bit: the launcher refuses launches with 2^32 tiles or more, and 64-bit compares of wave-uniform
+	// values run on the VALU -- the SALU has none)
+	struct Cursor { uint32_t stream; uint32_t t; };
+	const uint32_t tiles_per_stream = (uint32_t)a.tiles_per_stream;
 	Cursor cur = {a.n_streams, 0};               // stream == n_streams: nothing (left) to do
 	uint32_t handed = 0;                          // tiles handed out so far
 	if (n_mine) {
-		cur.stream = a.n_streams > 1 ? first_tile / (uint32_t)a.tiles_per_stream : 0;
-		cur.t = first_tile - (uint64_t)cur.stream * a.tiles_per_stream;
+		cur.stream = a.n_streams > 1 ? first_tile / tiles_per_stream : 0;
+		cur.t = first_tile - cur.stream * tiles_per_stream;
 	}
 	auto advance = [&](Cursor &c) {
 		if (++handed >= n_mine) {
 			c.stream = a.n_streams;
 			return;
 		}
+		// (no wrap: the launcher keeps the tile count below 2^20 x grid size)
 		c.t += tile_step;
-		while (c.t >= a.tiles_per_stream && c.stream < a.n_streams) {
-			c.t -= a.tiles_per_stream;
+		while (c.t >= tiles_per_stream && c.stream < a.n_streams) {
+			c.t -= tiles_per_stream;
 			c.stream++;
 		}
 	};
 	// a tile whose 1024 words + halo word and 65536 offsets are all in range needs no masks
-	auto tile_full = [&](uint64_t tt) {                         // (one scalar compare; the launcher did the 64-bit arithmetic)
+	auto tile_full = [&](uint32_t tt) {                         // (one scalar compare; the launcher did the 64-bit arithmetic)
 		return tt < a.full_tiles;
 	};
 	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
 		lo = hi = 0;
 		if (c.stream >= a.n_streams)
 			return;
-		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + c.t * SCAN_THREADS;   // uniform
+		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SCAN_THREADS;   // uniform
 		if (tile_full(c.t)) {
 			lo = tp[tid];
 			hi = tp[tid + 1];
 		} else {
-			const uint64_t w = c.t * SCAN_THREADS + tid;
+			const uint64_t w = (uint64_t)c.t * SCAN_THREADS + tid;
 			lo = w < a.n_words ? tp[tid] : 0;
 			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
 		}
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			if (tc[u].stream >= a.n_streams) {
 				validA = validB = 0;
 			} else if (!tile_full(tc[u].t)) {
-				const uint64_t first_off = (tc[u].t * SCAN_THREADS + tid) * 64;
+				const uint64_t first_off = ((uint64_t)tc[u].t * SCAN_THREADS + tid) * 64;
 				const uint64_t valid = first_off >= a.search_bits ? 0ULL
 					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 				validA = (uint32_t)valid;
