@@ -39,7 +39,7 @@ struct ScanArgs {
 	uint64_t tiles_per_stream;
 	uint64_t n_tiles;
 	uint32_t xcd_tiles;      // LAP_ANY: tiles per XCD share (0 = plain round robin over workgroups)
-	uint32_t full_tiles;     // LAP_ANY: leading tiles of a stream whose words, halo word and offsets are all in range
+	uint32_t full_tiles;     // leading tiles of a stream whose words, halo word and offsets are all in range
 	uint32_t n_streams;
 	uint32_t lap;            // known-LAP mode
 	uint64_t syncword;       // known-LAP mode
@@ -689,6 +689,9 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 #define KRING 128
 struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per staged hit
 
+// LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
+// and / andn of the count planes; with the limit in a register it is sixteen instructions with SGPR masks), -1 = any
+template <int LIMIT>
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
 	__shared__ KnownHit ring_mem[4][KRING];
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		flip[k] = ((ac_hi >> (16 + k)) & 1) ? 0xffffffffu : 0u;
 		asm volatile("" : "+v"(flip[k]));
 	}
-	const int limit = a.max_err < 0 ? -1 : a.max_err;
+	const int limit = LIMIT >= 0 ? LIMIT : (a.max_err < 0 ? -1 : a.max_err);
 	if (limit < 0)
 		return;
 	const bool wide = limit >= 2;               // launch-uniform choice of the pre-filter
@@ -752,22 +755,30 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	};
 
 	// division-free (stream, tile) cursor, as in the LAP_ANY kernel
+	// (32-bit tile numbers: the launcher refuses more; 64-bit compares of wave-uniform values would run on the VALU)
+	const uint32_t tiles_per_stream = (uint32_t)a.tiles_per_stream;
 	uint32_t stream = 0;
-	uint64_t t = blockIdx.x;
-	while (t >= a.tiles_per_stream && stream < a.n_streams) {
-		t -= a.tiles_per_stream;
+	uint32_t t = blockIdx.x;
+	while (t >= tiles_per_stream && stream < a.n_streams) {
+		t -= tiles_per_stream;
 		stream++;
 	}
 	while (stream < a.n_streams) {
-		const uint64_t word = t * 256 + tid;
+		const uint64_t word = (uint64_t)t * 256 + tid;
 		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
-		const uint64_t lo = load_word(base, word, a.n_words);
-		const uint64_t hi = load_word(base, word + 1, a.n_words);
+		uint64_t lo, hi, valid = FULL_MASK;
+		if (t < a.full_tiles) {                         // wave-uniform: every word, halo word and offset of the tile is in range
+			lo = base[word];
+			hi = base[word + 1];
+		} else {
+			lo = load_word(base, word, a.n_words);
+			hi = load_word(base, word + 1, a.n_words);
+			const uint64_t first_off = word * 64;
+			valid = first_off >= a.search_bits ? 0ULL
+				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+		}
 		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
 		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
-		uint64_t first_off = word * 64;
-		uint64_t valid = first_off >= a.search_bits ? 0ULL
-			: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 		uint32_t mA, mB;
 		if (wide) {
 			mA = top16_filter(d1, d2, flip, limit);
@@ -794,8 +805,8 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		while (q_tail - q_head >= 64)
 			flush(64);
 		t += gridDim.x;
-		while (t >= a.tiles_per_stream) {
-			t -= a.tiles_per_stream;
+		while (t >= tiles_per_stream) {
+			t -= tiles_per_stream;
 			stream++;
 		}
 	}
@@ -971,9 +982,25 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		a.lap = lap;
 		a.tiles_per_stream = (search_words + 255) / 256;
 		a.n_tiles = a.tiles_per_stream * n_streams;
+		{	// tile t (256 words) is full iff (t + 1) * 256 + 1 <= n_words and (t + 1) * 16384 <= search_bits
+			const uint64_t by_words = n_words ? (n_words - 1) / 256 : 0, by_bits = search_bits / (256 * 64ull);
+			const uint64_t full = by_words < by_bits ? by_words : by_bits;
+			a.full_tiles = full > 0xffffffffull ? 0xffffffffu : (uint32_t)full;
+		}
 		uint64_t cap = (uint64_t)c.num_cus * 8;
 		uint64_t grid = a.n_tiles < cap ? a.n_tiles : cap;
-		hipLaunchKernelGGL(scan_known_lap_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a);
+		if (a.tiles_per_stream + grid >= (1ull << 32)) {
+			set_error("btbbx_scan: stream too long for one launch (split it)");
+			return BTBBX_E_ARG;
+		}
+		switch (max_ac_errors) {
+		case 0: hipLaunchKernelGGL(scan_known_lap_kernel<0>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		case 1: hipLaunchKernelGGL(scan_known_lap_kernel<1>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		case 2: hipLaunchKernelGGL(scan_known_lap_kernel<2>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		case 3: hipLaunchKernelGGL(scan_known_lap_kernel<3>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		case 4: hipLaunchKernelGGL(scan_known_lap_kernel<4>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		default: hipLaunchKernelGGL(scan_known_lap_kernel<-1>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
