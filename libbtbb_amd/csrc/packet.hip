@@ -171,6 +171,16 @@ __device__ __forceinline__ uint64_t pk_bits(const uint64_t *w, uint32_t pos, uin
 	return n == 64 ? v : v & ((1ULL << n) - 1);
 }
 
+// the same for n <= 32 through two dword reads and one funnel shift (the 64-bit form costs two 8-byte reads, two
+// 64-bit shifts and a 64-bit mask); pos + n <= 3200, so dword (pos >> 5) + 1 is still inside the 50-word row
+__device__ __forceinline__ uint32_t pk_bits32(const uint64_t *w, uint32_t pos, uint32_t n)
+{
+	const uint32_t *d = reinterpret_cast<const uint32_t *>(w);
+	const uint32_t i = pos >> 5;
+	const uint32_t v = __builtin_amdgcn_alignbit(d[i + 1], d[i], pos & 31);
+	return n == 32 ? v : v & ((1u << n) - 1);
+}
+
 // n (1..64) whitening bits starting at phase idx (0..126), straight from constant memory (used
 // where a kernel needs a handful of them; the decoders below use the LDS copies)
 __device__ __forceinline__ uint64_t wh_bits_const(uint32_t idx, uint32_t n)
@@ -923,14 +933,14 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		if (p < mine) {
 			uint32_t d;
 			if (sub < TL_B_BLOCKS) {
-				if (!fec23_block((uint32_t)pk_bits(pk[p], 202 + 15 * sub, 15), d))
+				if (!fec23_block(pk_bits32(pk[p], 202 + 15 * sub, 15), d))
 					atomicMin(&b_fail[p], sub);
 				b10[p][sub] = (uint16_t)d;
 			}
 			for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
 				const uint32_t k = k0 + sub;
 				if (k < TL_A_BLOCKS) {
-					if (!fec23_block((uint32_t)pk_bits(pk[p], 122 + 15 * k, 15), d))
+					if (!fec23_block(pk_bits32(pk[p], 122 + 15 * k, 15), d))
 						atomicMin(&a_fail[p], k);
 					a10[p][k] = (uint16_t)d;
 				}
@@ -1027,7 +1037,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		}
 	};
 	auto data_word = [&](uint32_t p, uint32_t layout, uint32_t i) {
-		return layout == 0 ? (uint32_t)pk_bits(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
+		return layout == 0 ? pk_bits32(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
 	};
 	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
 		uint32_t p, r, layout, j, nwords, crc = 0;
@@ -1120,7 +1130,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		auto data_reg = [&](int layout, uint32_t L) {
 			const uint32_t q = L >> 2, r = L & 3;
 			uint32_t crc, w;
-			if (layout == 0) { crc = p4c[p][q]; w = r ? (uint32_t)pk_bits(pk[p], 122 + 32 * q, 32) : 0; }
+			if (layout == 0) { crc = p4c[p][q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
 			else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
 			else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
 			for (uint32_t j = 0; j < r; j++)
@@ -1162,7 +1172,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 				if (fail < (uint32_t)hb) break;
 				raw = (layout == 2 ? b_bytes[p][0] : a_bytes[p][0]) & ((1u << hbits) - 1);
 			} else {
-				raw = (uint32_t)pk_bits(pk[p], 122, hbits);
+				raw = pk_bits32(pk[p], 122, hbits);
 			}
 			const uint32_t ph = raw ^ (wht ? (uint32_t)wh_bits(wh_start(clock, 18), hbits) : 0u);
 			int plen = hb == 2 ? (int)((ph >> 3) & 0x3ff) + 4 : (int)((ph >> 3) & 0x1f) + 3;
