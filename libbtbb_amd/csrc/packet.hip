@@ -1039,15 +1039,32 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	auto data_word = [&](uint32_t p, uint32_t layout, uint32_t i) {
 		return layout == 0 ? pk_bits32(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
 	};
+	// the (up to) eight words of a chunk, all loaded before any is used: one LDS round trip, not eight.  The raw
+	// payload starts at symbol 122 = dword 3, bit 26 of the packet row, so its words are funnel shifts by 26 of
+	// nine consecutive dwords
+	auto chunk_words = [&](uint32_t p, uint32_t layout, uint32_t j, uint32_t nwords, uint32_t (&w8)[8]) {
+		if (layout == 0) {
+			const uint32_t *d = reinterpret_cast<const uint32_t *>(pk[p]) + 3 + 8 * j;
+			uint32_t raw[9];
+#pragma unroll
+			for (uint32_t i = 0; i < 9; i++)
+				raw[i] = i <= nwords ? d[i] : 0;
+#pragma unroll
+			for (uint32_t i = 0; i < 8; i++)
+				w8[i] = __builtin_amdgcn_alignbit(raw[i + 1], raw[i], 26);
+		} else {
+#pragma unroll
+			for (uint32_t i = 0; i < 8; i++)
+				w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
+		}
+	};
 	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
 		uint32_t p, r, layout, j, nwords, crc = 0;
 		chunk_of(t, p, r, layout, j, nwords);
 		if (!nwords)
 			continue;
 		uint32_t w8[8];
-#pragma unroll
-		for (uint32_t i = 0; i < 8; i++)                   // all eight words first: one LDS round trip, not eight
-			w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
+		chunk_words(p, layout, j, nwords, w8);
 #pragma unroll
 		for (uint32_t i = 0; i < 8; i++)
 			if (i < nwords)
@@ -1077,9 +1094,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		uint32_t crc = chunk_reg[p][r];
 		uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
 		uint32_t w8[8];
-#pragma unroll
-		for (uint32_t i = 0; i < 8; i++)
-			w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
+		chunk_words(p, layout, j, nwords, w8);
 #pragma unroll
 		for (uint32_t i = 0; i < 8; i++)
 			if (i < nwords) {
