@@ -829,7 +829,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];   // register after the 20 whitening bytes of an FHS attempt
 	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
 	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
-	__shared__ uint8_t t_uap[TL_TRIALS], t_type[TL_TRIALS], t_ret[TL_TRIALS];
+	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
 	__shared__ uint32_t type_count[16], type_base[16];
 	// per packet
@@ -983,9 +983,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			uap = ret = v & 0xff;
 			type = v >> 8;
 		}
-		t_uap[i] = (uint8_t)uap;
-		t_type[i] = (uint8_t)type;
-		t_ret[i] = (uint8_t)ret;
+		t_info[i] = ret | (type << 8) | (uap << 16);
 		t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
 	}
 	// 2b. the decoded bits as bytes (four per thread and step), as far as they decode
@@ -1105,14 +1103,14 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__syncthreads();
 	TL_PROF(3);
 	for (uint32_t i = tid; i < total; i += TL_THREADS)
-		order[type_base[t_type[i] & 15] + t_slot[i]] = (uint16_t)i;
+		order[type_base[(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
 	__syncthreads();
 	TL_PROF(4);
 
 	// 3. crc_check (:708-769) in type order
 	for (uint32_t kk = tid; kk < total; kk += TL_THREADS) {
 		const uint32_t i = order[kk], p = i >> 6, clock = i & 63;
-		const uint32_t type = t_type[i], uap = t_uap[i];
+		const uint32_t info = t_info[i], type = (info >> 8) & 0xff, uap = (info >> 16) & 0xff;
 		const bool wht = pin[p].flags & F_WHITENED;
 		const int size = (int)pin[p].length - 122;
 		const uint32_t seed = crc_seed(uap);
@@ -1242,7 +1240,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	static_assert(sizeof(btbbx_trial) == 4, "one dword per trial");
 	for (uint32_t i = tid; i < total; i += TL_THREADS)
 		reinterpret_cast<uint32_t *>(trials)[(uint64_t)first * 64 + i] =
-			(uint32_t)t_ret[i] | ((uint32_t)t_type[i] << 8) | ((uint32_t)(uint16_t)t_rv[i] << 16);
+			(t_info[i] & 0xffff) | ((uint32_t)(uint16_t)t_rv[i] << 16);
 	TL_PROF(6);
 	}
 	TL_PROF_END;
