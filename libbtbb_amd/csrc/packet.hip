@@ -1214,11 +1214,23 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			const uint32_t lmax = B ? 5 * (B - 1) / 4 : 0;        // bytes L-1 with ceil(4 L / 5) <= B - 1 are reached
 			uint32_t crc = seed, idx = wh_start(clock, 18);
 			rv = B == 98 ? 2 : 1;
-			for (uint32_t L = 1; L <= lmax; L++) {
-				const uint32_t byte = (a_bytes[p][(L - 1) >> 2] >> (8 * ((L - 1) & 3))) & 0xff;
-				crc = crc_byte(crc, byte ^ (wht ? (uint32_t)wh_bits(idx, 8) : 0u));
-				idx = idx + 8 >= 127 ? idx + 8 - 127 : idx + 8;
-				if (L >= 2 && crc == 0) { rv = 10; break; }
+			// Four bytes per step, and the register after EACH of them from ten independent table reads (the
+			// same slicing as crc_word: the 16-bit register is used up by the first two bytes) -- the scan for
+			// the first zero register is a chain of up to 121 dependent steps otherwise, and with the trials
+			// sorted by type the EV4 waves are what the other fifteen wait for at the barrier.
+			for (uint32_t L0 = 0; L0 < lmax; L0 += 4) {
+				const uint32_t w = a_bytes[p][L0 >> 2] ^ (wht ? (uint32_t)wh_bits(idx, 32) : 0u);
+				idx = idx + 32 >= 127 ? idx + 32 - 127 : idx + 32;
+				const uint32_t x0 = (crc ^ w) & 0xff, x1 = ((crc ^ w) >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
+				const uint32_t c1 = (crc >> 8) ^ g_lds.crc[x0];
+				const uint32_t c2 = g_lds.crc_z[0][x0] ^ g_lds.crc[x1];
+				const uint32_t c3 = g_lds.crc_z[1][x0] ^ g_lds.crc_z[0][x1] ^ g_lds.crc[b2];
+				const uint32_t c4 = g_lds.crc_z[2][x0] ^ g_lds.crc_z[1][x1] ^ g_lds.crc_z[0][b2] ^ g_lds.crc[b3];
+				// byte counts L0 + 1 .. L0 + 4; a zero register counts from 2 bytes on and up to lmax
+				const bool z1 = c1 == 0 && L0 + 1 >= 2 && L0 + 1 <= lmax, z2 = c2 == 0 && L0 + 2 <= lmax;
+				const bool z3 = c3 == 0 && L0 + 3 <= lmax, z4 = c4 == 0 && L0 + 4 <= lmax;
+				if (z1 || z2 || z3 || z4) { rv = 10; break; }
+				crc = c4;
 			}
 			break;
 		}
