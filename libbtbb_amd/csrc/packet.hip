@@ -1163,9 +1163,18 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			if (!wht) {
 				if (x == 0) rv = 1000;
 			} else {
-				if (x == pw20[clock]) rv = 1000;
-				for (uint32_t c = 32; c < 64 && rv == 0; c++)
-					if (x == pw20[c]) rv = 1000;
+				// attempt 0 is the trial's own clock, attempts 1..32 are clocks 32..63: their registers in four
+				// 16-byte reads (not unrolled: the kernel sits at its 128-VGPR ceiling)
+				uint32_t hit = x == pw20[clock];
+				const uint32_t xx = x | (x << 16);
+#pragma unroll 1
+				for (int v = 0; v < 4; v++) {
+					const uint4 q = reinterpret_cast<const uint4 *>(&pw20[32])[v];
+					const uint32_t d0 = q.x ^ xx, d1 = q.y ^ xx, d2 = q.z ^ xx, d3 = q.w ^ xx;
+					hit |= ((d0 & 0xffff) == 0) | ((d0 >> 16) == 0) | ((d1 & 0xffff) == 0) | ((d1 >> 16) == 0)
+					     | ((d2 & 0xffff) == 0) | ((d2 >> 16) == 0) | ((d3 & 0xffff) == 0) | ((d3 >> 16) == 0);
+				}
+				if (hit) rv = 1000;
 			}
 			break;
 		}
