@@ -49,6 +49,9 @@ __device__ __attribute__((aligned(16))) ChainLds g_chain_lds_image;
 //   [15]    0
 #define LIN_MAXLEN 344                      // payload lengths 0 .. 343 (DH5)
 __device__ __attribute__((aligned(16))) uint16_t g_lin[LIN_MAXLEN * 16];
+// g_advw[i - 1][h][x]: the CRC register 4 i zero bytes after holding x in its low (h = 0) / high (h = 1) byte,
+// i = 1 .. 7 (linear: XOR the two halves) -- what carries a chunk's start register to a word inside the chunk
+__device__ __attribute__((aligned(16))) uint16_t g_advw[7 * 2 * 256];
 
 static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
 {
@@ -142,6 +145,16 @@ int chain_upload(const HostTables &t)
 			}
 		}
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lin), lin, sizeof(lin)));
+		static uint16_t advw[7 * 2 * 256];
+		for (int i = 1; i <= 7; i++)
+			for (int h = 0; h < 2; h++)
+				for (int x = 0; x < 256; x++) {
+					uint32_t c = (uint32_t)x << (8 * h);
+					for (int k = 0; k < 4 * i; k++)
+						c = host_crc_byte(c, 0);
+					advw[((i - 1) * 2 + h) * 256 + x] = (uint16_t)c;
+				}
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_advw), advw, sizeof(advw)));
 	}
 	ChainTables c;
 	memset(&c, 0, sizeof(c));
@@ -828,6 +841,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ uint16_t clk_ut[64];
 	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];   // register after the 20 whitening bytes of an FHS attempt
 	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
+	__shared__ __attribute__((aligned(16))) uint16_t advw[7 * 2 * 256];
 	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
 	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
@@ -845,6 +859,8 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	// tables once per workgroup (the workgroups are persistent: each takes every gridDim.x-th batch)
 	for (uint32_t i = tid; i < LIN_MAXLEN * 2; i += TL_THREADS)
 		reinterpret_cast<uint4 *>(lin)[i] = reinterpret_cast<const uint4 *>(g_lin)[i];
+	for (uint32_t i = tid; i < 7 * 2 * 256 / 8; i += TL_THREADS)
+		reinterpret_cast<uint4 *>(advw)[i] = reinterpret_cast<const uint4 *>(g_advw)[i];
 	chain_lds_init();                                       // ends with a barrier
 	if (tid >= 64 && tid < 128) {
 		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
@@ -1013,9 +1029,10 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		}
 	}
 	// 2c. reg(0, data, 4 i) for the three layouts (raw: 86 words, FEC at 122: 58, FEC at 202: 4), in chunks of
-	// eight words = twenty chunks per packet: (i) every chunk's own register from 0, all in parallel; (ii) per
-	// layout the chunk starts, start' = adv32(start) ^ chunk (a dozen dependent steps instead of 86);
-	// (iii) every chunk again from its start, storing the register in front of each word
+	// eight words = twenty chunks per packet: (i) every chunk from 0, all in parallel, storing the register in front
+	// of each of its words; (ii) per layout the chunk starts, start' = adv32(start) ^ chunk (a dozen dependent
+	// steps instead of 86).  reg(0, data, 4 q) is then (register stored for word q) ^ (the chunk's start carried
+	// 4 (q mod 8) bytes forward, two reads of advw) -- put together by the trial that asks for it.
 	// task t -> (packet, chunk slot r, layout, chunk j, words): raw and DV chunks first (12 per packet), then the
 	// payload-layout chunks, of which a packet needs only those in front of its first failing block
 	auto chunk_of = [&](uint32_t t, uint32_t &p, uint32_t &r, uint32_t &layout, uint32_t &j, uint32_t &nwords) {
@@ -1063,10 +1080,13 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			continue;
 		uint32_t w8[8];
 		chunk_words(p, layout, j, nwords, w8);
+		uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
 #pragma unroll
 		for (uint32_t i = 0; i < 8; i++)
-			if (i < nwords)
+			if (i < nwords) {
+				dst[8 * j + i] = (uint16_t)crc;                // the register in front of word i, from 0 at the chunk start
 				crc = crc_word(crc, w8[i]);
+			}
 		chunk_reg[p][r] = (uint16_t)crc;
 	}
 	__syncthreads();
@@ -1084,23 +1104,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(9);
-	for (uint32_t t = tid; t < mine * 20; t += TL_THREADS) {
-		uint32_t p, r, layout, j, nwords;
-		chunk_of(t, p, r, layout, j, nwords);
-		if (!nwords)
-			continue;
-		uint32_t crc = chunk_reg[p][r];
-		uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
-		uint32_t w8[8];
-		chunk_words(p, layout, j, nwords, w8);
-#pragma unroll
-		for (uint32_t i = 0; i < 8; i++)
-			if (i < nwords) {
-				dst[8 * j + i] = (uint16_t)crc;
-				crc = crc_word(crc, w8[i]);
-			}
-	}
-	__syncthreads();
 	TL_PROF(3);
 	for (uint32_t i = tid; i < total; i += TL_THREADS)
 		order[type_base[(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
@@ -1146,6 +1149,9 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			if (layout == 0) { crc = p4c[p][q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
 			else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
 			else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
+			// + the chunk's start register carried to word q
+			const uint32_t start = chunk_reg[p][(layout == 0 ? 0u : layout == 1 ? 11u : 19u) + (q >> 3)], iw = q & 7;
+			crc ^= iw ? (uint32_t)(advw[((iw - 1) * 2) * 256 + (start & 0xff)] ^ advw[((iw - 1) * 2 + 1) * 256 + (start >> 8)]) : start;
 			for (uint32_t j = 0; j < r; j++)
 				crc = crc_byte(crc, (w >> (8 * j)) & 0xff);
 			return crc;
@@ -1158,7 +1164,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		case 2: {                                               // fhs (:783-818)
 			if (size < 240) { rv = 1; break; }
 			if (a_fail[p] < 16) { rv = 0; break; }
-			const uint32_t x = p4a[p][5] ^ seed_row20(seed);        // zero register <=> x == reg(0, whitening of the attempt, 20)
+			const uint32_t x = data_reg(1, 20) ^ seed_row20(seed);   // zero register <=> x == reg(0, whitening of the attempt, 20)
 			rv = 0;
 			if (!wht) {
 				if (x == 0) rv = 1000;
