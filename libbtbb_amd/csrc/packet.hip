@@ -944,6 +944,11 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	// the first undecodable block can matter to any trial, and in the noise behind a short packet half of
 	// all blocks fail.  HV1 verdict (:1131-1150).
 	static_assert(TL_THREADS == 16 * TL_PACKETS, "sixteen threads per packet");
+	// 32-bit words of the payload layout that lie in front of the packet's first undecodable block (+ the one it starts in)
+	auto a_words = [&](uint32_t p) {
+		const uint32_t blocks = *(volatile uint32_t *)&a_fail[p] < TL_A_BLOCKS ? *(volatile uint32_t *)&a_fail[p] : TL_A_BLOCKS, n = (blocks * 10 + 31) / 32 + 1;
+		return n < TL_A_BYTES / 4 ? n : (uint32_t)(TL_A_BYTES / 4);
+	};
 	{
 		const uint32_t p = tid >> 4, sub = tid & 15;
 		if (p < mine) {
@@ -966,6 +971,21 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 				if (*(volatile uint32_t *)&a_fail[p] < k0 + 16)
 					break;
 			}
+			// the decoded bits as bytes, four per thread and step, as far as they decode: by the same sixteen
+			// lanes, which wrote every 10-bit group these words are made of (same wave: in order)
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			auto word_from = [&](const uint16_t *src, uint32_t nblk, uint32_t word) {
+				const uint32_t bit = 32 * word, k0 = bit / 10, sh = bit % 10;    // bits 32 word .. 32 word + 31 of the groups
+				uint64_t acc = 0;
+				for (uint32_t j = 0; j < 5; j++)
+					acc |= (uint64_t)(k0 + j < nblk ? src[k0 + j] : 0) << (10 * j);
+				return (uint32_t)(acc >> sh);
+			};
+			if (sub < TL_B_BYTES / 4)
+				b_bytes[p][sub] = word_from(b10[p], TL_B_BLOCKS, sub);
+			const uint32_t need = a_words(p);
+			for (uint32_t word = sub; word < need; word += 16)
+				a_bytes[p][word] = word_from(a10[p], TL_A_BLOCKS, word);
 		}
 	}
 	if (tid >= 128 && tid < 128 + mine) {
@@ -984,11 +1004,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(1);
-	// 32-bit words of the payload layout that lie in front of the packet's first undecodable block (+ the one it starts in)
-	auto a_words = [&](uint32_t p) {
-		const uint32_t blocks = a_fail[p] < TL_A_BLOCKS ? a_fail[p] : TL_A_BLOCKS, n = (blocks * 10 + 31) / 32 + 1;
-		return n < TL_A_BYTES / 4 ? n : (uint32_t)(TL_A_BYTES / 4);
-	};
 	const uint32_t total = mine * 64;
 	for (uint32_t i = tid; i < total; i += TL_THREADS) {
 		const uint32_t p = i >> 6;
@@ -1001,32 +1016,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		}
 		t_info[i] = ret | (type << 8) | (uap << 16);
 		t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
-	}
-	// 2b. the decoded bits as bytes (four per thread and step), as far as they decode
-	for (uint32_t i = tid; i < mine * (TL_A_BYTES / 4 + TL_B_BYTES / 4); i += TL_THREADS) {
-		const uint32_t p = i / (TL_A_BYTES / 4 + TL_B_BYTES / 4), q = i % (TL_A_BYTES / 4 + TL_B_BYTES / 4);
-		const bool isb = q >= TL_A_BYTES / 4;
-		const uint32_t word = isb ? q - TL_A_BYTES / 4 : q;
-		if (!isb && word >= a_words(p))
-			continue;
-		const uint16_t *src = isb ? b10[p] : a10[p];
-		const uint32_t nblk = isb ? TL_B_BLOCKS : TL_A_BLOCKS;
-		// bits 32 word .. 32 word + 31 of the 10-bit groups
-		const uint32_t bit = 32 * word, k0 = bit / 10, sh = bit % 10;
-		uint64_t acc = 0;
-		for (uint32_t j = 0; j < 5; j++)
-			acc |= (uint64_t)(k0 + j < nblk ? src[k0 + j] : 0) << (10 * j);
-		const uint32_t v = (uint32_t)(acc >> sh);
-		if (isb) b_bytes[p][word] = v; else a_bytes[p][word] = v;
-	}
-	__syncthreads();
-	TL_PROF(2);
-	if (tid == 0) {
-		uint32_t run = 0;
-		for (uint32_t t = 0; t < 16; t++) {
-			type_base[t] = run;
-			run += type_count[t];
-		}
 	}
 	// 2c. reg(0, data, 4 i) for the three layouts (raw: 86 words, FEC at 122: 58, FEC at 202: 4), in chunks of
 	// eight words = twenty chunks per packet: (i) every chunk from 0, all in parallel, storing the register in front
@@ -1091,6 +1080,13 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(8);
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (uint32_t t = 0; t < 16; t++) {
+			type_base[t] = run;
+			run += type_count[t];
+		}
+	}
 	if (tid >= 64 && tid < 64 + 3 * mine) {
 		const uint32_t p = (tid - 64) / 3, layout = (tid - 64) % 3;
 		const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
