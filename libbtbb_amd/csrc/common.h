@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/btbbx.h"
+#include "slide.h"
 
 // ---- spec constants ---------------------------------------------------------------
 #define SW_POLY   0260534236651ULL         // (64,30) block code generator, degree 34
@@ -53,6 +54,7 @@ struct ScanTables {
 	const uint32_t *tabA;      // [2048]   low-32 syndrome of window bits 34..44
 	const uint32_t *tabB;      // [4096]   low-32 syndrome of bits 45..56 ^ class-0 constant
 	const uint32_t *bitmap;    // 2^BITMAP_BITS-bit set: projection of acceptable syndromes
+	const uint32_t *slide_bitmap;  // 2^SLIDE_BITS-bit set over the sliding checks (slide.h), PN constant folded in
 	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)
 	uint64_t hmask;            // slots - 1
 	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1

@@ -306,9 +306,57 @@ static int upload_tables(int max_ac_errors)
 		tabB[v] = (uint32_t)s;
 	}
 
-	// one block: tabA | tabB | bitmap
+	// The candidate set of the sliding checks (slide.h): index bit b = parity of the window ^ PN under the
+	// taps shifted to b; a window the reference accepts differs from a codeword in at most max_ac_errors of
+	// the bits 0..56 (the map's patterns reach bit 57, which the checks do not touch), so its index is K ^ the
+	// XOR of that many columns.
+	static_assert(SLIDE_BITS == BITMAP_BITS, "both candidate sets use the same LDS region");
+	std::vector<uint32_t> slide_bitmap(LDS_BITMAP_WORDS, 0);
+	{
+		const uint64_t taps = SLIDE_TAPS;
+		for (int b = 0; b < SLIDE_BITS; b++)           // every check must annihilate every codeword
+			for (int r = 0; r < 30; r++) {
+				const uint64_t row = (1ULL << (34 + r)) | t.col[34 + r];
+				if (((taps << b) >> 57) || (__builtin_popcountll(row & (taps << b)) & 1)) {
+					set_error("btbb_init: the sliding parity check does not hold for this generator");
+					return BTBBX_E_ARG;
+				}
+			}
+		uint32_t colv[57], k_pn = 0;
+		for (int b = 0; b < SLIDE_BITS; b++)
+			k_pn |= (uint32_t)(__builtin_popcountll(SW_PN & (taps << b)) & 1) << b;
+		for (int i = 0; i < 57; i++) {
+			colv[i] = 0;
+			for (int b = 0; b < SLIDE_BITS; b++)
+				if (i >= b && ((taps >> (i - b)) & 1))
+					colv[i] |= 1u << b;
+		}
+		slide_bitmap[k_pn >> 5] |= 1u << (k_pn & 31);
+		int idx[5];
+		for (int k = 1; k <= max_ac_errors && k <= 5; k++) {
+			for (int i = 0; i < k; i++)
+				idx[i] = i;
+			for (;;) {
+				uint32_t v = k_pn;
+				for (int i = 0; i < k; i++)
+					v ^= colv[idx[i]];
+				slide_bitmap[v >> 5] |= 1u << (v & 31);
+				int i = k - 1;
+				while (i >= 0 && idx[i] == 57 - k + i)
+					i--;
+				if (i < 0)
+					break;
+				idx[i]++;
+				for (int j = i + 1; j < k; j++)
+					idx[j] = idx[j - 1] + 1;
+			}
+		}
+	}
+
+	// one block: tabA | tabB | bitmap | slide bitmap
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
-	size_t total = off_m + 4 * LDS_BITMAP_WORDS;
+	size_t off_s = off_m + 4 * LDS_BITMAP_WORDS;
+	size_t total = off_s + 4 * LDS_BITMAP_WORDS;
 	// Build the new set beside the old one and swap only when every copy has succeeded: a failure
 	// leaves the context as it was, and nothing is freed under a scan that may still be running.
 	struct Fresh {
@@ -325,6 +373,7 @@ static int upload_tables(int max_ac_errors)
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_m, mb.bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(base + off_s, slide_bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(fresh.hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipDeviceSynchronize());                   // scans queued on any stream still read the old tables
 	std::swap(c.d_tab_block, fresh.tab);
@@ -334,6 +383,7 @@ static int upload_tables(int max_ac_errors)
 	c.scan.tabA = (const uint32_t *)(base + off_a);
 	c.scan.tabB = (const uint32_t *)(base + off_b);
 	c.scan.bitmap = (const uint32_t *)(base + off_m);
+	c.scan.slide_bitmap = (const uint32_t *)(base + off_s);
 	c.scan.hslots = (const uint64_t *)c.d_hslots;
 	c.scan.hmask = mb.mask;
 	c.scan.kclass[0] = kclass[0];

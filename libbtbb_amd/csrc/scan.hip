@@ -230,6 +230,59 @@ __device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
 	return (proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2);
 }
 
+// 32 positions of the sliding check stream (slide.h): bit b = parity of the stream bits b + k over the taps k,
+// stream bit i = bit i of e2:e1:e0.  Taps and shifts are compile-time constants (a funnel shift by a
+// run-time amount costs more, see 3.2 of DESIGN.md).
+#ifndef SCAN_SLIDE
+#define SCAN_SLIDE 1
+#endif
+struct SlideTapList { int n; int k[32]; };
+constexpr SlideTapList slide_tap_list()
+{
+	SlideTapList l = {0, {0}};
+	for (int k = 0; k < 64; k++)
+		if ((SLIDE_TAPS >> k) & 1)
+			l.k[l.n++] = k;
+	return l;
+}
+__device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e2)
+{
+	constexpr SlideTapList taps = slide_tap_list();
+	uint32_t plane[32];
+#pragma unroll
+	for (int i = 0; i < taps.n; i++) {
+		const int k = taps.k[i];
+		if (k == 0)
+			plane[i] = e0;
+		else if (k < 32)
+			plane[i] = alignbit(e1, e0, k);
+		else if (k == 32)
+			plane[i] = e1;
+		else
+			plane[i] = alignbit(e2, e1, k - 32);
+	}
+	uint32_t acc = plane[0];
+#pragma unroll
+	for (int i = 1; i + 1 < taps.n; i += 2)
+		acc = xor3(acc, plane[i], plane[i + 1]);
+	if ((taps.n & 1) == 0)
+		acc ^= plane[taps.n - 1];
+	return acc;
+}
+
+// the low bits (b <= 63 - highest tap) of the same for wave-uniform dwords, written with 64-bit shifts so that it
+// stays on the SALU
+__device__ __forceinline__ uint32_t slide32_low_uniform(uint32_t e0, uint32_t e1)
+{
+	constexpr SlideTapList taps = slide_tap_list();
+	const uint64_t w = ((uint64_t)e1 << 32) | e0;
+	uint32_t acc = 0;
+#pragma unroll
+	for (int i = 0; i < taps.n; i++)
+		acc ^= (uint32_t)(w >> taps.k[i]);
+	return acc;
+}
+
 template <int VARIANT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 {
@@ -264,7 +317,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		char *ldsb = reinterpret_cast<char *>(lds);
 		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
 		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
-		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
+		const uint4 *srcM = reinterpret_cast<const uint4 *>(VARIANT == 1 ? a.t.slide_bitmap : a.t.bitmap);
 		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
 		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
 		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
@@ -468,7 +521,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			advance(cur);
 		}
 
-		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2];
+		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2], c[UNROLL][3];
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
@@ -486,6 +539,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			}
 			barker32(d[u][1], d[u][2], validA, m[u][0], cls[u][0]);    // offsets 0..31: window bits 57.. in d1:d2
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls[u][1]);    // offsets 32..63
+#ifdef SCAN_PROFILE
+			PROF_PIN(m[u][0]); PROF_PIN(m[u][1]);
+			if (u == UNROLL - 1) PROF_MARK(14);
+#endif
+			if (VARIANT == 1) {
+				// check stream of positions 0..31 and 32..63 of this word, and of 64..95 for the indices that start in 45..63 ...
+				c[u][0] = slide32(d[u][0], d[u][1], d[u][2]);
+				c[u][1] = slide32(d[u][1], d[u][2], d[u][3]);
+				// ... which is the first check dword of the next word, i.e. of the next lane (a wave-wide shift through
+				// the LDS crossbar; the DPP wave_shl form measured 1 % slower, computing it in place 3 %); lane 63
+				// takes it from the scalar unit: the halo word it holds, broadcast -- uniform values stay on the SALU
+				const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
+				const uint32_t last = slide32_low_uniform(s2, s3);
+				const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
+				c[u][2] = lane == 63 ? last : next;
+			}
 		}
 
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
@@ -503,6 +572,55 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			PROF_PIN(m[u][1]);
 		}
 		PROF_MARK(0);
+		if (VARIANT == 1) {
+			// Sliding checks (slide.h): the candidate index of the survivor at offset p is 19 bits of the check
+			// stream at p -- one funnel shift and one LDS read per survivor.
+			struct Stage { uint32_t p[UNROLL][2], v[UNROLL][2], bw[UNROLL][2], live[UNROLL][2]; };
+			auto any_left = [&]() {
+				uint32_t any = 0;
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+					any |= m[u][0] | m[u][1];
+				return __ballot(any != 0) != 0;
+			};
+			auto issue = [&](Stage &g) {              // next survivor of every chain: index, bitmap read in flight
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						g.p[u][h] = lowest_bit(m[u][h]);
+						g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
+						g.bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(g.v[u][h]));
+						g.live[u][h] = m[u][h] >> g.p[u][h];      // bit 0: this lane has a survivor (p = ~0 for m == 0)
+						m[u][h] &= m[u][h] - 1;
+					}
+			};
+			auto finish = [&](const Stage &g) {
+				uint32_t anybit = 0, bit[UNROLL][2];
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
+						anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
+					}
+				if (anybit & 1) {
+#pragma unroll
+					for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+						for (int h = 0; h < 2; h++)
+							if (bit[u][h] & g.live[u][h] & 1)
+								park(((it + u) << 12) | (lane << 6) | (h << 5) | (g.p[u][h] & 31),
+								     alignbit(d[u][h + 1], d[u][h], g.p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]));
+				}
+			};
+			for (uint32_t pass = 1; any_left(); pass++) {
+				Stage g;
+				issue(g);
+				finish(g);
+				PROF_MARK(pass < 13 ? pass : 13);
+			}
+		} else
 		for (uint32_t pass = 1;; pass++) {
 			uint32_t any = 0;
 #pragma unroll
@@ -950,7 +1068,7 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		}
 		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
 		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one)
-		int run_variant = 0;
+		int run_variant = SCAN_SLIDE ? 1 : 0;
 		if (c.scan.bitmap2 && c.table_errors >= 4)
 			run_variant = c.table_errors == 4 ? 9 : 8;
 #define LAUNCH_VARIANT(V) do { \
@@ -964,6 +1082,7 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		switch (run_variant) {
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
+		case 1: LAUNCH_VARIANT(1); break;
 		default: LAUNCH_VARIANT(0); break;
 		}
 #ifdef SCAN_PROFILE
