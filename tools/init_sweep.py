@@ -1,5 +1,5 @@
 import sys, ctypes as C, json
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch, numpy as np
 import libbtbb_amd as bt
 lib=bt.lib()
