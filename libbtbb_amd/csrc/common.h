@@ -29,7 +29,9 @@
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
 #endif
+#ifndef PARK_SLOTS
 #define PARK_SLOTS     2                   // private candidate slots per lane
+#endif
 #define CAND_BYTES     16                  // a parked candidate: position code + its 64-bit window + pad (one ds_*_b128)
 
 // LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a

@@ -99,6 +99,35 @@ def test_adversarial_all_candidates():
     assert len(got) >= 4096
 
 
+def test_adversarial_two_hits_per_word():
+    """Two access codes that START in the same 64-bit word, in every second word: a sync word at bit 0 and one at
+    bit 57 whose seven lowest (parity) bits equal the first one's seven highest (barker + LAP MSB) bits.  A lane
+    then has four candidates per trip of the scan loop and two private slots: the path that hands a survivor
+    back and compacts in the middle of a trip (sliding-check kernel) / checks in place (tables for >= 4 errors)."""
+    rng = np.random.default_rng(_libs.seed(77))
+    pairs = []
+    while len(pairs) < 24:
+        l1 = int(rng.integers(0, 1 << 24))
+        top7 = synth.syncword(l1) >> 57
+        for _ in range(4000):
+            l2 = int(rng.integers(0, 1 << 24))
+            if synth.syncword(l2) & 0x7F == top7:
+                pairs.append((l1, l2))
+                break
+    words = []
+    for k in range(3000):
+        s1, s2 = (synth.syncword(l) for l in pairs[k % len(pairs)])
+        both = s1 | (s2 << 57)                     # 121 bits: s2's low seven bits coincide with s1's top seven
+        words += [both & ((1 << 64) - 1), both >> 64]
+    words = np.array(words + [0], dtype=np.uint64)
+    sym = np.ascontiguousarray(synth.unpack_bits(words))
+    n = len(sym) - 63
+    for max_err in (0, 2):
+        got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, max_err))
+        assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, max_err)
+        assert len(got) >= 6000
+
+
 def test_symbols_entry_and_pack_roundtrip():
     words, sym, _ = stream(104, 1 << 10, stride=512)
     n = len(sym) - 63
