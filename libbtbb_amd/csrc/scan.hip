@@ -910,6 +910,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			valid = first_off >= a.search_bits ? 0ULL
 				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 		}
+		__builtin_amdgcn_s_setprio(0);                  // bit-sliced filter: lowest (see PRIO_FILTER above)
 		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
 		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
 		uint32_t mA, mB;
@@ -922,6 +923,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 		mA &= (uint32_t)valid;
 		mB &= (uint32_t)(valid >> 32);
+		__builtin_amdgcn_s_setprio(3);                  // survivors, hit staging, flush and the next tile's loads: highest
 		// wave-uniform survivor loop, one offset of each half per pass
 		while (__ballot((mA | mB) != 0)) {
 			const uint32_t pA = __builtin_ctz(mA | 0x80000000u), pB = __builtin_ctz(mB | 0x80000000u);
