@@ -99,6 +99,12 @@ void btbbx_shutdown(void);
 const char *btbbx_last_error(void);
 int btbbx_device_count(void);
 int btbbx_table_errors(void);          /* the max_ac_errors the tables were built with */
+/* Host-only diagnostic, no device needed: the candidate set the LAP_ANY scan probes for every offset that passes
+ * the barker filter -- all values of nineteen sliding parity checks of the (64,30) code (gen_syndrome's generator,
+ * bluetooth_packet.c:147-159) that a window within max_ac_errors of a sync word can take, as a 2^19-bit set in
+ * 16384 words.  *taps (may be NULL) receives the check's tap pattern: check b of a window w is the parity of
+ * w & (taps << b), b = 0..18.  Returns the number of members or a negative BTBBX_E_*. */
+int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64_t *taps);
 
 /* ---- device memory helpers (so C callers need not link HIP themselves) -------- */
 void *btbbx_malloc(size_t bytes);

@@ -255,6 +255,74 @@ struct MapBuilder {
 	}
 };
 
+// The candidate set of the sliding checks (slide.h): index bit b = parity of the window ^ PN under the
+// taps shifted to b; a window the reference accepts differs from a codeword in at most max_ac_errors of
+// the bits 0..56 (the map's patterns reach bit 57, which the checks do not touch), so its index is K ^ the
+// XOR of that many columns.  Host only.  Returns the number of members or a negative error.
+static_assert(SLIDE_BITS == BITMAP_BITS, "both candidate sets use the same LDS region");
+static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<uint32_t> &slide_bitmap)
+{
+	slide_bitmap.assign(LDS_BITMAP_WORDS, 0);
+	const uint64_t taps = SLIDE_TAPS;
+	for (int b = 0; b < SLIDE_BITS; b++)           // every check must annihilate every codeword
+		for (int r = 0; r < 30; r++) {
+			const uint64_t row = (1ULL << (34 + r)) | t.col[34 + r];
+			if (((taps << b) >> 57) || (__builtin_popcountll(row & (taps << b)) & 1)) {
+				set_error("btbb_init: the sliding parity check does not hold for this generator");
+				return BTBBX_E_ARG;
+			}
+		}
+	uint32_t colv[57], k_pn = 0;
+	for (int b = 0; b < SLIDE_BITS; b++)
+		k_pn |= (uint32_t)(__builtin_popcountll(SW_PN & (taps << b)) & 1) << b;
+	for (int i = 0; i < 57; i++) {
+		colv[i] = 0;
+		for (int b = 0; b < SLIDE_BITS; b++)
+			if (i >= b && ((taps >> (i - b)) & 1))
+				colv[i] |= 1u << b;
+	}
+	slide_bitmap[k_pn >> 5] |= 1u << (k_pn & 31);
+	int idx[5];
+	for (int k = 1; k <= max_ac_errors && k <= 5; k++) {
+		for (int i = 0; i < k; i++)
+			idx[i] = i;
+		for (;;) {
+			uint32_t v = k_pn;
+			for (int i = 0; i < k; i++)
+				v ^= colv[idx[i]];
+			slide_bitmap[v >> 5] |= 1u << (v & 31);
+			int i = k - 1;
+			while (i >= 0 && idx[i] == 57 - k + i)
+				i--;
+			if (i < 0)
+				break;
+			idx[i]++;
+			for (int j = i + 1; j < k; j++)
+				idx[j] = idx[j - 1] + 1;
+		}
+	}
+	int members = 0;
+	for (uint32_t w : slide_bitmap)
+		members += __builtin_popcount(w);
+	return members;
+}
+
+extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64_t *taps)
+{
+	if (max_ac_errors < 0 || !bitmap_words) {
+		set_error("btbbx_slide_set: bad argument");
+		return BTBBX_E_ARG;
+	}
+	std::vector<uint32_t> set;
+	const int members = build_slide_set(host_tables(), max_ac_errors, set);
+	if (members < 0)
+		return members;
+	memcpy(bitmap_words, set.data(), set.size() * sizeof(uint32_t));
+	if (taps)
+		*taps = SLIDE_TAPS;
+	return members;
+}
+
 static int upload_tables(int max_ac_errors)
 {
 	const HostTables &t = host_tables();
@@ -306,51 +374,11 @@ static int upload_tables(int max_ac_errors)
 		tabB[v] = (uint32_t)s;
 	}
 
-	// The candidate set of the sliding checks (slide.h): index bit b = parity of the window ^ PN under the
-	// taps shifted to b; a window the reference accepts differs from a codeword in at most max_ac_errors of
-	// the bits 0..56 (the map's patterns reach bit 57, which the checks do not touch), so its index is K ^ the
-	// XOR of that many columns.
-	static_assert(SLIDE_BITS == BITMAP_BITS, "both candidate sets use the same LDS region");
-	std::vector<uint32_t> slide_bitmap(LDS_BITMAP_WORDS, 0);
+	std::vector<uint32_t> slide_bitmap;
 	{
-		const uint64_t taps = SLIDE_TAPS;
-		for (int b = 0; b < SLIDE_BITS; b++)           // every check must annihilate every codeword
-			for (int r = 0; r < 30; r++) {
-				const uint64_t row = (1ULL << (34 + r)) | t.col[34 + r];
-				if (((taps << b) >> 57) || (__builtin_popcountll(row & (taps << b)) & 1)) {
-					set_error("btbb_init: the sliding parity check does not hold for this generator");
-					return BTBBX_E_ARG;
-				}
-			}
-		uint32_t colv[57], k_pn = 0;
-		for (int b = 0; b < SLIDE_BITS; b++)
-			k_pn |= (uint32_t)(__builtin_popcountll(SW_PN & (taps << b)) & 1) << b;
-		for (int i = 0; i < 57; i++) {
-			colv[i] = 0;
-			for (int b = 0; b < SLIDE_BITS; b++)
-				if (i >= b && ((taps >> (i - b)) & 1))
-					colv[i] |= 1u << b;
-		}
-		slide_bitmap[k_pn >> 5] |= 1u << (k_pn & 31);
-		int idx[5];
-		for (int k = 1; k <= max_ac_errors && k <= 5; k++) {
-			for (int i = 0; i < k; i++)
-				idx[i] = i;
-			for (;;) {
-				uint32_t v = k_pn;
-				for (int i = 0; i < k; i++)
-					v ^= colv[idx[i]];
-				slide_bitmap[v >> 5] |= 1u << (v & 31);
-				int i = k - 1;
-				while (i >= 0 && idx[i] == 57 - k + i)
-					i--;
-				if (i < 0)
-					break;
-				idx[i]++;
-				for (int j = i + 1; j < k; j++)
-					idx[j] = idx[j - 1] + 1;
-			}
-		}
+		const int rc_slide = build_slide_set(t, max_ac_errors, slide_bitmap);
+		if (rc_slide < 0)
+			return rc_slide;
 	}
 
 	// one block: tabA | tabB | bitmap | slide bitmap

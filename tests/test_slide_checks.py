@@ -58,3 +58,37 @@ def test_index_of_a_damaged_sync_word_is_a_sum_of_columns(tmp_path):
             expect ^= col[int(e)]
         window ^= int(rng.integers(0, 128)) << 57
         assert index(window) == expect
+
+
+def test_product_candidate_set_contains_every_acceptable_window(tmp_path):
+    """btbbx_slide_set (host only) is the set the kernel loads into LDS: every window the reference's rule can accept --
+    a sync word with at most n errors in bits 0..56 and anything in the seven bits the barker correction replaces --
+    must be a member, and the set must be no larger than the patterns allow."""
+    import ctypes as C
+    from math import comb
+
+    import libbtbb_amd as bt
+
+    lib = bt.lib()                      # loads without a GPU; this entry point makes no HIP call
+    taps_c, bits = _slide_constants(tmp_path)
+    orc = oracle()
+    rng = np.random.default_rng(seed(4102))
+    for n in (0, 1, 2, 3):
+        words = (C.c_uint32 * (1 << (bits - 5)))()
+        taps = C.c_uint64(0)
+        members = lib.btbbx_slide_set(n, words, C.byref(taps))
+        assert taps.value == taps_c
+        assert 1 <= members <= sum(comb(57, k) for k in range(n + 1))
+        bitmap = np.frombuffer(words, dtype=np.uint32)
+        assert int(np.unpackbits(bitmap.view(np.uint8)).sum()) == members
+        for _ in range(1500):
+            window = orc.orc_gen_syncword(int(rng.integers(0, 1 << 24)))
+            for e in rng.choice(57, size=int(rng.integers(0, n + 1)), replace=False):
+                window ^= 1 << int(e)
+            window ^= int(rng.integers(0, 128)) << 57
+            idx = sum((bin(window & (taps_c << b)).count("1") & 1) << b for b in range(bits))
+            assert (int(bitmap[idx >> 5]) >> (idx & 31)) & 1, (n, hex(window))
+    # two errors: the distinct XORs of at most two columns, rebuilt here from the tap pattern
+    col = [sum((((taps_c >> (i - b)) & 1) if i >= b else 0) << b for b in range(bits)) for i in range(57)]
+    distinct = {0} | set(col) | {col[i] ^ col[j] for i in range(57) for j in range(i)}
+    assert lib.btbbx_slide_set(2, words, None) == len(distinct)
