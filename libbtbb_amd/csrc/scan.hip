@@ -230,9 +230,7 @@ __device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
 	return (proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2);
 }
 
-// 32 positions of the sliding check stream (slide.h): bit b = parity of the stream bits b + k over the taps k,
-// stream bit i = bit i of e2:e1:e0.  Taps and shifts are compile-time constants (a funnel shift by a
-// run-time amount costs more, see 3.2 of DESIGN.md).
+// SCAN_SLIDE 0 builds the library with the table-probe kernel of rounds 1-2 (scan_lap_any_kernel<0>) for A/B runs
 #ifndef SCAN_SLIDE
 #define SCAN_SLIDE 1
 #endif
@@ -256,6 +254,9 @@ constexpr SlideTapList slide_tap_list()
 			l.k[l.n++] = k;
 	return l;
 }
+// 32 positions of the sliding check stream (slide.h): bit b = parity of the stream bits b + k over the taps k,
+// stream bit i = bit i of e2:e1:e0.  Taps and shifts are compile-time constants (a funnel shift by a
+// run-time amount costs more, see 3.2 of DESIGN.md).
 __device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e2)
 {
 	constexpr SlideTapList taps = slide_tap_list();
