@@ -401,6 +401,7 @@ def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gath
     d_out = DeviceBuffer(n * PKTOUT_DTYPE.itemsize).zero()
     d_len = DeviceBuffer(n * 4).zero()
     pkt_in = np.array(pkt_in, copy=True)
+    d_in = d_pk = None
     try:
         if via_gather:
             d_pk = DeviceBuffer(n * PKT_WORDS * 8).zero()
@@ -411,7 +412,6 @@ def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gath
             pkt_in["length"] = lengths
             d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
             check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
-            d_pk.free()
         else:
             d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
             check(lib().btbbx_decode_hits_device(d_w.ptr, n_words, n_words, d_h.ptr, d_in.ptr, n, max_length, d_out.ptr,
@@ -419,8 +419,9 @@ def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gath
         check(lib().btbbx_sync(None))
         return d_out.download(PKTOUT_DTYPE, n), d_len.download(np.uint32, n)
     finally:
-        for b in (d_w, d_h, d_out, d_len, d_in):
-            b.free()
+        for b in (d_w, d_h, d_out, d_len, d_in, d_pk):
+            if b is not None:
+                b.free()
 
 
 # ---- hop selection / CLK1-27 reversal -------------------------------------------------------

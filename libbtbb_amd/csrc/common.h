@@ -90,7 +90,7 @@ uint64_t host_syndrome(uint64_t cw);
 // entry point works on the context of the calling thread's CURRENT device, so one-process-per-GPU
 // callers (hipSetDevice once) and one-process-many-GPUs callers (btbbx_scan_host_multi: one host
 // thread per device) go through the same code.
-#define BTBBX_MAX_DEVICES 16
+#define BTBBX_MAX_DEVICES 64          // CPX partitioning exposes up to 64 ordinals per node
 
 struct Ctx {
 	bool ready = false;
@@ -101,6 +101,7 @@ struct Ctx {
 	void *d_tab_block = nullptr;
 	void *d_hslots = nullptr;
 	void *d_bitmap2 = nullptr;
+	void *d_retired_tab = nullptr, *d_retired_hslots = nullptr, *d_retired_bitmap2 = nullptr;   // previous table set (context.cpp upload_tables)
 };
 
 Ctx &ctx();                              // context of the current device (never null; maybe !ready)
@@ -119,6 +120,7 @@ struct CallScope {
 };
 void *scope_device(size_t bytes);        // grow-only device scratch of the innermost live scope
 void *scope_pinned(size_t bytes);        // grow-only pinned host staging
+void *scope_hits(size_t bytes);          // grow-only device block for hit records + counter of host-level scans
 void *scope_packet_block(void **pinned_mirror, size_t bytes);   // fixed-size device block + pinned mirror
 hipStream_t scope_stream();              // private non-blocking stream of the lease
 

@@ -13,7 +13,11 @@
 #include <vector>
 #include "common.h"
 
-static Ctx g_ctx[BTBBX_MAX_DEVICES];
+// One context per HIP ordinal 0 .. BTBBX_MAX_DEVICES-1, plus one slot that is NEVER ready: an ordinal outside the
+// range (or a failing hipGetDevice) maps there, so every entry point fails with BTBBX_E_NOTINIT / BTBBX_E_ARG and a
+// message instead of silently running with device 0's tables and scratch.
+#define NO_DEVICE_SLOT BTBBX_MAX_DEVICES
+static Ctx g_ctx[BTBBX_MAX_DEVICES + 1];
 static std::mutex g_init_lock;            // table builds / re-builds and shutdown
 static int g_table_errors = 0;            // process-wide: the first non-zero btbb_init value
 static thread_local char g_err[512] = "";
@@ -22,7 +26,7 @@ static int current_device()
 {
 	int d = 0;
 	if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BTBBX_MAX_DEVICES)
-		return 0;
+		return NO_DEVICE_SLOT;
 	return d;
 }
 
@@ -60,6 +64,13 @@ extern "C" int btbbx_table_errors(void)
 
 int ctx_require()
 {
+	if (current_device() == NO_DEVICE_SLOT) {
+		int d = -1;
+		(void)hipGetDevice(&d);
+		set_error("btbbx: the current HIP device (ordinal %d) is outside the %d contexts this library keeps "
+			  "(BTBBX_MAX_DEVICES) or could not be queried", d, BTBBX_MAX_DEVICES);
+		return BTBBX_E_ARG;
+	}
 	if (!ctx().ready) {
 		set_error("btbbx: not initialised on this device (call btbb_init / btbbx_init / btbbx_init_devices first)");
 		return BTBBX_E_NOTINIT;
@@ -77,11 +88,13 @@ struct CallBufs {
 	size_t pinned_bytes = 0;
 	void *pkt_dev = nullptr, *pkt_host = nullptr;
 	size_t pkt_bytes = 0;
+	void *d_hits = nullptr;                  // hit records + counter of the host-level scans (scope_hits)
+	size_t hits_bytes = 0;
 	hipStream_t stream = nullptr;
 };
 
 static std::mutex g_pool_lock;
-static std::vector<CallBufs *> g_pool[BTBBX_MAX_DEVICES];
+static std::vector<CallBufs *> g_pool[BTBBX_MAX_DEVICES + 1];
 static thread_local CallBufs *tl_bufs = nullptr;
 static thread_local int tl_depth = 0;
 
@@ -91,6 +104,7 @@ static void bufs_free(CallBufs *b)
 	if (b->h_pinned) (void)hipHostFree(b->h_pinned);
 	if (b->pkt_dev) (void)hipFree(b->pkt_dev);
 	if (b->pkt_host) (void)hipHostFree(b->pkt_host);
+	if (b->d_hits) (void)hipFree(b->d_hits);
 	if (b->stream) (void)hipStreamDestroy(b->stream);
 	delete b;
 }
@@ -157,6 +171,32 @@ void *scope_device(size_t bytes)
 	}
 	b->scratch_bytes = want;
 	return b->d_scratch;
+}
+
+// Grow-only device block for the hit list (and its counter) of a host-level scan: in steady state a drop-in
+// caller allocates nothing (hipFree synchronises the whole device, which would serialise concurrent callers).
+void *scope_hits(size_t bytes)
+{
+	CallBufs *b = tl_bufs;
+	if (!b) {
+		set_error("internal: scope_hits outside a CallScope");
+		return nullptr;
+	}
+	if (bytes <= b->hits_bytes)
+		return b->d_hits;
+	if (b->d_hits) {
+		if (b->stream) (void)hipStreamSynchronize(b->stream);
+		(void)hipFree(b->d_hits);
+	}
+	b->d_hits = nullptr;
+	b->hits_bytes = 0;
+	const size_t want = bytes + bytes / 4 + 4096;
+	if (hipMalloc(&b->d_hits, want) != hipSuccess) {
+		set_error("btbbx: hit buffer allocation of %zu bytes failed", want);
+		return nullptr;
+	}
+	b->hits_bytes = want;
+	return b->d_hits;
 }
 
 void *scope_pinned(size_t bytes)
@@ -259,10 +299,10 @@ struct MapBuilder {
 // taps shifted to b; a window the reference accepts differs from a codeword in at most max_ac_errors of
 // the bits 0..56 (the map's patterns reach bit 57, which the checks do not touch), so its index is K ^ the
 // XOR of that many columns.  Host only.  Returns the number of members or a negative error.
-static_assert(SLIDE_BITS == BITMAP_BITS, "both candidate sets use the same LDS region");
+#define SLIDE_WORDS (1u << (SLIDE_BITS - 5))
 static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<uint32_t> &slide_bitmap)
 {
-	slide_bitmap.assign(LDS_BITMAP_WORDS, 0);
+	slide_bitmap.assign(SLIDE_WORDS, 0);
 	const uint64_t taps = SLIDE_TAPS;
 	for (int b = 0; b < SLIDE_BITS; b++)           // every check must annihilate every codeword
 		for (int r = 0; r < 30; r++) {
@@ -384,9 +424,9 @@ static int upload_tables(int max_ac_errors)
 	// one block: tabA | tabB | bitmap | slide bitmap
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
 	size_t off_s = off_m + 4 * LDS_BITMAP_WORDS;
-	size_t total = off_s + 4 * LDS_BITMAP_WORDS;
+	size_t total = off_s + 4 * SLIDE_WORDS;
 	// Build the new set beside the old one and swap only when every copy has succeeded: a failure
-	// leaves the context as it was, and nothing is freed under a scan that may still be running.
+	// leaves the context as it was; the replaced set outlives the swap by one re-build (see below).
 	struct Fresh {
 		void *tab = nullptr, *hslots = nullptr, *bitmap2 = nullptr;
 		~Fresh() { if (tab) (void)hipFree(tab); if (hslots) (void)hipFree(hslots); if (bitmap2) (void)hipFree(bitmap2); }
@@ -401,12 +441,22 @@ static int upload_tables(int max_ac_errors)
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_m, mb.bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(base + off_s, slide_bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(base + off_s, slide_bitmap.data(), 4 * SLIDE_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(fresh.hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipDeviceSynchronize());                   // scans queued on any stream still read the old tables
-	std::swap(c.d_tab_block, fresh.tab);
-	std::swap(c.d_hslots, fresh.hslots);
-	std::swap(c.d_bitmap2, fresh.bitmap2);             // `fresh` now owns the old set and frees it
+	// The set just replaced is not freed here: a launcher on another thread may have copied `c.scan` (the old
+	// pointers) a moment ago and not launched yet.  It is parked in the context and freed by the NEXT re-build,
+	// i.e. after one more hipDeviceSynchronize() -- by then every launch that could have seen it has finished.
+	if (c.d_retired_tab) (void)hipFree(c.d_retired_tab);
+	if (c.d_retired_hslots) (void)hipFree(c.d_retired_hslots);
+	if (c.d_retired_bitmap2) (void)hipFree(c.d_retired_bitmap2);
+	c.d_retired_tab = c.d_tab_block;
+	c.d_retired_hslots = c.d_hslots;
+	c.d_retired_bitmap2 = c.d_bitmap2;
+	c.d_tab_block = fresh.tab;
+	c.d_hslots = fresh.hslots;
+	c.d_bitmap2 = fresh.bitmap2;
+	fresh.tab = fresh.hslots = fresh.bitmap2 = nullptr;
 	base = (char *)c.d_tab_block;
 	c.scan.tabA = (const uint32_t *)(base + off_a);
 	c.scan.tabB = (const uint32_t *)(base + off_b);
@@ -432,6 +482,13 @@ static int upload_tables(int max_ac_errors)
 static int init_current_device(int max_ac_errors)
 {
 	const int dev = current_device();
+	if (dev == NO_DEVICE_SLOT) {
+		int d = -1;
+		(void)hipGetDevice(&d);
+		set_error("btbbx_init: HIP device ordinal %d is not below BTBBX_MAX_DEVICES = %d (or hipGetDevice failed)", d,
+			  BTBBX_MAX_DEVICES);
+		return BTBBX_E_ARG;
+	}
 	Ctx &c = g_ctx[dev];
 	// first non-zero max_ac_errors builds the map, later calls keep it -- for the whole process, as in
 	// the reference (bluetooth_packet.c:288-289: `if ((syndrome_map == NULL) && (max_ac_errors))`)
@@ -527,6 +584,9 @@ extern "C" void btbbx_shutdown(void)
 		if (c.d_tab_block) (void)hipFree(c.d_tab_block);
 		if (c.d_hslots) (void)hipFree(c.d_hslots);
 		if (c.d_bitmap2) (void)hipFree(c.d_bitmap2);
+		if (c.d_retired_tab) (void)hipFree(c.d_retired_tab);
+		if (c.d_retired_hslots) (void)hipFree(c.d_retired_hslots);
+		if (c.d_retired_bitmap2) (void)hipFree(c.d_retired_bitmap2);
 		c = Ctx();
 	}
 	g_table_errors = 0;

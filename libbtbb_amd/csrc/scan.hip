@@ -115,6 +115,7 @@ __device__ __forceinline__ void lds_st4(uint32_t byte_off, u32x4 v) { *reinterpr
 // w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
 // batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
 // HBM traffic).
+template <bool LDS_TABLES = true>
 __device__ __forceinline__ bool verify_lap_any(const ScanArgs &a, uint64_t w, uint32_t &lap, uint32_t &nerr_out)
 {
 	uint32_t win = (uint32_t)(w >> 57);
@@ -125,8 +126,9 @@ __device__ __forceinline__ bool verify_lap_any(const ScanArgs &a, uint64_t w, ui
 	// byte tables in global memory cost eight divergent loads per candidate, which is what bounded
 	// the scan for tables built for three or more errors.)
 	const uint64_t low = w & LOW57;
-	const uint32_t s_lo = (uint32_t)low ^ lds_ld(LDS_OFF_TABA + (((uint32_t)(low >> TABA_FIRST) & ((1u << TABA_BITS) - 1)) << 2))
-			      ^ lds_ld(LDS_OFF_TABB + ((uint32_t)(low >> (TABA_FIRST + TABA_BITS)) << 2)) ^ (cls ? a.t.kdiff : 0u);
+	const uint32_t ia = (uint32_t)(low >> TABA_FIRST) & ((1u << TABA_BITS) - 1), ib = (uint32_t)(low >> (TABA_FIRST + TABA_BITS));
+	const uint32_t s_lo = (uint32_t)low ^ (LDS_TABLES ? lds_ld(LDS_OFF_TABA + (ia << 2)) : a.t.tabA[ia])
+			      ^ (LDS_TABLES ? lds_ld(LDS_OFF_TABB + (ib << 2)) : a.t.tabB[ib]) ^ (cls ? a.t.kdiff : 0u);
 	const uint32_t s_hi = ((uint32_t)(a.t.kclass[cls] >> 32) ^ (__popcll(low & a.t.hi_mask[0]) & 1)
 			       ^ ((__popcll(low & a.t.hi_mask[1]) & 1) << 1)) & 3;
 	const uint64_t syn = ((uint64_t)s_hi << 32) | s_lo;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		char *ldsb = reinterpret_cast<char *>(lds);
 		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
 		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
-		const uint4 *srcM = reinterpret_cast<const uint4 *>(VARIANT == 1 ? a.t.slide_bitmap : a.t.bitmap);
+		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
 		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
 		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
 		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
@@ -533,9 +535,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			advance(cur);
 		}
 
-		if (VARIANT == 1 && PRIO_FILTER != PRIO_CAND)
-			__builtin_amdgcn_s_setprio(PRIO_FILTER);
-		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2], c[UNROLL][3];
+		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2];
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
@@ -557,18 +557,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			PROF_PIN(m[u][0]); PROF_PIN(m[u][1]);
 			if (u == UNROLL - 1) PROF_MARK(14);
 #endif
-			if (VARIANT == 1) {
-				// check stream of positions 0..31 and 32..63 of this word, and of 64..95 for the indices that start in 45..63 ...
-				c[u][0] = slide32(d[u][0], d[u][1], d[u][2]);
-				c[u][1] = slide32(d[u][1], d[u][2], d[u][3]);
-				// ... which is the first check dword of the next word, i.e. of the next lane (a wave-wide shift through
-				// the LDS crossbar; the DPP wave_shl form measured 1 % slower, computing it in place 3 %); lane 63
-				// takes it from the scalar unit: the halo word it holds, broadcast -- uniform values stay on the SALU
-				const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
-				const uint32_t last = slide32_low_uniform(s2, s3);
-				const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
-				c[u][2] = lane == 63 ? last : next;
-			}
 		}
 
 		// Survivor loop: runs while any lane of the wave has survivors; each pass takes one
@@ -586,57 +574,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			PROF_PIN(m[u][1]);
 		}
 		PROF_MARK(0);
-		if (VARIANT == 1) {
-			// Sliding checks (slide.h): the candidate index of the survivor at offset p is 19 bits of the check
-			// stream at p -- one funnel shift and one LDS read per survivor.
-			struct Stage { uint32_t p[UNROLL][2], v[UNROLL][2], bw[UNROLL][2], live[UNROLL][2]; };
-			auto any_left = [&]() {
-				uint32_t any = 0;
-#pragma unroll
-				for (int u = 0; u < UNROLL; u++)
-					any |= m[u][0] | m[u][1];
-				return __ballot(any != 0) != 0;
-			};
-			auto issue = [&](Stage &g) {              // next survivor of every chain: index, bitmap read in flight
-#pragma unroll
-				for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-					for (int h = 0; h < 2; h++) {
-						g.p[u][h] = lowest_bit(m[u][h]);
-						g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
-						g.bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(g.v[u][h]));
-						g.live[u][h] = m[u][h] >> g.p[u][h];      // bit 0: this lane has a survivor (p = ~0 for m == 0)
-						m[u][h] &= m[u][h] - 1;
-					}
-			};
-			auto finish = [&](const Stage &g) {
-				uint32_t anybit = 0, bit[UNROLL][2];
-#pragma unroll
-				for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-					for (int h = 0; h < 2; h++) {
-						bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
-						anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
-					}
-				if (anybit & 1) {
-#pragma unroll
-					for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-						for (int h = 0; h < 2; h++)
-							if (bit[u][h] & g.live[u][h] & 1)
-								park(((it + u) << 12) | (lane << 6) | (h << 5) | (g.p[u][h] & 31),
-								     alignbit(d[u][h + 1], d[u][h], g.p[u][h]), alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]));
-				}
-			};
-			__builtin_amdgcn_s_setprio(PRIO_LOOP);
-			for (uint32_t pass = 1; any_left(); pass++) {
-				Stage g;
-				issue(g);
-				finish(g);
-				PROF_MARK(pass < 13 ? pass : 13);
-			}
-			__builtin_amdgcn_s_setprio(PRIO_CAND);
-		} else
 		for (uint32_t pass = 1;; pass++) {
 			uint32_t any = 0;
 #pragma unroll
@@ -728,6 +665,330 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	if (lane < 32)
 		atomicAdd(&g_scan_prof[lane], (unsigned long long)lds_ld(prof_off + 4u * lane));
 #endif
+}
+
+
+// ---- LAP_ANY, sliding checks (tables for <= 3 errors) ----------------------------------------------
+//
+// The kernel of the headline path (promiscuous_packet_search, bluetooth_packet.c:368-420).  Per trip of
+// TILES tiles: the bit-sliced barker filter (barker32) and the check stream (slide32, slide.h) for both
+// halves of the lane's words, then the lock-step survivor loop -- one funnel shift into the check stream and
+// ONE read of the 2^SLIDE_BITS-bit candidate set in LDS per survivor.  A candidate goes straight to the wave's
+// ring in LDS (ballot + mbcnt, no atomics); the exact reference rule (verify_lap_any, syndrome tables read
+// through L2) runs on ring batches of up to 64.  The ring is the only LDS besides the set, so TWO workgroups
+// fit a CU: 2 x 768 threads = 6 waves per SIMD at <= 80 VGPRs (76 KiB of LDS each).  Measured on one box,
+// 4 GiB, ms per launch (profiles/r03_ab/): one 1024-thread workgroup per CU (4 waves per SIMD) 4.12, 2 x 1024
+// (8 waves, 64 VGPRs, spills outside the loop) 3.82-3.90, 2 x 768 3.59, 2 x 896 / 832 / 704 / 640 (waves that do
+// not divide evenly over the four SIMDs) 4.4-5.6; the 2^20-bit set (128 KiB, one workgroup per CU only) 3.81.
+// Candidates ranked beyond the ring's free entries are checked in place, never dropped (a stream made of sync
+// words: tests/test_gpu_scan.py adversarial cases).
+#ifndef SLIDE_TILES
+#define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane)
+#endif
+#ifndef SLIDE_WGS
+#define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
+#endif
+#ifndef SLIDE_THREADS
+#define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD)
+#endif
+#ifndef SLIDE_WAVES_PER_EU
+#define SLIDE_WAVES_PER_EU (SLIDE_WGS * SLIDE_THREADS / 256)
+#endif
+#ifndef SLIDE_PREFETCH
+#define SLIDE_PREFETCH 1                   // next tiles loaded while these are worked on (0: 8 VGPRs less, same time at 6 waves per SIMD)
+#endif
+#ifndef SLIDE_SINGLE
+#define SLIDE_SINGLE 1                     // fast path for the event "one lane of the wave holds a candidate" (1 % of the launch)
+#endif
+#ifndef SLIDE_FIXED
+#define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (0: +3 %)
+#endif
+#define SLIDE_SET_WORDS  (1u << (SLIDE_BITS - 5))
+#define SLIDE_SET_BYTES  (4u * SLIDE_SET_WORDS)
+template <int WGS> struct SlideGeom {
+	static constexpr uint32_t RING = WGS == 2 ? 64 : 128;               // ring entries per wave
+	static constexpr uint32_t LDS_BYTES = SLIDE_SET_BYTES + CAND_BYTES * (SLIDE_THREADS / 64) * RING;
+};
+
+template <int TILES, int WGS>
+__global__ __launch_bounds__(SLIDE_THREADS) __attribute__((amdgpu_waves_per_eu(SLIDE_WAVES_PER_EU, SLIDE_WAVES_PER_EU)))
+void scan_slide_kernel(ScanArgs a)
+{
+	extern __shared__ uint32_t lds[];
+	constexpr uint32_t RING = SlideGeom<WGS>::RING;
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: ring addresses stay on the SALU
+	const uint32_t ring_off = SLIDE_SET_BYTES + CAND_BYTES * wave * RING;
+
+	// tile order: one contiguous eighth of the tiles per XCD, its workgroups interleaved (see scan_lap_any_kernel)
+	uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, n_mine;
+	if (a.xcd_tiles) {
+		const uint32_t xcd = blockIdx.x & 7, lo_t = xcd * a.xcd_tiles;
+		const uint32_t hi_t = min((uint64_t)lo_t + a.xcd_tiles, a.n_tiles);
+		tile_step = gridDim.x >> 3;
+		first_tile = lo_t + (blockIdx.x >> 3);
+		n_mine = first_tile < hi_t ? (hi_t - first_tile + tile_step - 1) / tile_step : 0;
+	} else {
+		n_mine = first_tile < a.n_tiles ? (uint32_t)((a.n_tiles - first_tile + tile_step - 1) / tile_step) : 0;
+	}
+
+	{	// candidate set -> LDS byte 0, 16 bytes per lane per step
+		const uint4 *src = reinterpret_cast<const uint4 *>(a.t.slide_bitmap);
+		uint4 *dst = reinterpret_cast<uint4 *>(lds);
+		for (uint32_t i = tid; i < SLIDE_SET_WORDS / 4; i += SLIDE_THREADS)
+			dst[i] = src[i];
+	}
+	__syncthreads();
+
+	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
+	// code = (tile iteration << 12) | (lane that owns the word << 6) | offset in the word
+	auto code_word = [&](uint32_t code, uint32_t &stream) {
+		const uint32_t tile = first_tile + (code >> 12) * tile_step;
+		uint32_t t = tile;
+		stream = 0;
+		if (a.n_streams > 1) {
+			stream = tile / (uint32_t)a.tiles_per_stream;
+			t = tile - stream * (uint32_t)a.tiles_per_stream;
+		}
+		return (uint64_t)t * SLIDE_THREADS + wave * 64 + ((code >> 6) & 63);
+	};
+	// hits: up to 64 pending records per wave in registers, written 1 KiB at a time behind one counter atomic
+	uint32_t pend = 0;                            // wave-uniform
+	uint32_t h_off = 0, h_hi = 0, h_lap = 0;      // lane k < pend: offset low, offset high | stream << 16, lap << 8 | errors
+	auto flush_hits = [&]() {
+		if (pend == 0)
+			return;
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(a.hit_count, pend);
+		base = __builtin_amdgcn_readfirstlane(base);
+		const uint32_t idx = base + lane;
+		if (lane < pend && idx < a.hit_cap) {
+			uint4 rec;
+			rec.x = h_off;
+			rec.y = h_hi & 0xffff;
+			rec.z = h_lap >> 8;
+			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
+			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+		}
+		pend = 0;
+	};
+	auto push_hits = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t lap, uint32_t nerr) {
+		if (a.first) {                            // first-match mode: atomicMin, hits go out one by one
+			if (hit)
+				emit_hit(a, stream, offset, lap, nerr);
+			return;
+		}
+		const uint64_t m = __ballot(hit);
+		if (!m)
+			return;
+		const uint32_t c = (uint32_t)__popcll(m);
+		if (pend + c > 64)
+			flush_hits();
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+		const int dst = (int)((hit ? pend + rank : (pend ? 0u : c)) << 2);
+		const uint32_t r_off = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(uint32_t)offset);
+		const uint32_t r_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((uint32_t)(offset >> 32) | (stream << 16)));
+		const uint32_t r_lap = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)((lap << 8) | nerr));
+		if (lane - pend < c) {
+			h_off = r_off;
+			h_hi = r_hi;
+			h_lap = r_lap;
+		}
+		pend += c;
+	};
+	auto drain = [&](uint32_t n) {               // the n <= 64 oldest ring entries through the exact rule
+		bool hit = false;
+		uint32_t stream = 0, lap = 0, nerr = 0;
+		uint64_t offset = 0;
+		if (lane < n) {
+			const u32x4 rec = lds_ld4(ring_off + CAND_BYTES * ((q_head + lane) & (RING - 1)));
+			const uint32_t code = rec.x;
+			const uint64_t w = ((uint64_t)rec.z << 32) | rec.y;
+			offset = code_word(code, stream) * 64 + (code & 63);
+			hit = verify_lap_any<false>(a, w, lap, nerr);
+		}
+		push_hits(hit, stream, offset, lap, nerr);
+		q_head += n;
+	};
+
+	struct Cursor { uint32_t stream; uint32_t t; };
+	const uint32_t tiles_per_stream = (uint32_t)a.tiles_per_stream;
+	Cursor cur = {a.n_streams, 0};               // stream == n_streams: nothing (left) to do
+	uint32_t handed = 0;
+	if (n_mine) {
+		cur.stream = a.n_streams > 1 ? first_tile / tiles_per_stream : 0;
+		cur.t = first_tile - cur.stream * tiles_per_stream;
+	}
+	auto advance = [&](Cursor &c) {
+		if (++handed >= n_mine) {
+			c.stream = a.n_streams;
+			return;
+		}
+		c.t += tile_step;
+		while (c.t >= tiles_per_stream && c.stream < a.n_streams) {
+			c.t -= tiles_per_stream;
+			c.stream++;
+		}
+	};
+	auto tile_full = [&](uint32_t tt) { return tt < a.full_tiles; };
+	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
+		lo = hi = 0;
+		if (c.stream >= a.n_streams)
+			return;
+		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SLIDE_THREADS;   // uniform
+		if (tile_full(c.t)) {
+			lo = tp[tid];
+			hi = tp[tid + 1];
+		} else {
+			const uint64_t w = (uint64_t)c.t * SLIDE_THREADS + tid;
+			lo = w < a.n_words ? tp[tid] : 0;
+			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
+		}
+	};
+
+	Cursor tc[TILES];
+	uint64_t lo[TILES], hi[TILES];
+#pragma unroll
+	for (int u = 0; u < TILES; u++) {
+		tc[u] = cur;
+		load_pair(cur, lo[u], hi[u]);
+		advance(cur);
+	}
+
+	for (uint32_t it = 0; tc[0].stream < a.n_streams; it += TILES) {
+		Cursor nc[TILES];
+		uint64_t nlo[TILES], nhi[TILES];
+		if (SLIDE_PREFETCH) {
+#pragma unroll
+			for (int u = 0; u < TILES; u++) {       // software prefetch: the loads fly while these tiles are worked on
+				nc[u] = cur;
+				load_pair(cur, nlo[u], nhi[u]);
+				advance(cur);
+			}
+		}
+
+		__builtin_amdgcn_s_setprio(PRIO_FILTER);
+		uint32_t d[TILES][4], m[TILES][2], c[TILES][3];
+#pragma unroll
+		for (int u = 0; u < TILES; u++) {
+			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
+			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
+			if (tc[u].stream >= a.n_streams) {
+				validA = validB = 0;
+			} else if (!tile_full(tc[u].t)) {
+				const uint64_t first_off = ((uint64_t)tc[u].t * SLIDE_THREADS + tid) * 64;
+				const uint64_t valid = first_off >= a.search_bits ? 0ULL
+					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+				validA = (uint32_t)valid;
+				validB = (uint32_t)(valid >> 32);
+			}
+			uint32_t cls_unused;
+			barker32(d[u][1], d[u][2], validA, m[u][0], cls_unused);    // offsets 0..31: window bits 57.. in d1:d2
+			barker32(d[u][2], d[u][3], validB, m[u][1], cls_unused);    // offsets 32..63
+			c[u][0] = slide32(d[u][0], d[u][1], d[u][2]);
+			c[u][1] = slide32(d[u][1], d[u][2], d[u][3]);
+			// positions 64..95 = the first check dword of the next lane's word; lane 63's from the scalar unit
+			const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
+			const uint32_t last = slide32_low_uniform(s2, s3);
+			const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
+			c[u][2] = lane == 63 ? last : next;
+		}
+
+		struct Stage { uint32_t p[TILES][2], v[TILES][2], bw[TILES][2], live[TILES][2]; };
+		auto any_left = [&]() {
+			uint32_t any = 0;
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+				any |= m[u][0] | m[u][1];
+			return __ballot(any != 0) != 0;
+		};
+		auto pass = [&]() {
+			Stage g;
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {       // next survivor of every chain: index, set read in flight
+					g.p[u][h] = lowest_bit(m[u][h]);
+					g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
+					g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
+					g.live[u][h] = m[u][h] >> g.p[u][h];      // bit 0: this lane has a survivor (p = ~0 for m == 0)
+					m[u][h] &= m[u][h] - 1;
+				}
+			uint32_t anybit = 0, bit[TILES][2];
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
+					anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
+				}
+			if (__ballot(anybit & 1)) {              // some lane of the wave holds a candidate (a third of the passes)
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const bool cand = (bit[u][h] & g.live[u][h] & 1) != 0;
+						const uint64_t cm = __ballot(cand);
+						if (!cm)
+							continue;
+						// ring entries left for this chain; candidates ranked beyond them (a stream made of
+						// sync words: tests/test_gpu_scan.py adversarial cases) go through the exact rule in place
+						const uint32_t room = RING - (q_tail - q_head);
+						const uint32_t n = min((uint32_t)__popcll(cm), room);
+						if (cand) {
+							const uint32_t code = ((it + u) << 12) | (lane << 6) | (h << 5) | (g.p[u][h] & 31);
+							const uint32_t wlo = alignbit(d[u][h + 1], d[u][h], g.p[u][h]);
+							const uint32_t whi = alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]);
+							const u32x4 rec = {code, wlo, whi, 0u};
+							if (SLIDE_SINGLE && (cm & (cm - 1)) == 0 && room) {
+								// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
+								lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
+							} else {
+								const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
+										__builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0));
+								if (rank < room) {
+									lds_st4(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
+								} else {
+									uint32_t stream, lap, nerr;
+									const uint64_t word = code_word(code, stream);
+									if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
+										emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
+								}
+							}
+						}
+						q_tail += n;
+					}
+			}
+		};
+		__builtin_amdgcn_s_setprio(PRIO_LOOP);
+#pragma unroll 1
+		for (int k = 0; k < SLIDE_FIXED; k++)       // practically every trip needs these (TILES * 128 chains of ~4 survivors)
+			pass();
+		while (any_left())
+			pass();
+		__builtin_amdgcn_s_setprio(PRIO_CAND);
+		if (q_tail - q_head >= (RING == 64 ? 48u : 64u))
+			drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+#pragma unroll
+		for (int u = 0; u < TILES; u++) {
+			if (SLIDE_PREFETCH) {
+				tc[u] = nc[u];
+				lo[u] = nlo[u];
+				hi[u] = nhi[u];
+			} else {                                // no prefetch (8 registers less): the other waves of the SIMD cover the loads
+				tc[u] = cur;
+				load_pair(cur, lo[u], hi[u]);
+				advance(cur);
+			}
+		}
+	}
+	while (q_tail != q_head)
+		drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+	flush_hits();
 }
 
 
@@ -1071,24 +1332,27 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	a.t = c.scan;
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
-		a.tiles_per_stream = (search_words + SCAN_THREADS - 1) / SCAN_THREADS;
+		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
+		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one); everything else
+		// runs the sliding-check kernel
+		int run_variant = SCAN_SLIDE ? 1 : 0;
+		if (c.scan.bitmap2 && c.table_errors >= 4)
+			run_variant = c.table_errors == 4 ? 9 : 8;
+		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : SCAN_THREADS;      // one word per thread
+		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
-		{	// tile t is full iff (t + 1) * 1024 + 1 <= n_words and (t + 1) * 65536 <= search_bits
-			const uint64_t by_words = n_words ? (n_words - 1) / SCAN_THREADS : 0, by_bits = search_bits / (SCAN_THREADS * 64ull);
+		{	// tile t is full iff (t + 1) * tile_words + 1 <= n_words and (t + 1) * tile_words * 64 <= search_bits
+			const uint64_t by_words = n_words ? (n_words - 1) / tile_words : 0, by_bits = search_bits / (tile_words * 64ull);
 			const uint64_t full = by_words < by_bits ? by_words : by_bits;
 			a.full_tiles = full > 0xffffffffull ? 0xffffffffu : (uint32_t)full;
 		}
-		uint64_t grid = a.n_tiles < (uint64_t)c.num_cus ? a.n_tiles : (uint64_t)c.num_cus;
+		const uint64_t resident = (uint64_t)c.num_cus * (run_variant == 1 ? SLIDE_WGS : 1);
+		uint64_t grid = a.n_tiles < resident ? a.n_tiles : resident;
 		a.xcd_tiles = (grid % 8 == 0 && a.n_tiles >= grid) ? (uint32_t)((a.n_tiles + 7) / 8) : 0;
 		if ((a.n_tiles + grid - 1) / grid >= (1u << 20) || (a.n_tiles >> 32)) {
 			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
 			return BTBBX_E_ARG;
 		}
-		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
-		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one)
-		int run_variant = SCAN_SLIDE ? 1 : 0;
-		if (c.scan.bitmap2 && c.table_errors >= 4)
-			run_variant = c.table_errors == 4 ? 9 : 8;
 #define LAUNCH_VARIANT(V) do { \
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
 					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
@@ -1100,7 +1364,13 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		switch (run_variant) {
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
-		case 1: LAUNCH_VARIANT(1); break;
+		case 1: {
+			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS>),
+						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+			hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+			break;
+		}
 		default: LAUNCH_VARIANT(0); break;
 		}
 #ifdef SCAN_PROFILE
@@ -1263,26 +1533,24 @@ extern "C" void btbbx_sort_hits(btbbx_hit *hits, size_t n)
 static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits, uint32_t lap,
 			     int max_ac_errors, btbbx_hit *hits, uint64_t cap, uint64_t offset_base, hipStream_t q)
 {
+	// counter + records live in one grow-only block of the call's lease (context.cpp scope_hits): no allocation
+	// in steady state.  Layout: 16 bytes for the counter, then the records (16-byte aligned).
 	struct Dev {
 		btbbx_hit *hits = nullptr;
 		uint32_t *count = nullptr;
-		~Dev() { if (hits) (void)hipFree(hits); if (count) (void)hipFree(count); }
 	} d;
 	// first guess: room for what the caller can take, but no more than one hit per 256 offsets + slack
 	uint64_t guess = search_bits / 256 + 4096;
 	if (guess > cap)
 		guess = cap;
 	uint32_t dev_cap = guess > 0xffffffffULL ? 0xffffffffu : (uint32_t)guess;
-	if (hipMalloc(&d.count, sizeof(uint32_t)) != hipSuccess) {
-		set_error("btbbx_scan: counter allocation failed");
-		return BTBBX_E_NOMEM;
-	}
 	uint32_t count = 0;
 	for (int pass = 0; pass < 2; pass++) {
-		if (dev_cap && hipMalloc(&d.hits, (size_t)dev_cap * sizeof(btbbx_hit)) != hipSuccess) {
-			set_error("btbbx_scan: hit buffer allocation failed (%u records)", dev_cap);
+		char *block = (char *)scope_hits(16 + (size_t)dev_cap * sizeof(btbbx_hit));
+		if (!block)
 			return BTBBX_E_NOMEM;
-		}
+		d.count = (uint32_t *)block;
+		d.hits = (btbbx_hit *)(block + 16);
 		HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(uint32_t), q));
 		int rc = btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap,
 					   d.count, q);
@@ -1294,8 +1562,6 @@ static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t
 			break;
 		// more matches than records kept, and the kept ones are whichever lanes came first: repeat
 		// with room for all of them, then keep the smallest
-		if (d.hits) (void)hipFree(d.hits);
-		d.hits = nullptr;
 		dev_cap = count;
 	}
 	const uint32_t have = count < dev_cap ? count : dev_cap;

@@ -10,6 +10,22 @@ import numpy as np
 HALO_BITS = 63            # an access code starting at the last owned offset ends 63 symbols later
 
 
+def plan_py(total_search_bits, world):
+    """The same arithmetic as btbbx_shard_plan (csrc/scan.hip), in Python: for hosts that plan without a GPU runtime
+    (the C library needs libamdhip64 to load).  tests/test_sharding_gloo.py holds the two against each other."""
+    words_total = (total_search_bits + 63) // 64
+    per = (words_total + world - 1) // world
+    out = []
+    for r in range(world):
+        w0 = min(r * per, words_total)
+        w1 = min(w0 + per, words_total)
+        end = min(w1 * 64, total_search_bits)
+        bits = end - w0 * 64 if end > w0 * 64 else 0
+        out.append({"first_word": w0, "first_offset": w0 * 64, "search_bits": bits,
+                    "n_words": (bits + 63 + 63) // 64 if bits else 0})
+    return out
+
+
 def plan(total_search_bits, world):
     """Split offsets [0, total_search_bits) into `world` contiguous word-aligned slices.
 
@@ -19,9 +35,12 @@ def plan(total_search_bits, world):
 
     The plan itself is the C library's (btbbx_shard_plan, include/btbbx.h) -- the same one
     btbbx_scan_host_multi applies inside one process -- so the two multi-GPU forms cannot drift."""
-    from . import shard_plan
     assert world >= 1 and total_search_bits >= 0
-    return [shard_plan(total_search_bits, world, r) for r in range(world)]
+    from . import shard_plan
+    try:
+        return [shard_plan(total_search_bits, world, r) for r in range(world)]
+    except OSError:                                     # the library (libamdhip64) does not load here: same plan in Python
+        return plan_py(total_search_bits, world)
 
 
 def merge(per_rank_hits, plans):

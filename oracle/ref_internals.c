@@ -15,8 +15,12 @@
  *   uap_from_hec   :693                       air_to_host* :211-242
  *   tables         :49-59, 73-119; sw_check_tables.h
  */
+#define _GNU_SOURCE
 #include <string.h>
 #include <stddef.h>
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include REF_PACKET_C
 
 uint64_t refint_gen_syndrome(uint64_t cw) { return gen_syndrome(cw); }
@@ -118,6 +122,150 @@ size_t refint_find_all(char *stream, uint64_t search_length, uint32_t lap, int m
 	if (pkt)
 		btbb_packet_unref(pkt);
 	return n;
+}
+
+/* ---- the all-matches scan on many host threads, timed natively (bench.py cpu_baseline) ----------------
+ * n_threads workers over disjoint slices [bounds[i], bounds[i+1]) of one symbol-per-byte stream, each the
+ * caller loop above.  They start together behind a barrier; every worker takes CLOCK_MONOTONIC right before
+ * and right after its native loop -- nothing else is inside the timed region: no interpreter, no allocation
+ * (hit arrays are preallocated by the caller, cap_per_thread records per worker), no unpacking.  cpus[i] >= 0
+ * pins worker i to that logical CPU (one worker per physical core runs).  Returns 0, or -1 if a thread could
+ * not be created.  wall_seconds = last end - first start. */
+
+struct refint_mt_job {
+	char *stream;
+	uint64_t lo, hi;
+	uint32_t lap;
+	int max_ac_errors, cpu;
+	uint64_t *hit_offset;
+	uint32_t *hit_lap;
+	uint8_t *hit_err;
+	size_t cap, found;
+	double t0, t1;
+	pthread_barrier_t *start;
+};
+
+static double refint_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *refint_mt_worker(void *arg)
+{
+	struct refint_mt_job *j = (struct refint_mt_job *)arg;
+	size_t k, n;
+	if (j->cpu >= 0) {
+		cpu_set_t set;
+		CPU_ZERO(&set);
+		CPU_SET(j->cpu, &set);
+		pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+	}
+	pthread_barrier_wait(j->start);
+	j->t0 = refint_now();
+	n = refint_find_all(j->stream + j->lo, j->hi - j->lo, j->lap, j->max_ac_errors,
+			    j->hit_offset, j->hit_lap, j->hit_err, j->cap);
+	j->t1 = refint_now();
+	j->found = n;
+	for (k = 0; k < n && k < j->cap; k++)          /* slice-relative -> stream offsets (outside the timed region) */
+		j->hit_offset[k] += j->lo;
+	return NULL;
+}
+
+int refint_find_all_mt(char *stream, const uint64_t *bounds, int n_threads, uint32_t lap, int max_ac_errors,
+		       const int *cpus, uint64_t *hit_offset, uint32_t *hit_lap, uint8_t *hit_err,
+		       size_t cap_per_thread, uint64_t *found_per_thread, double *seconds_per_thread,
+		       double *wall_seconds)
+{
+	struct refint_mt_job *jobs;
+	pthread_t *tids;
+	pthread_barrier_t start;
+	int i, made = 0, rc = 0;
+	double first = 0, last = 0;
+	if (n_threads <= 0)
+		return -1;
+	jobs = (struct refint_mt_job *)calloc((size_t)n_threads, sizeof(*jobs));
+	tids = (pthread_t *)calloc((size_t)n_threads, sizeof(*tids));
+	if (!jobs || !tids)
+		return -1;
+	pthread_barrier_init(&start, NULL, (unsigned)n_threads);
+	for (i = 0; i < n_threads; i++) {
+		jobs[i].stream = stream;
+		jobs[i].lo = bounds[i];
+		jobs[i].hi = bounds[i + 1];
+		jobs[i].lap = lap;
+		jobs[i].max_ac_errors = max_ac_errors;
+		jobs[i].cpu = cpus ? cpus[i] : -1;
+		jobs[i].hit_offset = hit_offset + (size_t)i * cap_per_thread;
+		jobs[i].hit_lap = hit_lap + (size_t)i * cap_per_thread;
+		jobs[i].hit_err = hit_err + (size_t)i * cap_per_thread;
+		jobs[i].cap = cap_per_thread;
+		jobs[i].start = &start;
+		if (pthread_create(&tids[i], NULL, refint_mt_worker, &jobs[i]) != 0)
+			break;
+		made++;
+	}
+	if (made < n_threads) {
+		/* release the ones that wait: re-arming a barrier under waiters is not allowed, so give up loudly */
+		fprintf(stderr, "refint_find_all_mt: only %d of %d threads could be created\n", made, n_threads);
+		abort();
+	}
+	for (i = 0; i < n_threads; i++)
+		pthread_join(tids[i], NULL);
+	for (i = 0; i < n_threads; i++) {
+		found_per_thread[i] = jobs[i].found;
+		seconds_per_thread[i] = jobs[i].t1 - jobs[i].t0;
+		if (i == 0 || jobs[i].t0 < first) first = jobs[i].t0;
+		if (i == 0 || jobs[i].t1 > last) last = jobs[i].t1;
+	}
+	*wall_seconds = last - first;
+	pthread_barrier_destroy(&start);
+	free(jobs);
+	free(tids);
+	return rc;
+}
+
+/* packed LSB-first words -> one symbol per byte (the reference's input layout), on n_threads threads */
+struct refint_unpack_job { const uint64_t *words; uint8_t *out; uint64_t w0, w1; };
+static void *refint_unpack_worker(void *arg)
+{
+	struct refint_unpack_job *j = (struct refint_unpack_job *)arg;
+	uint64_t w;
+	int b;
+	for (w = j->w0; w < j->w1; w++) {
+		uint64_t v = j->words[w];
+		uint8_t *o = j->out + w * 64;
+		for (b = 0; b < 64; b++)
+			o[b] = (uint8_t)((v >> b) & 1);
+	}
+	return NULL;
+}
+int refint_unpack_mt(const uint64_t *words, uint64_t n_words, uint8_t *out, int n_threads)
+{
+	struct refint_unpack_job *jobs;
+	pthread_t *tids;
+	int i;
+	if (n_threads <= 0)
+		n_threads = 1;
+	jobs = (struct refint_unpack_job *)calloc((size_t)n_threads, sizeof(*jobs));
+	tids = (pthread_t *)calloc((size_t)n_threads, sizeof(*tids));
+	for (i = 0; i < n_threads; i++) {
+		jobs[i].words = words;
+		jobs[i].out = out;
+		jobs[i].w0 = n_words * (uint64_t)i / (uint64_t)n_threads;
+		jobs[i].w1 = n_words * (uint64_t)(i + 1) / (uint64_t)n_threads;
+		if (pthread_create(&tids[i], NULL, refint_unpack_worker, &jobs[i]) != 0) {
+			refint_unpack_worker(&jobs[i]);
+			tids[i] = 0;
+		}
+	}
+	for (i = 0; i < n_threads; i++)
+		if (tids[i])
+			pthread_join(tids[i], NULL);
+	free(jobs);
+	free(tids);
+	return 0;
 }
 
 /* packet object layout (bluetooth_packet.h:52-112) so tests can peek at fields */

@@ -185,6 +185,9 @@ def ref():
         "btbb_uap_from_header": (C.c_int, [vp, vp]),
         "btbb_process_packet": (C.c_int, [vp, vp]),
         "refint_find_all": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, C.c_size_t]),
+        "refint_find_all_mt": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_int, vp, vp, vp, vp, C.c_size_t, vp, vp,
+                                         C.POINTER(C.c_double)]),
+        "refint_unpack_mt": (C.c_int, [vp, C.c_uint64, vp, C.c_int]),
         "refint_known_lap_chain": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint8, C.c_uint32,
                                                 C.POINTER(C.c_uint64)]),
         "refint_clk6_trials": (C.c_uint64, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
@@ -265,6 +268,39 @@ def ref_find_all_native(stream_u8, search_length, lap, max_err, cap=1 << 22, bas
                             ptr(off), ptr(laps), ptr(errs), cap)
     assert n <= cap
     return [(int(off[i]), int(laps[i]), int(errs[i])) for i in range(n)]
+
+
+def ref_find_all_mt(stream_u8, search_length, lap, max_err, n_threads, cpus=None, cap_per_thread=None):
+    """The all-matches loop on n_threads host threads over disjoint slices of [0, search_length), started and timed
+    natively (oracle/ref_internals.c: refint_find_all_mt -- nothing of Python runs between the barrier and the last
+    clock read).  Returns (offsets, laps, errors) in stream order as numpy arrays, found per thread, seconds per
+    thread, wall seconds."""
+    lib = ref()
+    bounds = np.linspace(0, search_length, n_threads + 1).astype(np.uint64)
+    cap = int(cap_per_thread or (search_length // n_threads) // 1024 + 4096)
+    off = np.zeros(n_threads * cap, np.uint64)
+    laps = np.zeros(n_threads * cap, np.uint32)
+    errs = np.zeros(n_threads * cap, np.uint8)
+    found = np.zeros(n_threads, np.uint64)
+    secs = np.zeros(n_threads, np.float64)
+    wall = C.c_double(0)
+    cpu_arr = None if cpus is None else np.ascontiguousarray(np.asarray(cpus, np.int32))
+    rc = lib.refint_find_all_mt(ptr(stream_u8), ptr(bounds), n_threads, lap, max_err,
+                                None if cpu_arr is None else ptr(cpu_arr), ptr(off), ptr(laps), ptr(errs), cap,
+                                ptr(found), ptr(secs), C.byref(wall))
+    assert rc == 0
+    assert int(found.max()) <= cap, "hit buffer per thread too small"
+    keep = np.concatenate([np.arange(i * cap, i * cap + int(found[i])) for i in range(n_threads)]) if n_threads else []
+    return off[keep], laps[keep], errs[keep], found, secs, wall.value
+
+
+def ref_unpack_mt(words_u64, n_threads=16):
+    """Packed LSB-first words -> one symbol per byte, natively on n_threads threads."""
+    lib = ref()
+    words_u64 = np.ascontiguousarray(words_u64, dtype=np.uint64)
+    out = np.empty(len(words_u64) * 64, np.uint8)
+    lib.refint_unpack_mt(ptr(words_u64), len(words_u64), ptr(out), n_threads)
+    return out
 
 
 def ref_find_all(stream_u8, search_length, lap, max_err):

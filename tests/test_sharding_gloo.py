@@ -72,6 +72,7 @@ def test_plan_covers_every_offset_once():
     for total in (0, 1, 63, 64, 65, 1000, 64 * 1000 + 5, 1 << 35):
         for world in (1, 2, 3, 4, 8):
             plans = shard.plan(total, world)
+            assert plans == shard.plan_py(total, world)          # C plan (btbbx_shard_plan) == the Python arithmetic
             assert len(plans) == world
             pos = 0
             for p in plans:

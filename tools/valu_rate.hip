@@ -36,6 +36,12 @@ KERNEL(k_add, OP8("v_add_u32"))
 KERNEL(k_lshr, OP8("v_lshrrev_b32"))
 KERNEL(k_alignbit, OP8_3("v_alignbit_b32"))
 KERNEL(k_bfe, OP8_3("v_bfe_u32"))
+#define OP8_C(ins, lit) asm volatile(ins " %0, %0, %1, " lit "\n" ins " %1, %1, %2, " lit "\n" ins " %2, %2, %3, " lit "\n" ins " %3, %3, %4, " lit "\n" \
+	ins " %4, %4, %5, " lit "\n" ins " %5, %5, %6, " lit "\n" ins " %6, %6, %7, " lit "\n" ins " %7, %7, %0, " lit "\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+KERNEL(k_alignbit_const, OP8_C("v_alignbit_b32", "7"))
+KERNEL(k_ffbh, OP8_1("v_ffbh_u32"))
+KERNEL(k_mov, OP8_1("v_mov_b32"))
 KERNEL(k_lshl_add, OP8_3("v_lshl_add_u32"))
 KERNEL(k_and_or, OP8_3("v_and_or_b32"))
 KERNEL(k_ffbl, OP8_1("v_ffbl_b32"))
@@ -107,10 +113,11 @@ static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
 	hipEventCreate(&e1);
-	int threads = 256 * waves_per_simd;
-	hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, d_out, 1u);
+	// up to 4 waves per SIMD in one 1024-thread workgroup per CU; 8 = two such workgroups per CU
+	int threads = 256 * (waves_per_simd > 4 ? 4 : waves_per_simd), blocks = 256 * (waves_per_simd > 4 ? waves_per_simd / 4 : 1);
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, d_out, 1u);
 	hipEventRecord(e0);
-	hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, d_out, 2u);
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, d_out, 2u);
 	hipEventRecord(e1);
 	hipEventSynchronize(e1);
 	float ms = 0;
@@ -124,14 +131,17 @@ static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
 int main()
 {
 	uint32_t *d_out;
-	hipMalloc(&d_out, 256 * 1024 * 4);
-	for (int w = 4; w <= 4; w *= 2) {
+	hipMalloc(&d_out, 512 * 1024 * 4);
+	for (int w = 4; w <= 8; w *= 2) {
 		run("v_and_b32", k_and, d_out, w);
 		run("v_xor_b32", k_xor, d_out, w);
 		run("v_add_u32", k_add, d_out, w);
 		run("v_lshrrev_b32", k_lshr, d_out, w);
 		run("v_alignbit_b32", k_alignbit, d_out, w);
 		run("v_bfe_u32", k_bfe, d_out, w);
+		run("v_alignbit const", k_alignbit_const, d_out, w);
+		run("v_ffbh_u32", k_ffbh, d_out, w);
+		run("v_mov_b32", k_mov, d_out, w);
 		run("v_lshl_add_u32", k_lshl_add, d_out, w);
 		run("v_and_or_b32", k_and_or, d_out, w);
 		run("v_bitop3_b32", k_bitop3, d_out, w);
