@@ -172,6 +172,13 @@ void btbbx_sort_hits(btbbx_hit *hits, size_t n);
 /* the same order for a hit list still in device memory (the host wrappers and the streaming ingest
  * sort here before copying out); synchronises hip_stream */
 int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_stream);
+/* The same order with the list's length still in device memory (the counter btbbx_scan_device filled): orders the
+ * first min(*d_count, cap) records of d_hits in place -- no host round trip, no synchronisation, all work on
+ * hip_stream.  d_scratch: btbbx_order_hits_scratch_bytes(cap) bytes of device memory owned by the caller (16-byte
+ * aligned), so callers on different streams share nothing.  Offsets must stay below 2^47. */
+size_t btbbx_order_hits_scratch_bytes(uint32_t cap);
+int btbbx_order_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, void *d_scratch,
+			    size_t scratch_bytes, void *hip_stream);
 
 /* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
  * ceil(n_symbols / 64), the tail of the last word is zero */
@@ -243,6 +250,12 @@ int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in *d_in, uin
 int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			     const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, uint32_t n_packets,
 			     uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream);
+/* ... with the number of hits still in device memory: decodes the first min(*d_count, cap) hits (launched for cap);
+ * scan -> btbbx_order_hits_device -> this call is the known-LAP chain without a host round trip */
+int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+				     const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, const uint32_t *d_count,
+				     uint32_t cap, uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths,
+				     void *hip_stream);
 
 /* ---- hop selection and CLK1-27 reversal ------------------------- */
 #define BTBBX_SEQUENCE_LENGTH 134217728u   /* values of CLK1-27, bluetooth_piconet.h:102 */

@@ -104,6 +104,8 @@ SIGNATURES = {
     "btbbx_scan_host_multi": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64, _vp, C.c_int]),
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
     "btbbx_sort_hits_device": (C.c_int, [_vp, _u32, _vp]),
+    "btbbx_order_hits_scratch_bytes": (C.c_size_t, [_u32]),
+    "btbbx_order_hits_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _vp]),
     "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_unpack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_msb_to_lsb_device": (C.c_int, [_vp, _u64, _vp]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "btbbx_trials_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_hits_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "btbbx_decode_hits_counted_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_uap_table_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
     "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),

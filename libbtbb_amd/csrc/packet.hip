@@ -1464,10 +1464,13 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 // gather's: min(max_length, 3125, symbols left in the stream), and d_in[i].length is ignored.
 __global__ __launch_bounds__(256) void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
-							  uint32_t max_length, btbbx_pkt_out *outs, uint32_t *lengths, uint32_t mode)
+							  const uint32_t *d_count, uint32_t max_length, btbbx_pkt_out *outs,
+							  uint32_t *lengths, uint32_t mode)
 {
 	chain_lds_init();
 	const uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
+		n_packets = min(n_packets, *d_count);
 	if (pkt >= n_packets)
 		return;
 	const btbbx_hit h = hits[pkt];
@@ -1936,7 +1939,31 @@ extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_word
 		return BTBBX_E_ARG;
 	}
 	hipLaunchKernelGGL(decode_hits_kernel, dim3((n_packets + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
-			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, max_length, d_out, d_lengths,
+			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, (const uint32_t *)nullptr, max_length, d_out,
+			   d_lengths, DEC_HEADER | DEC_PAYLOAD);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+// The same with the number of hits still on the device (the counter btbbx_scan_device filled): decodes
+// min(*d_count, cap) packets, launches for `cap`.  With btbbx_order_hits_device in front of it the chain
+// scan -> order -> decode runs without a host round trip.
+extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+						const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, const uint32_t *d_count,
+						uint32_t cap, uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths,
+						void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!cap)
+		return BTBBX_OK;
+	if (!d_words || !d_hits || !d_in || !d_out || !d_count) {
+		set_error("btbbx_decode_hits_counted_device: null pointer");
+		return BTBBX_E_ARG;
+	}
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
+			   d_words, n_words, pitch_words, d_hits, d_in, cap, d_count, max_length, d_out, d_lengths,
 			   DEC_HEADER | DEC_PAYLOAD);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;

@@ -1,52 +1,409 @@
-// sort.hip -- (stream, offset) order for hit lists while they are still in HBM.
+// sort.hip -- (stream, offset) order for hit lists while they are still in HBM, without a host round trip.
 //
 // The scan kernels append hits unordered; callers of the reference get them in stream order
-// (lib/src/bluetooth_packet.c:444-464 is called on a sliding window).  Sorting 10^6 records on the
-// host costs ~60 ms and used to be most of the PCIe-inclusive time of the ingest paths; on the
-// device it is a few hundred microseconds.  The sort itself is rocPRIM's LSD radix sort (AMD's own
-// primitive library, the plain-library case like a rocBLAS GEMM); this file adds the key
-// extraction and the scratch management.
+// (lib/src/bluetooth_packet.c:444-464 is called on a sliding window, first match first).  Rounds 1-2 handed
+// the list to rocPRIM's general radix sort between two hipStreamSynchronize() calls.  A hit list is not a
+// general sorting problem: keys (stream, offset) are UNIQUE -- an offset matches at most once -- and sparse
+// (one hit per thousands of offsets), so the order follows from counting:
+//
+//   1. extent:   max offset / max stream of the list (the count itself is read from HBM: no `n` from the host)
+//   2. buckets:  lin = stream * (max_offset + 1) + offset, bucket = lin >> shift with as many buckets as the
+//                list can have records (<= 2^22): histogram, exclusive scan, scatter -- records grouped by bucket
+//   3. rank:     inside a bucket the rank of a record is the number of bucket-mates with a smaller key: for the
+//                usual handful of mates a loop over them; for a crowded bucket (a stream made of sync words) a
+//                presence bitmap of the bucket's 2^shift possible keys in LDS and a prefix popcount -- O(k), and
+//                exact because keys are unique (a list with repeated keys, which no scan produces, is still
+//                ordered correctly: ties go by position, a crowded bucket with a repeated key by all pairs).
+//
+// Eight small launches and a memset on the caller's stream, no synchronisation, no vendor library on the path.  The caller
+// owns the scratch memory (btbbx_order_hits_scratch_bytes) so that concurrent callers on different streams
+// share nothing; btbbx_sort_hits_device keeps its old signature on top of a per-device scratch block.
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include "common.h"
-#include <rocprim/rocprim.hpp>
 
 struct __attribute__((aligned(16))) HitRec { uint64_t a, b; };      // a btbbx_hit as an opaque 16-byte value
 
-// The key is (stream << offset_bits) | offset with just as many bits as the list needs: an LSD radix sort pays
-// one pass over keys and 16-byte values per digit, and a 4 GiB capture of 79 channels needs 39 key bits, not 64.
-// Pass 1 ORs all offsets and all stream numbers (one atomic per wave), pass 2 builds the keys.
-__global__ __launch_bounds__(256) void hit_extent_kernel(const btbbx_hit *hits, uint32_t n, unsigned long long *extent)
+struct OrderParams {
+	unsigned long long max_off, max_stream;    // extent of the list (atomicMax targets)
+	unsigned long long mul;                    // max_off + 1
+	uint32_t n;                                // records in the list = min(*d_count, cap)
+	uint32_t shift;                            // bucket = lin >> shift
+	uint32_t ticket;                           // last workgroup of the extent pass works the parameters out
+	uint32_t pad[3];
+};
+
+#define ORDER_SMALL 48u                        // bucket-mates up to here are ranked by a plain loop
+#define ORDER_SCAN_ITEMS 4                     // counters per thread of the scan kernels (1024 threads)
+#define ORDER_BIG_BITS 20                      // a crowded bucket's presence bitmap covers 2^20 keys at a time (128 KiB of LDS)
+#define ORDER_PAIRS 4096u                      // crowded buckets up to here: every record against every other
+
+__device__ __forceinline__ uint64_t order_lin(const btbbx_hit &h, unsigned long long mul)
 {
-	// grid-stride: a few hundred workgroups, one pair of atomics each (one pair per wave of a 10^6-hit list
-	// was 20 000 atomics on two addresses and took longer than the sort passes it saves)
-	__shared__ unsigned long long part[2][4];
+	return (uint64_t)h.stream * mul + h.offset;
+}
+__device__ __forceinline__ bool order_less(const btbbx_hit &x, const btbbx_hit &y)
+{
+	return x.stream != y.stream ? x.stream < y.stream : x.offset < y.offset;
+}
+
+// x (at position ix of the grouped list) goes in front of y (at iy): smaller key, or the same key and the earlier
+// position -- the scans never report an offset twice, but a caller may hand over any list
+__device__ __forceinline__ bool order_before(const btbbx_hit &x, uint32_t ix, const btbbx_hit &y, uint32_t iy)
+{
+	if (x.stream != y.stream)
+		return x.stream < y.stream;
+	if (x.offset != y.offset)
+		return x.offset < y.offset;
+	return ix < iy;
+}
+
+__global__ __launch_bounds__(256) void order_extent_kernel(const btbbx_hit *hits, const uint32_t *d_count, uint32_t n_imm,
+							  uint32_t cap, uint32_t nb_log2, OrderParams *p)
+{
+	const uint32_t n = d_count ? min(*d_count, cap) : n_imm;
 	unsigned long long off = 0, st = 0;
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-		off |= (unsigned long long)hits[i].offset;
-		st |= hits[i].stream;
+		off = max(off, (unsigned long long)hits[i].offset);
+		st = max(st, (unsigned long long)hits[i].stream);
 	}
 	for (int d = 32; d; d >>= 1) {
-		off |= __shfl_xor(off, d);
-		st |= __shfl_xor(st, d);
+		off = max(off, (unsigned long long)__shfl_xor(off, d));
+		st = max(st, (unsigned long long)__shfl_xor(st, d));
 	}
 	if ((threadIdx.x & 63) == 0) {
-		part[0][threadIdx.x >> 6] = off;
-		part[1][threadIdx.x >> 6] = st;
+		atomicMax(&p->max_off, off);
+		atomicMax(&p->max_stream, st);
 	}
 	__syncthreads();
-	if (threadIdx.x < 2)
-		atomicOr(&extent[threadIdx.x], part[threadIdx.x][0] | part[threadIdx.x][1] | part[threadIdx.x][2] | part[threadIdx.x][3]);
+	if (threadIdx.x == 0) {
+		__threadfence();
+		if (atomicAdd(&p->ticket, 1u) == gridDim.x - 1) {        // every workgroup's maxima are in: derive the bucket shift
+			__threadfence();
+			const unsigned long long mo = atomicMax(&p->max_off, 0ull), ms = atomicMax(&p->max_stream, 0ull);
+			const unsigned long long mul = mo + 1;
+			// total = (ms + 1) * mul keys at most; 2^T >= total
+			uint32_t T = 64;
+			if (__umul64hi(ms + 1, mul) == 0) {
+				const unsigned long long total = (ms + 1) * mul;
+				T = total > 1 ? 64 - __builtin_clzll(total - 1) : 0;
+			}
+			p->mul = mul;
+			p->n = n;
+			p->shift = T > nb_log2 ? T - nb_log2 : 0;
+		}
+	}
 }
 
-__global__ __launch_bounds__(256) void hit_keys_kernel(const btbbx_hit *hits, uint32_t n, uint64_t *keys, uint32_t offset_bits)
+__global__ __launch_bounds__(256) void order_hist_kernel(const btbbx_hit *hits, const OrderParams *p, uint32_t *cnt)
 {
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n)
-		keys[i] = ((uint64_t)hits[i].stream << offset_bits) | hits[i].offset;
+	const uint32_t n = p->n, shift = p->shift;
+	const unsigned long long mul = p->mul;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		atomicAdd(&cnt[order_lin(hits[i], mul) >> shift], 1u);
 }
 
-// one scratch block per device: keys in | keys out | values out | rocPRIM temporary
+// exclusive scan of cnt[0 .. nb) in place, three launches: per-block sums, scan of the sums, per-block scan + base.
+// cnt[nb] receives the total.
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *lds_wave, uint32_t &total)
+{
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(inc, d);
+		if (lane >= (uint32_t)d)
+			inc += t;
+	}
+	if (lane == 63)
+		lds_wave[wave] = inc;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for (uint32_t w = 0; w < 16; w++) {
+		const uint32_t s = lds_wave[w];
+		if (w < wave)
+			base += s;
+		tot += s;
+	}
+	__syncthreads();
+	total = tot;
+	return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums)
+{
+	__shared__ uint32_t lds_wave[16];
+	const uint32_t base = blockIdx.x * 1024 * ORDER_SCAN_ITEMS + threadIdx.x * ORDER_SCAN_ITEMS;
+	uint32_t v = 0;
+#pragma unroll
+	for (int k = 0; k < ORDER_SCAN_ITEMS; k++)
+		if (base + k < nb)
+			v += cnt[base + k];
+	uint32_t total;
+	(void)block_exclusive_scan_1024(v, lds_wave, total);
+	if (threadIdx.x == 0)
+		block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void order_scan_top_kernel(uint32_t *block_sums, uint32_t n_blocks)
+{
+	// n_blocks <= 1024 (2^22 counters / 4096 per block)
+	__shared__ uint32_t lds_wave[16];
+	const uint32_t v = threadIdx.x < n_blocks ? block_sums[threadIdx.x] : 0;
+	uint32_t total;
+	const uint32_t ex = block_exclusive_scan_1024(v, lds_wave, total);
+	if (threadIdx.x < n_blocks)
+		block_sums[threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, uint32_t nb, const uint32_t *block_sums)
+{
+	__shared__ uint32_t lds_wave[16];
+	const uint32_t base = blockIdx.x * 1024 * ORDER_SCAN_ITEMS + threadIdx.x * ORDER_SCAN_ITEMS;
+	uint32_t v[ORDER_SCAN_ITEMS], sum = 0;
+#pragma unroll
+	for (int k = 0; k < ORDER_SCAN_ITEMS; k++) {
+		v[k] = base + k < nb ? cnt[base + k] : 0;
+		sum += v[k];
+	}
+	uint32_t total;
+	uint32_t run = block_exclusive_scan_1024(sum, lds_wave, total) + block_sums[blockIdx.x];
+#pragma unroll
+	for (int k = 0; k < ORDER_SCAN_ITEMS; k++) {
+		if (base + k < nb)
+			cnt[base + k] = run;
+		run += v[k];
+	}
+	if (base < nb && base + ORDER_SCAN_ITEMS >= nb)      // the thread that holds the last counter writes the total behind it
+		cnt[nb] = run;
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, const OrderParams *p, const uint32_t *start,
+							    uint32_t *cursor, btbbx_hit *grouped)
+{
+	const uint32_t n = p->n, shift = p->shift;
+	const unsigned long long mul = p->mul;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const btbbx_hit h = hits[i];
+		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+		const uint32_t pos = start[b] + atomicAdd(&cursor[b], 1u);
+		reinterpret_cast<HitRec *>(grouped)[pos] = *reinterpret_cast<const HitRec *>(&h);
+	}
+}
+
+// records of buckets with up to ORDER_SMALL members: rank = bucket-mates with a smaller key (they sit in L1 / L2)
+__global__ __launch_bounds__(256) void order_rank_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
+							 btbbx_hit *out)
+{
+	const uint32_t n = p->n, shift = p->shift;
+	const unsigned long long mul = p->mul;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const btbbx_hit h = grouped[i];
+		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+		const uint32_t s = start[b], k = start[b + 1] - s;
+		if (k > ORDER_SMALL)
+			continue;                                   // order_crowded_kernel's
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < k; j++)
+			rank += order_before(grouped[s + j], s + j, h, i) ? 1u : 0u;
+		reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
+	}
+}
+
+// buckets with more members than that, one at a time per workgroup: up to ORDER_PAIRS members every record against
+// every other; beyond that a presence bitmap of the bucket's keys in LDS (2^20 keys per window), rank = set bits below
+// the record's own -- exact because keys are unique, and checked: a bucket whose bitmap holds fewer bits than it has
+// members (a repeated key) is redone by all pairs.
+__global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
+							     uint32_t nb, btbbx_hit *out)
+{
+	extern __shared__ uint32_t bits[];                  // 2^shift bits, then 1024 group prefixes
+	__shared__ uint32_t lds_wave[16];
+	__shared__ uint32_t found[1024], n_found;
+	__shared__ unsigned long long win_lo, win_hi;
+	const uint32_t shift = p->shift;
+	const unsigned long long mul = p->mul;
+	// 1024 buckets are looked at per step, one per thread (a workgroup stepping through the buckets one by one spent
+	// 5 ms on 2^22 of them waiting for its own loads); the crowded ones among them are then worked off one at a time
+	for (uint32_t first = blockIdx.x * 1024; first < nb; first += gridDim.x * 1024) {
+		if (threadIdx.x == 0)
+			n_found = 0;
+		__syncthreads();
+		const uint32_t mine_b = first + threadIdx.x;
+		if (mine_b < nb && start[mine_b + 1] - start[mine_b] > ORDER_SMALL)
+			found[atomicAdd(&n_found, 1u)] = mine_b;
+		__syncthreads();
+		const uint32_t todo = n_found;
+		for (uint32_t f = 0; f < todo; f++) {
+			const uint32_t b = found[f];
+			const uint32_t s = start[b], k = start[b + 1] - s;   // uniform over the workgroup
+			auto rank_all_pairs = [&]() {
+				for (uint32_t i = threadIdx.x; i < k; i += 1024) {
+					const btbbx_hit h = grouped[s + i];
+					uint32_t rank = 0;
+					for (uint32_t j = 0; j < k; j++)
+						rank += order_before(grouped[s + j], j, h, i) ? 1u : 0u;
+					reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
+				}
+			};
+			if (k <= ORDER_PAIRS) {                                  // at most 16 M comparisons: cheaper than clearing 128 KiB
+				rank_all_pairs();
+				continue;
+			}
+			// Presence bitmap over ORDER_BIG_BITS key bits at a time: the bucket's 2^shift keys are cut into windows of
+			// 2^20, only the windows between the smallest and the largest key present are visited, ranks carry over.
+			const uint32_t wbits = shift < ORDER_BIG_BITS ? shift : ORDER_BIG_BITS;
+			const uint32_t words = wbits >= 5 ? 1u << (wbits - 5) : 1u;  // bitmap words per window
+			const uint32_t per = (words + 1023) / 1024;                  // words per thread group
+			uint32_t *group_prefix = bits + words;
+			const uint64_t low_mask = shift ? ((1ull << shift) - 1) : 0, win_mask = (1ull << wbits) - 1;
+			if (threadIdx.x == 0) {
+				win_lo = ~0ull;
+				win_hi = 0;
+			}
+			__syncthreads();
+			{
+				unsigned long long lo = ~0ull, hi = 0;
+				for (uint32_t i = threadIdx.x; i < k; i += 1024) {
+					const unsigned long long wdw = (order_lin(grouped[s + i], mul) & low_mask) >> wbits;
+					lo = min(lo, wdw);
+					hi = max(hi, wdw);
+				}
+				if (lo <= hi) {
+					atomicMin(&win_lo, lo);
+					atomicMax(&win_hi, hi);
+				}
+			}
+			__syncthreads();
+			const unsigned long long w_first = win_lo, w_last = win_hi;
+			if (w_last - w_first > 65535) {                          // dense runs far apart inside one bucket: not worth the windows
+				rank_all_pairs();
+				__syncthreads();
+				continue;
+			}
+			uint32_t base_rank = 0;
+			for (unsigned long long wdw = w_first; wdw <= w_last; wdw++) {
+				for (uint32_t w = threadIdx.x; w < words; w += 1024)
+					bits[w] = 0;
+				__syncthreads();
+				for (uint32_t i = threadIdx.x; i < k; i += 1024) {
+					const uint64_t low = order_lin(grouped[s + i], mul) & low_mask;
+					const uint32_t lw = (uint32_t)(low & win_mask);
+					if ((low >> wbits) == wdw)
+						atomicOr(&bits[lw >> 5], 1u << (lw & 31));
+				}
+				__syncthreads();
+				uint32_t mine = 0;
+				for (uint32_t w = threadIdx.x * per; w < min(words, (threadIdx.x + 1) * per); w++)
+					mine += __popc(bits[w]);
+				uint32_t total;
+				group_prefix[threadIdx.x] = block_exclusive_scan_1024(mine, lds_wave, total);
+				__syncthreads();
+				if (total) {
+					for (uint32_t i = threadIdx.x; i < k; i += 1024) {
+						const btbbx_hit h = grouped[s + i];
+						const uint64_t low = order_lin(h, mul) & low_mask;
+						if ((low >> wbits) != wdw)
+							continue;
+						const uint32_t lw = (uint32_t)(low & win_mask);
+						const uint32_t w = lw >> 5, g = w / per;
+						uint32_t rank = base_rank + group_prefix[g] + __popc(bits[w] & ((1u << (lw & 31)) - 1));
+						for (uint32_t x = g * per; x < w; x++)
+							rank += __popc(bits[x]);
+						reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
+					}
+				}
+				base_rank += total;
+				__syncthreads();
+			}
+			if (base_rank != k) {                                    // a key occurs twice: the bitmap counted it once -- all pairs
+				rank_all_pairs();
+				__syncthreads();
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+static uint32_t order_nb_log2(uint32_t cap)
+{
+	// as many buckets as the list can have records, 2^8 .. 2^22
+	uint32_t l = 8;
+	while (l < 22 && (1u << l) < cap)
+		l++;
+	return l;
+}
+
+struct OrderLayout { size_t params, start, cursor, sums, grouped, total; uint32_t nb_log2; };
+static OrderLayout order_layout(uint32_t cap)
+{
+	OrderLayout L;
+	L.nb_log2 = order_nb_log2(cap);
+	const size_t nb = (size_t)1 << L.nb_log2;
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	L.params = 0;
+	L.start = up(sizeof(OrderParams));
+	L.cursor = L.start + up((nb + 1) * 4);
+	L.sums = L.cursor + up(nb * 4);
+	L.grouped = L.sums + up(1024 * 4);
+	L.total = L.grouped + up((size_t)cap * sizeof(btbbx_hit));
+	return L;
+}
+
+extern "C" size_t btbbx_order_hits_scratch_bytes(uint32_t cap)
+{
+	return order_layout(cap ? cap : 1).total;
+}
+
+static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_imm, uint32_t cap, void *d_scratch,
+			size_t scratch_bytes, hipStream_t stream)
+{
+	if (cap < 2)
+		return BTBBX_OK;
+	const OrderLayout L = order_layout(cap);
+	if (!d_scratch || scratch_bytes < L.total || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_hits & 15)) {
+		set_error("btbbx_order_hits_device: scratch of %zu bytes (16-byte aligned) needed, %zu given", L.total, scratch_bytes);
+		return BTBBX_E_ARG;
+	}
+	char *base = (char *)d_scratch;
+	OrderParams *p = (OrderParams *)(base + L.params);
+	uint32_t *start = (uint32_t *)(base + L.start), *cursor = (uint32_t *)(base + L.cursor), *sums = (uint32_t *)(base + L.sums);
+	btbbx_hit *grouped = (btbbx_hit *)(base + L.grouped);
+	const uint32_t nb = 1u << L.nb_log2;
+	// parameters, bucket counters and cursors are contiguous: one memset
+	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)cap + 255) / 256, 2048);
+	hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
+	hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
+	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
+	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	hipLaunchKernelGGL(order_scan_top_kernel, dim3(1), dim3(1024), 0, stream, sums, scan_blocks);
+	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped);
+	hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
+	const uint32_t crowded_lds = 4u * ((1u << (ORDER_BIG_BITS - 5)) + 1024u);
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(order_crowded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+				    crowded_lds));
+	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits);
+	HIP_TRY(hipGetLastError());
+	return BTBBX_OK;
+}
+
+// Device-resident count: sorts the first min(*d_count, cap) records of d_hits in place; nothing comes back to the
+// host and nothing is synchronised.  d_scratch: btbbx_order_hits_scratch_bytes(cap) bytes owned by the caller.
+extern "C" int btbbx_order_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, void *d_scratch,
+				       size_t scratch_bytes, void *hip_stream)
+{
+	if (!d_hits || !d_count) {
+		set_error("btbbx_order_hits_device: null pointer");
+		return BTBBX_E_ARG;
+	}
+	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, (hipStream_t)hip_stream);
+}
+
+// one scratch block per device for the signature without caller scratch
 struct SortScratch {
 	std::mutex lock;
 	void *block = nullptr;
@@ -77,53 +434,28 @@ extern "C" int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_s
 		return BTBBX_OK;
 	hipStream_t stream = (hipStream_t)hip_stream;
 	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BTBBX_MAX_DEVICES)
-		dev = 0;
-	SortScratch &sc = sort_scratch[dev];
-	void *&sort_block = sc.block;
-	size_t &sort_block_bytes = sc.bytes;
-	std::lock_guard<std::mutex> g(sc.lock);
-	size_t tmp_bytes = 0;
-	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (HitRec *)nullptr,
-					  (HitRec *)nullptr, (size_t)n, 0u, 64u, stream));
-	const size_t key_bytes = ((size_t)n * 8 + 255) & ~(size_t)255, val_bytes = ((size_t)n * 16 + 255) & ~(size_t)255;
-	const size_t need = 2 * key_bytes + val_bytes + tmp_bytes + 512;
-	if (need > sort_block_bytes) {
-		if (sort_block)
-			(void)hipFree(sort_block);
-		sort_block = nullptr;
-		sort_block_bytes = 0;
-		const size_t want = need + need / 2;
-		hipError_t e = hipMalloc(&sort_block, want);
-		if (e != hipSuccess)
-			return hip_fail(e, "hipMalloc(sort scratch)");
-		sort_block_bytes = want;
-	}
-	char *p = (char *)sort_block;
-	uint64_t *k_in = (uint64_t *)p, *k_out = (uint64_t *)(p + key_bytes);
-	HitRec *v_out = (HitRec *)(p + 2 * key_bytes);
-	void *tmp = p + 2 * key_bytes + val_bytes;
-	unsigned long long *d_extent = (unsigned long long *)(p + 2 * key_bytes + val_bytes + ((tmp_bytes + 255) & ~(size_t)255));
-	unsigned long long extent[2] = {0, 0};
-	HIP_TRY(hipMemsetAsync(d_extent, 0, sizeof(extent), stream));
-	hipLaunchKernelGGL(hit_extent_kernel, dim3((n + 255) / 256 < 512 ? (n + 255) / 256 : 512), dim3(256), 0, stream, d_hits, n, d_extent);
-	HIP_TRY(hipMemcpyAsync(extent, d_extent, sizeof(extent), hipMemcpyDeviceToHost, stream));
-	HIP_TRY(hipStreamSynchronize(stream));
-	uint32_t offset_bits = 1, stream_bits = 0;
-	while (offset_bits < 64 && (extent[0] >> offset_bits))
-		offset_bits++;
-	while (stream_bits < 16 && (extent[1] >> stream_bits))
-		stream_bits++;
-	if (offset_bits + stream_bits > 64) {       // cannot happen with 16-bit stream numbers and offsets below 2^48
-		set_error("btbbx_sort_hits_device: offsets too large for the sort key");
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BTBBX_MAX_DEVICES) {
+		set_error("btbbx_sort_hits_device: HIP device ordinal outside the %d contexts this library keeps", BTBBX_MAX_DEVICES);
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(hit_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_hits, n, k_in, offset_bits);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, (HitRec *)d_hits, v_out, (size_t)n, 0u,
-					  offset_bits + stream_bits, stream));
-	HIP_TRY(hipMemcpyAsync(d_hits, v_out, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToDevice, stream));
-	// the scratch is shared: finish before another caller may reuse it
+	SortScratch &sc = sort_scratch[dev];
+	std::lock_guard<std::mutex> g(sc.lock);
+	const size_t need = order_layout(n).total;
+	if (need > sc.bytes) {
+		if (sc.block)
+			(void)hipFree(sc.block);
+		sc.block = nullptr;
+		sc.bytes = 0;
+		const size_t want = need + need / 2;
+		hipError_t e = hipMalloc(&sc.block, want);
+		if (e != hipSuccess)
+			return hip_fail(e, "hipMalloc(sort scratch)");
+		sc.bytes = want;
+	}
+	int rc = order_launch(d_hits, nullptr, n, n, sc.block, sc.bytes, stream);
+	if (rc)
+		return rc;
+	// the scratch is shared between the callers of this signature: finish before another one may reuse it
 	HIP_TRY(hipStreamSynchronize(stream));
 	return BTBBX_OK;
 }

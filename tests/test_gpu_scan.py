@@ -367,6 +367,64 @@ def test_device_hit_sort():
         assert np.array_equal(np.sort(got, order=full), np.sort(h, order=full))      # a permutation of the input
 
 
+def test_device_hit_order_with_the_count_in_hbm():
+    """btbbx_order_hits_device: the list's length is read from device memory (the scan's own counter), the scratch
+    is the caller's, nothing is synchronised in between.  Cases: sparse multi-stream lists, a crowded bucket (runs of
+    consecutive offsets: the presence-bitmap path), a short list over a huge key space with more than 48 records in
+    one bucket (the all-pairs path), repeated keys, a count above / below the capacity, empty and one-record lists."""
+    lib = bt.lib()
+    rng = np.random.default_rng(_libs.seed(11))
+
+    def run(h, cap, count=None):
+        n = len(h)
+        count = n if count is None else count
+        room = np.zeros(max(cap, 1), bt.HIT_DTYPE)
+        room[:min(n, cap)] = h[:cap]
+        d = bt.DeviceBuffer(room.nbytes).upload(room)
+        c = bt.DeviceBuffer(16).upload(np.array([count, 0, 0, 0], np.uint32))
+        sb = lib.btbbx_order_hits_scratch_bytes(cap)
+        scratch = bt.DeviceBuffer(sb)
+        bt.check(lib.btbbx_order_hits_device(d.ptr, c.ptr, cap, scratch.ptr, sb, None), "btbbx_order_hits_device")
+        bt.check(lib.btbbx_sync(None))
+        got = d.download(bt.HIT_DTYPE, max(cap, 1))
+        for b in (d, c, scratch):
+            b.free()
+        m = min(count, cap)
+        want = np.sort(room[:m], order=["stream", "offset"], kind="stable")
+        key = lambda a: (a["stream"].astype(np.uint64) << np.uint64(48)) | a["offset"]
+        assert np.array_equal(key(got[:m]), key(want)), (n, cap, count)
+        full = ["stream", "offset", "lap", "ac_errors"]
+        assert np.array_equal(np.sort(got[:m], order=full), np.sort(room[:m], order=full))
+        assert np.array_equal(got[m:], room[m:])                       # records behind the count are left alone
+
+    def hits(offsets, streams):
+        h = np.zeros(len(offsets), bt.HIT_DTYPE)
+        h["offset"], h["stream"] = offsets, streams
+        h["lap"] = rng.integers(0, 1 << 24, len(h))
+        h["ac_errors"] = rng.integers(0, 3, len(h))
+        return h[rng.permutation(len(h))]
+
+    # sparse: 79 streams, one hit per ~4096 offsets of 2^26
+    off = np.concatenate([np.sort(rng.choice(1 << 26, 16000, replace=False)) for _ in range(79)]).astype(np.uint64)
+    st = np.repeat(np.arange(79), 16000)
+    run(hits(off, st), cap=79 * 16000 + 5000)
+    run(hits(off, st), cap=79 * 16000 + 5000, count=1000)              # a short list in a big buffer
+    run(hits(off, st)[:3000], cap=2000, count=3000)                    # the counter ran past the capacity
+    # crowded: 300 000 consecutive offsets (a stream made of sync words) next to sparse ones
+    off = np.concatenate([np.arange(5_000_000, 5_300_000), rng.choice(1 << 33, 50000, replace=False)]).astype(np.uint64)
+    run(hits(np.unique(off), 0), cap=400000)
+    # few buckets, huge key space, 200 records inside one bucket: all pairs
+    off = np.concatenate([(1 << 40) + np.arange(0, 200 * 977, 977), rng.choice(1 << 41, 100, replace=False)]).astype(np.uint64)
+    run(hits(np.unique(off), 0), cap=400)
+    # repeated keys (no scan produces them)
+    off = rng.integers(0, 50, 5000).astype(np.uint64)
+    run(hits(off, rng.integers(0, 3, 5000)), cap=5000)
+    off = np.concatenate([np.repeat(np.arange(100000, 100100), 3), np.arange(100100, 160000), [1 << 33]]).astype(np.uint64)
+    run(hits(off, 0), cap=70000)                                      # a crowded bucket (bitmap path) with repeats
+    for n in (0, 1, 2):
+        run(hits(np.arange(n, dtype=np.uint64) * 77, 0), cap=max(n, 4))
+
+
 @pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33])
 def test_sharded_product_scan_equals_single_scan(lap):
     """btbbx_scan_host_multi (the C-ABI form of the N-GPU path): the library's own shard plan --
