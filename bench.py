@@ -43,6 +43,19 @@ SEED = 20260926
 STRIDE = 4096
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel / library sources the loaded .so is built from (libbtbb_amd/csrc: *.hip,
+    *.cpp, *.h, Makefile, in name order).  profiles/traffic*.json carry the fingerprint of the build their PMC passes
+    measured; a line whose build differs prints traffic: null instead of a number that belongs to another kernel."""
+    import hashlib
+    d = os.path.join(ROOT, "libbtbb_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
+            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def host_cpu():
     """What the CPU baseline runs on: model string, logical threads, physical cores."""
     model, cores = "unknown", set()
@@ -223,6 +236,9 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
         e = tsec.get(name)
         if not e:
             return None, None
+        if tsec.get("csrc_sha16") != csrc_fingerprint():
+            return None, "null: profiles/traffic_secondary.json was measured on sources %s, this build is %s" % (
+                tsec.get("csrc_sha16"), csrc_fingerprint())
         return int(e["bytes_per_step"]), "profiles/traffic_secondary.json (%s); not re-measured in this run" % tsec.get("source", "rocprofv3 --pmc")
     ref = _libs.ref() if with_cpu else None
     if ref is not None:
@@ -411,20 +427,133 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
     return out
 
 
+def channels79(args, bt, lib, shard, dev, rank, world, red_dev):
+    """BASELINE configs[3] as written: promiscuous LAP_ANY over 79 channel streams, --gib GiB in total, every channel
+    time-sharded over the `world` ranks by the library's own plan (btbbx_shard_plan: slice + 63-symbol halo, no
+    collective).  The logical capture is ONE synthetic stream cut into 79 equal channels (channel c = global words
+    [c W, (c + 1) W)), so any slice can be regenerated and the injected sync words are known: every rank checks its
+    hit count against that ground truth.  One step = one launch over the rank's 79 x (W / world) words."""
+    NCH = 79
+    W = int(args.gib * (1 << 30)) // 8 // NCH                     # words per channel
+    ch_bits = W * 64 - 63                                         # offsets searched per channel
+    plan = shard.plan(ch_bits, world)[rank]
+    nw, nbits, fw = plan["n_words"], plan["search_bits"], plan["first_word"]
+    assert nw > 0, "more ranks than words per channel"
+    stream = torch.empty(NCH * nw, dtype=torch.int64, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    hs = C.c_void_p(cur.cuda_stream)
+    for c in range(NCH):                                          # row c = this rank's slice of channel c
+        bt.check(lib.btbbx_synth_device(stream.data_ptr() + 8 * c * nw, c * W + fw, nw, SEED, STRIDE, -1, 4, hs))
+    cap = NCH * (nbits // STRIDE + 64) + (1 << 16)
+    hits_t = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    cnt_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        cnt_t.zero_()
+        bt.check(lib.btbbx_scan_device(stream.data_ptr(), nw, nw, NCH, nbits, bt.LAP_ANY, 2, hits_t.data_ptr(), cap,
+                                       cnt_t.data_ptr(), hs))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        cnt_t.zero_()
+        ev[k][0].record(cur)
+        bt.check(lib.btbbx_scan_device(stream.data_ptr(), nw, nw, NCH, nbits, bt.LAP_ANY, 2, hits_t.data_ptr(), cap,
+                                       cnt_t.data_ptr(), hs))
+        ev[k][1].record(cur)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    nhits = int(cnt_t.item())
+    assert nhits <= cap, "hit buffer overflow"
+    if args.dump_hits:
+        mine_h = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:nhits].copy()
+        mine_h["offset"] += np.uint64(plan["first_offset"])         # offset inside the channel (stream = channel number)
+        np.save("%s.rank%d.npy" % (args.dump_hits, rank), mine_h)
+
+    # ground truth: injected sync words with <= 2 bit errors whose window starts inside this rank's range of a channel
+    from libbtbb_amd import synth
+    true_hits = 0
+    for c in range(NCH):
+        lo = (c * W + fw) * 64
+        k0, k1 = max(lo // STRIDE - 1, 0), (lo + nbits) // STRIDE + 1
+        pos, _, nerr, mask = synth.injection_params(SEED, np.arange(k0, k1, dtype=np.uint64), STRIDE, 4)
+        popc = np.unpackbits(mask.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)
+        true_hits += int(((popc <= 2) & (pos >= np.uint64(lo)) & (pos < np.uint64(lo + nbits))).sum())
+    chance = 1.25e-8 * NCH * nbits
+    hits_ok = 0 <= nhits - true_hits < 3 * chance + 100
+    t_el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev)
+    sums = torch.tensor([float(NCH * nbits), float(nhits), float(true_hits), 1.0 if hits_ok else 0.0], dtype=torch.float64, device=red_dev)
+    per_rank = [torch.zeros(4, dtype=torch.float64, device=red_dev) for _ in range(world)]
+    mine = torch.tensor([float(rank), kern_ms, float(nhits), float(true_hits)], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    if rank == 0:
+        elapsed, kern_max = float(t_el[0]), float(t_el[1])
+        total_bits = float(sums[0])
+        alg_bytes = NCH * nbits / 8 + 16 * nhits                  # this rank's launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Gbit/s raw bitstream scanned (LAP_ANY, err<=2)", "value": round(total_bits * args.steps / elapsed / 1e9, 2),
+            "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: promiscuous LAP_ANY over 79 channel streams, %.4g GiB packed in total, "
+                                   "max_ac_errors=2, sync word every %d symbols, every channel time-sharded over %d rank(s)"
+                                   % (args.gib, STRIDE, world),
+                       "symbols_total": int(total_bits), "symbols_per_gpu": NCH * nbits, "hits_total": int(sums[1]),
+                       "injected_hits_total": int(sums[2]), "hit_counts_match_ground_truth": bool(int(sums[3]) == world),
+                       "per_rank": [{"rank": int(v[0]), "kernel_ms": round(float(v[1]), 4), "hits": int(v[2]),
+                                     "injected_hits": int(v[3])} for v in per_rank],
+                       "parallelism": "79 channels x time shards x%d (btbbx_shard_plan per channel), no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "scan_slide_kernel",
+                         "kernel_ms": round(kern_ms, 4), "kernel_ms_max_over_ranks": round(kern_max, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "cpu_baseline": None,
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gib", type=float, default=4.0, help="packed stream size per GPU in GiB")
+    ap.add_argument("--gib", type=float, default=None, help="packed stream size in GiB: per GPU for --layout single (default 4), "
+                    "in total for --layout channels79 (default 64)")
     ap.add_argument("--cpu-symbols", type=int, default=0, help="size of the CPU-baseline sample (0 = 2^33 symbols when the host has >= 64 CPUs and the RAM for it, else 2^30)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 block")
+    ap.add_argument("--layout", default="single", choices=["single", "channels79"],
+                    help="single: one stream of --gib GiB per GPU (weak scaling, BASELINE configs[1], the default line); "
+                         "channels79: BASELINE configs[3] as written -- 79 channel streams, --gib GiB IN TOTAL (default 64), every "
+                         "channel time-sharded over the ranks (strong scaling)")
+    ap.add_argument("--dump-hits", default=None, metavar="PREFIX", help="testing: every rank writes its hit list with GLOBAL "
+                    "offsets to PREFIX.rank<r>.npy (tests/test_two_ranks.py merges them and compares with one scan)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "exercising the N>1 path where ranks share one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gib is None:
+        args.gib = 4.0 if args.layout == "single" else 64.0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -446,6 +575,9 @@ def main():
     from libbtbb_amd import shard
     bt.init(2)
     lib = bt.lib()
+
+    if args.layout == "channels79":
+        return channels79(args, bt, lib, shard, dev, rank, world, red_dev)
 
     # the logical capture is `world` x --gib; this rank's shard of it (slice + 63-symbol halo)
     words_per_gpu = int(args.gib * (1 << 30)) // 8
@@ -491,6 +623,10 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     nhits = int(cnt_t.item())
     assert nhits <= cap, "hit buffer overflow"
+    if args.dump_hits:
+        mine_h = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:nhits].copy()
+        mine_h["offset"] += np.uint64(plan["first_offset"])
+        np.save("%s.rank%d.npy" % (args.dump_hits, rank), mine_h)
     t_el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -504,11 +640,15 @@ def main():
         # HBM traffic per launch: NOT measured in this run -- the value of the last rocprofv3 --pmc passes over
         # this same command (separate passes, FETCH_SIZE doubled as the guide prescribes), see the file named
         traffic, traffic_source = None, None
+        fp = csrc_fingerprint()
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if abs(args.gib - 4.0) < 1e-9:
+            if abs(args.gib - 4.0) < 1e-9 and tj.get("csrc_sha16") == fp:
                 traffic = int(tj["bytes_per_launch"])
-                traffic_source = "profiles/traffic.json (%s); not re-measured in this run" % tj.get("source", "rocprofv3 --pmc")
+                traffic_source = "profiles/traffic.json (%s), same sources as this build (csrc_sha16 %s); not re-measured in this run" % (
+                    tj.get("source", "rocprofv3 --pmc"), fp)
+            else:
+                traffic_source = "null: profiles/traffic.json was measured on sources %s, this build is %s" % (tj.get("csrc_sha16"), fp)
         except Exception:
             traffic = None
         result = {
@@ -526,6 +666,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_slide_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "csrc_sha16": fp,
         }
         cpu = host_cpu()
         if world == 1 and not args.no_cpu:

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json and profiles/traffic_secondary.json from the PMC passes of tools/collect_evidence.sh:
+    python tools/make_traffic.py profiles/r03_v1
+HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (the gfx950 correction of MI355X_MICROARCH.md's HBM
+section, calibrated on this kernel's load shape in profiles/r01_calib).  Both files carry csrc_sha16 = the fingerprint
+of the sources that were measured (bench.csrc_fingerprint, written by collect_evidence.sh into <dir>/csrc_sha16.txt);
+bench.py prints traffic: null when the build it runs differs."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = sys.argv[1]
+rel = os.path.relpath(d, ROOT)
+fp = open(os.path.join(d, "csrc_sha16.txt")).read().strip()
+bench = json.load(open(os.path.join(d, "bench.json")))
+
+
+def hbm(entry):
+    return (2 * entry["FETCH_SIZE"]["mean_per_launch"] + entry["WRITE_SIZE"]["mean_per_launch"]) * 1024
+
+
+pmc = json.load(open(os.path.join(d, "pmc_scan.json")))
+name = [k for k in pmc if "scan_slide_kernel" in k][0]
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+b = hbm(pmc[name])
+json.dump({
+    "bytes_per_launch": int(b), "csrc_sha16": fp,
+    "source": "%s/pmc_scan.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 4 "
+              "--warmup 1 --no-cpu` (tools/collect_evidence.sh)" % rel,
+    "derivation": "(2 x FETCH_SIZE + WRITE_SIZE) KB x 1024; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for "
+                  "gfx950 and as calibrated on this kernel's own load shape (profiles/r01_calib: 0.5105 of the true bytes)",
+    "FETCH_SIZE_KB": pmc[name]["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc[name]["WRITE_SIZE"]["mean_per_launch"],
+    "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": round(b / alg, 3), "kernel": name + ", 4 GiB LAP_ANY bench workload",
+}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / alg))
+
+sec_path = os.path.join(d, "pmc_secondary.json")
+if os.path.exists(sec_path):
+    sec = json.load(open(sec_path))
+    out = {"csrc_sha16": fp, "source": "%s/pmc_secondary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+           "`python bench.py --steps 2 --warmup 1 --no-cpu`; (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
+    chain = [k for k in sec if k.startswith(("void scan_known_lap_kernel", "scan_known_lap_kernel", "order_", "decode_hits_kernel"))
+             or "order_" in k or "decode_hits_kernel" in k or "scan_known_lap_kernel" in k]
+    tot = sum(hbm(sec[k]) for k in chain if "FETCH_SIZE" in sec[k] and "WRITE_SIZE" in sec[k])
+    alg3 = bench["secondary"]["known_lap_79ch_chain"]["roofline"]["algorithmic_bytes_per_step"]
+    out["known_lap_79ch_chain"] = {"bytes_per_step": int(tot), "kernels": " + ".join(sorted(chain)) + " (the torch element-wise kernel that "
+                                   "fills btbbx_pkt_in is not counted)", "algorithmic_bytes_per_step": alg3,
+                                   "ratio_to_algorithmic": round(tot / alg3, 3)}
+    tl = [k for k in sec if "trials_linear_kernel" in k]
+    if tl:
+        t5 = hbm(sec[tl[0]])
+        alg5 = bench["secondary"]["clk6_bruteforce"]["roofline"]["algorithmic_bytes_per_step"]
+        out["clk6_bruteforce"] = {"bytes_per_step": int(t5), "kernels": "trials_linear_kernel", "algorithmic_bytes_per_step": alg5,
+                                  "ratio_to_algorithmic": round(t5 / alg5, 3)}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_secondary.json"), "w"), indent=1)
+    print("traffic_secondary.json:", {k: v["ratio_to_algorithmic"] for k, v in out.items() if isinstance(v, dict)})
