@@ -179,6 +179,10 @@ int btbbx_sort_hits_device(btbbx_hit *d_hits, uint32_t n, void *hip_stream);
 size_t btbbx_order_hits_scratch_bytes(uint32_t cap);
 int btbbx_order_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, void *d_scratch,
 			    size_t scratch_bytes, void *hip_stream);
+/* ... for the hit list of a btbbx_scan_device call over n_streams streams and search_bits offsets: the same without the
+ * pass that looks for the list's largest stream number and offset */
+int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, uint32_t n_streams,
+				 uint64_t search_bits, void *d_scratch, size_t scratch_bytes, void *hip_stream);
 
 /* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
  * ceil(n_symbols / 64), the tail of the last word is zero */

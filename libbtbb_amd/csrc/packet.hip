@@ -816,6 +816,13 @@ __device__ __forceinline__ int do_header_present(const PState &s)
 #define TL_WGS_PER_CU 1
 #endif
 #define TL_TRIALS  (TL_PACKETS * 64)
+// wave priority by phase (only meaningful with more than one workgroup per CU: the phases of ONE workgroup are
+// separated by barriers, its waves are always in the same phase)
+#ifdef TL_PRIO
+#define TL_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define TL_SETPRIO(x) do { } while (0)
+#endif
 #define TL_A_BLOCKS 183                     // DM5: 228 bytes = 1824 bits
 #define TL_A_BYTES  232                     // >= 229, multiple of 4
 #define TL_B_BLOCKS 10                      // DV: 12 bytes
@@ -925,6 +932,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 
 	__syncthreads();                                        // this batch is in LDS, the previous batch's results are read
 	TL_PROF(0);
+	TL_SETPRIO(1);
 
 	// 1. try_clock (:1178-1195).  uap_from_hec (:693-705) and the type field are GF(2)-linear in the 18 header
 	// bits and unwhitening XORs a clock-dependent constant onto them, so try_clock(c) = U(header) ^ U(whitening
@@ -1105,6 +1113,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		order[type_base[(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
 	__syncthreads();
 	TL_PROF(4);
+	TL_SETPRIO(3);
 
 	// 3. crc_check (:708-769) in type order
 	for (uint32_t kk = tid; kk < total; kk += TL_THREADS) {
@@ -1254,6 +1263,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(5);
+	TL_SETPRIO(0);
 	// The next batch moves in and the one after that is requested BEFORE this batch's results are stored: gfx9
 	// counts loads and stores in one in-order counter, so a wait for prefetched words that comes after the
 	// stores also waits for the stores (47 % of the kernel when it was written the other way round).

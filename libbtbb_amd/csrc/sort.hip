@@ -15,7 +15,7 @@
 //                exact because keys are unique (a list with repeated keys, which no scan produces, is still
 //                ordered correctly: ties go by position, a crowded bucket with a repeated key by all pairs).
 //
-// Eight small launches and a memset on the caller's stream, no synchronisation, no vendor library on the path.  The caller
+// Seven small launches and a memset on the caller's stream, no synchronisation, no vendor library on the path.  The caller
 // owns the scratch memory (btbbx_order_hits_scratch_bytes) so that concurrent callers on different streams
 // share nothing; btbbx_sort_hits_device keeps its old signature on top of a per-device scratch block.
 #include <string.h>
@@ -96,6 +96,22 @@ __global__ __launch_bounds__(256) void order_extent_kernel(const btbbx_hit *hits
 	}
 }
 
+// the caller knows the bounds of the list (stream count and search length of the scan that produced it): one thread
+// writes the parameters the extent pass would have derived
+__global__ void order_bounds_kernel(const uint32_t *d_count, uint32_t n_imm, uint32_t cap, uint32_t nb_log2, uint32_t n_streams,
+				    unsigned long long max_offset, OrderParams *p)
+{
+	const unsigned long long mul = max_offset + 1, ms = n_streams ? n_streams - 1 : 0;
+	uint32_t T = 64;
+	if (__umul64hi(ms + 1, mul) == 0) {
+		const unsigned long long total = (ms + 1) * mul;
+		T = total > 1 ? 64 - __builtin_clzll(total - 1) : 0;
+	}
+	p->mul = mul;
+	p->n = d_count ? min(*d_count, cap) : n_imm;
+	p->shift = T > nb_log2 ? T - nb_log2 : 0;
+}
+
 __global__ __launch_bounds__(256) void order_hist_kernel(const btbbx_hit *hits, const OrderParams *p, uint32_t *cnt)
 {
 	const uint32_t n = p->n, shift = p->shift;
@@ -145,20 +161,20 @@ __global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *c
 		block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void order_scan_top_kernel(uint32_t *block_sums, uint32_t n_blocks)
-{
-	// n_blocks <= 1024 (2^22 counters / 4096 per block)
-	__shared__ uint32_t lds_wave[16];
-	const uint32_t v = threadIdx.x < n_blocks ? block_sums[threadIdx.x] : 0;
-	uint32_t total;
-	const uint32_t ex = block_exclusive_scan_1024(v, lds_wave, total);
-	if (threadIdx.x < n_blocks)
-		block_sums[threadIdx.x] = ex;
-}
-
+// every workgroup adds up the sums of the workgroups before it itself (at most 1024 numbers from L2: cheaper than a
+// launch for a one-workgroup scan in between)
 __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, uint32_t nb, const uint32_t *block_sums)
 {
 	__shared__ uint32_t lds_wave[16];
+	__shared__ uint32_t my_base;
+	{
+		const uint32_t v = threadIdx.x < blockIdx.x ? block_sums[threadIdx.x] : 0;      // gridDim.x <= 1024
+		uint32_t before;
+		(void)block_exclusive_scan_1024(v, lds_wave, before);
+		if (threadIdx.x == 0)
+			my_base = before;
+		__syncthreads();
+	}
 	const uint32_t base = blockIdx.x * 1024 * ORDER_SCAN_ITEMS + threadIdx.x * ORDER_SCAN_ITEMS;
 	uint32_t v[ORDER_SCAN_ITEMS], sum = 0;
 #pragma unroll
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, u
 		sum += v[k];
 	}
 	uint32_t total;
-	uint32_t run = block_exclusive_scan_1024(sum, lds_wave, total) + block_sums[blockIdx.x];
+	uint32_t run = block_exclusive_scan_1024(sum, lds_wave, total) + my_base;
 #pragma unroll
 	for (int k = 0; k < ORDER_SCAN_ITEMS; k++) {
 		if (base + k < nb)
@@ -358,7 +374,7 @@ extern "C" size_t btbbx_order_hits_scratch_bytes(uint32_t cap)
 }
 
 static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_imm, uint32_t cap, void *d_scratch,
-			size_t scratch_bytes, hipStream_t stream)
+			size_t scratch_bytes, hipStream_t stream, uint32_t n_streams = 0, uint64_t max_offset = 0)
 {
 	if (cap < 2)
 		return BTBBX_OK;
@@ -375,11 +391,14 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	// parameters, bucket counters and cursors are contiguous: one memset
 	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)cap + 255) / 256, 2048);
-	hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
+	if (n_streams)
+		hipLaunchKernelGGL(order_bounds_kernel, dim3(1), dim3(1), 0, stream, d_count, n_imm, cap, L.nb_log2, n_streams,
+				   (unsigned long long)max_offset, p);
+	else
+		hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
 	hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
 	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
 	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
-	hipLaunchKernelGGL(order_scan_top_kernel, dim3(1), dim3(1024), 0, stream, sums, scan_blocks);
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
 	hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped);
 	hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
@@ -401,6 +420,19 @@ extern "C" int btbbx_order_hits_device(btbbx_hit *d_hits, const uint32_t *d_coun
 		return BTBBX_E_ARG;
 	}
 	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, (hipStream_t)hip_stream);
+}
+
+// ... when the caller knows what produced the list -- a scan of n_streams streams over search_bits offsets each (the
+// arguments of btbbx_scan_device) -- the pass over the list that looks for its largest stream number and offset is
+// not needed.  Records outside those bounds are a caller error (they would be binned wrongly).
+extern "C" int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, uint32_t n_streams,
+					    uint64_t search_bits, void *d_scratch, size_t scratch_bytes, void *hip_stream)
+{
+	if (!d_hits || !d_count || !n_streams || !search_bits) {
+		set_error("btbbx_order_scan_hits_device: bad argument");
+		return BTBBX_E_ARG;
+	}
+	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, (hipStream_t)hip_stream, n_streams, search_bits - 1);
 }
 
 // one scratch block per device for the signature without caller scratch

@@ -375,7 +375,7 @@ def test_device_hit_order_with_the_count_in_hbm():
     lib = bt.lib()
     rng = np.random.default_rng(_libs.seed(11))
 
-    def run(h, cap, count=None):
+    def run(h, cap, count=None, bounded=0):
         n = len(h)
         count = n if count is None else count
         room = np.zeros(max(cap, 1), bt.HIT_DTYPE)
@@ -384,7 +384,11 @@ def test_device_hit_order_with_the_count_in_hbm():
         c = bt.DeviceBuffer(16).upload(np.array([count, 0, 0, 0], np.uint32))
         sb = lib.btbbx_order_hits_scratch_bytes(cap)
         scratch = bt.DeviceBuffer(sb)
-        bt.check(lib.btbbx_order_hits_device(d.ptr, c.ptr, cap, scratch.ptr, sb, None), "btbbx_order_hits_device")
+        if bounded:                                                   # the form for a scan's own list: bounds from the caller
+            bt.check(lib.btbbx_order_scan_hits_device(d.ptr, c.ptr, cap, int(room["stream"].max()) + 1 + bounded - 1,
+                                                      int(room["offset"].max()) + bounded, scratch.ptr, sb, None), "order_scan_hits")
+        else:
+            bt.check(lib.btbbx_order_hits_device(d.ptr, c.ptr, cap, scratch.ptr, sb, None), "btbbx_order_hits_device")
         bt.check(lib.btbbx_sync(None))
         got = d.download(bt.HIT_DTYPE, max(cap, 1))
         for b in (d, c, scratch):
@@ -409,6 +413,8 @@ def test_device_hit_order_with_the_count_in_hbm():
     st = np.repeat(np.arange(79), 16000)
     run(hits(off, st), cap=79 * 16000 + 5000)
     run(hits(off, st), cap=79 * 16000 + 5000, count=1000)              # a short list in a big buffer
+    run(hits(off, st), cap=79 * 16000 + 5000, bounded=1)               # bounds given: exactly the extent ...
+    run(hits(off, st), cap=79 * 16000 + 5000, bounded=12345)           # ... and loose ones
     run(hits(off, st)[:3000], cap=2000, count=3000)                    # the counter ran past the capacity
     # crowded: 300 000 consecutive offsets (a stream made of sync words) next to sparse ones
     off = np.concatenate([np.arange(5_000_000, 5_300_000), rng.choice(1 << 33, 50000, replace=False)]).astype(np.uint64)

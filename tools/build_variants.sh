@@ -25,7 +25,7 @@ while [ $# -gt 0 ]; do
       $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -x hip -c "$src" -o "$o"
       objs="$objs $o"; skip="$skip|$(basename "${src%.*}").o"
     done
-    rest=$(ls build/*.o | grep -Ev "/(${skip#|})$")
+    rest=$(ls build/*.o | grep -v "/asan_" | grep -Ev "/(${skip#|})$")
     $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libbtbb.so.1 $rest $objs -o ../variants/$name.so
     rm -rf "$tmp"
     echo "built $name"
