@@ -425,6 +425,62 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
         }
         entry["parity"] = bool(np.array_equal(gpu_tab, table))
     out["clk6_bruteforce"] = entry
+
+    # ---- config 5 on the reference's WORST-CASE input: packets of 3125 random symbols whose header
+    # region is a clean FEC-1/3 encoding of 18 random bits, so that for every candidate clock the type field is uniform
+    # over 0..15 -- 89 % of the reference's time on this input goes into EV5's quadratic CRC scan (bluetooth_packet.c:1114-1126)
+    n_dist = 4096
+    rng5 = np.random.default_rng(SEED + 5)
+    w5 = rng5.integers(0, 1 << 63, (n_dist, 50), dtype=np.int64).view(np.uint64) * np.uint64(2) + \
+        rng5.integers(0, 2, (n_dist, 50), dtype=np.int64).view(np.uint64)
+    hdr18 = rng5.integers(0, 1 << 18, n_dist, dtype=np.int64).astype(np.uint64)
+    enc = np.zeros(n_dist, dtype=np.uint64)
+    for b in range(18):                                       # FEC 1/3: every header bit three times, symbols 68 .. 121
+        bit = (hdr18 >> np.uint64(b)) & np.uint64(1)
+        enc |= (bit * np.uint64(7)) << np.uint64(3 * b)
+    w5[:, 1] = (w5[:, 1] & ~(np.uint64((1 << 54) - 1) << np.uint64(4))) | (enc << np.uint64(4))
+    w5[:, 48] &= np.uint64((1 << (3125 - 48 * 64)) - 1)       # 3125 symbols captured, zeros behind them
+    w5[:, 49] = 0
+    pk6 = torch.from_numpy(w5.view(np.int64)).to(dev)[torch.arange(npk, device=dev) % n_dist].contiguous()
+    in6 = torch.zeros(npk, 4, dtype=torch.int32, device=dev)
+    in6[:, 0] = 3125
+    in6[:, 2] = 1
+    del pk5
+
+    def trials_all():
+        bt.check(lib.btbbx_trials_device(pk6.data_ptr(), in6.data_ptr(), npk, tr5.data_ptr(), hs))
+    t_all = tm.ms(trials_all, 3)
+    entry = {
+        "config": "BASELINE configs[4] on the reference's worst-case input (SURVEY.md Appendix A): 2^20 packets of 3125 random symbols "
+                  "with a clean FEC-1/3 header of 18 random bits (%d distinct, tiled) -- every candidate clock sees a uniform packet "
+                  "type; 64 x {try_clock, crc_check} per packet" % n_dist,
+        "value": round(npk / (t_all * 1e-3)), "unit": "packets/s", "ms_per_step": round(t_all, 3),
+        "trials_per_s": round(npk * 64 / (t_all * 1e-3)),
+        "roofline": {"bound": "hbm", "achieved": round(alg5 / (t_all * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg5 / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": alg5,
+                     "kernel": "trials_linear_kernel", "kernel_ms": round(t_all, 4), "traffic": None},
+    }
+    if ref is not None:
+        m = 128
+        buf = np.zeros((m, 3200), dtype=np.uint8)
+        for i in range(m):
+            buf[i] = synth.unpack_bits(w5[i])
+        table = np.zeros(m * 64, dtype=np.uint32)
+        t0 = time.perf_counter()
+        ref.refint_clk6_trials(_libs.ptr(buf), m, 3200, 3125, lap, _libs.ptr(table))
+        dt = time.perf_counter() - t0
+        g = tr5.view(npk, 64)[:m].cpu().numpy().view(bt.TRIAL_DTYPE).reshape(-1)
+        gpu_tab = g["uap"].astype(np.uint32) | (g["rv"].astype(np.int32).astype(np.uint32) << 8)
+        rv_hist = {int(k): int(v) for k, v in zip(*np.unique(g["rv"], return_counts=True))}
+        entry["cpu_baseline"] = {
+            "value": round(m / dt, 1), "unit": "packets/s", "cores": 1, "kind": "reference", "cpu_model": cpu["model"],
+            "physical_cores": cpu["physical_cores"],
+            "sample": "the first %d of the same packets, the 64-candidate try_clock + crc_check loop of btbb_uap_from_header "
+                      "(bluetooth_piconet.c:675-690) on one thread" % m,
+        }
+        entry["crc_check_rv_histogram_of_the_sample"] = rv_hist
+        entry["parity"] = bool(np.array_equal(gpu_tab, table))
+    out["clk6_bruteforce_all_types"] = entry
     return out
 
 
