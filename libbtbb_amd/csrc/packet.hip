@@ -318,6 +318,8 @@ struct PState {
 	// direct mode (decode_hits_kernel): the packet is bits [sh, sh + length) of w[0 .. wlimit)
 	uint32_t sh = 0;         // bit of w[0] the packet starts at
 	uint32_t wlimit = 0;     // stream words that exist from w on
+	uint32_t staged = 0;     // direct mode: w[0 .. staged) have a copy in LDS at LDS byte address `stage_off`
+	uint32_t stage_off = 0;
 	bool direct = false;
 	int length;              // pkt->length
 	uint32_t flags;
@@ -350,9 +352,15 @@ __device__ __forceinline__ uint64_t s_bits(const PState &s, uint32_t pos, uint32
 	if ((int)pos >= s.length)
 		return 0;
 	const uint32_t q = pos + s.sh, i = q >> 6, sft = q & 63;
-	uint64_t v = (i < s.wlimit ? s.w[i] : 0ULL) >> sft;
+	// words the wave staged through LDS (decode_hits_kernel) come from there, anything behind them from the stream
+	auto word = [&](uint32_t k) -> uint64_t {
+		if (k < s.staged)
+			return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>(s.stage_off + 8u * k);
+		return k < s.wlimit ? s.w[k] : 0ULL;
+	};
+	uint64_t v = word(i) >> sft;
 	if (sft + n > 64)
-		v |= (i + 1 < s.wlimit ? s.w[i + 1] : 0ULL) << (64 - sft);
+		v |= word(i + 1) << (64 - sft);
 	const uint32_t have = (uint32_t)s.length - pos;         // symbols left in front of `length`
 	const uint32_t keep = n < have ? n : have;
 	return keep == 64 ? v : v & ((1ULL << keep) - 1);
@@ -1379,18 +1387,37 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 	s.type = pi.type;
 	s.llid = pi.llid;
 	s.flow = pi.flow;
-	s.plen = o->payload_length;
-	s.phl = o->payload_header_length;
-	s.ph16 = (uint32_t)o->payload_header;
+	// The fixed part of btbbx_pkt_out (40 bytes in front of the payload words) is read and written as FIVE 8-byte
+	// words: a lane per packet means every vector memory instruction touches 64 different sectors, and the address
+	// unit works those off one by one -- twenty field-sized accesses per packet were most of decode_hits_kernel's time.
+	static_assert(offsetof(btbbx_pkt_out, payload) == 40 && offsetof(btbbx_pkt_out, payload_header) == 32, "head of btbbx_pkt_out");
+	union Head {
+		uint64_t q[5];
+		struct {
+			int32_t header_rv, payload_rv, payload_length, payload_header_length;
+			uint32_t flags, header_packed;
+			uint8_t header_present, type, lt_addr, hdr_flags, hec, llid, flow, uap;
+			uint64_t payload_header;
+		} f;
+	} hd;
+	{
+		const uint64_t *src = reinterpret_cast<const uint64_t *>(o);
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			hd.q[k] = src[k];
+	}
+	s.plen = hd.f.payload_length;
+	s.phl = hd.f.payload_header_length;
+	s.ph16 = (uint32_t)hd.f.payload_header;
 	s.ph_written = 0;
 	s.dirty = 0;
 	s.ph_mask = 0;
-	s.lt_addr = o->lt_addr; s.hdr_flags = o->hdr_flags; s.hec = o->hec; s.header18 = o->header_packed;
+	s.lt_addr = hd.f.lt_addr; s.hdr_flags = hd.f.hdr_flags; s.hec = hd.f.hec; s.header18 = hd.f.header_packed;
 	s.out = o->payload;
 	s.written = 0;
 
 	int header_rv = 0, payload_rv = 0;
-	o->header_present = (uint8_t)do_header_present(s);
+	hd.f.header_present = (uint8_t)do_header_present(s);
 
 	{
 		bool go = true;
@@ -1434,20 +1461,26 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 			s.flags |= F_HAS_PAYLOAD;
 		}
 	}
-	o->header_rv = header_rv;
-	o->payload_rv = payload_rv;
-	o->payload_length = s.plen;
-	o->payload_header_length = s.phl;
-	o->flags = s.flags;
-	o->header_packed = s.header18;
-	o->type = (uint8_t)s.type;
-	o->lt_addr = (uint8_t)s.lt_addr;
-	o->hdr_flags = (uint8_t)s.hdr_flags;
-	o->hec = (uint8_t)s.hec;
-	o->llid = (uint8_t)s.llid;
-	o->flow = (uint8_t)s.flow;
-	o->uap = (uint8_t)s.uap;
-	o->payload_header = s.ph16;
+	hd.f.header_rv = header_rv;
+	hd.f.payload_rv = payload_rv;
+	hd.f.payload_length = s.plen;
+	hd.f.payload_header_length = s.phl;
+	hd.f.flags = s.flags;
+	hd.f.header_packed = s.header18;
+	hd.f.type = (uint8_t)s.type;
+	hd.f.lt_addr = (uint8_t)s.lt_addr;
+	hd.f.hdr_flags = (uint8_t)s.hdr_flags;
+	hd.f.hec = (uint8_t)s.hec;
+	hd.f.llid = (uint8_t)s.llid;
+	hd.f.flow = (uint8_t)s.flow;
+	hd.f.uap = (uint8_t)s.uap;
+	hd.f.payload_header = s.ph16;
+	{
+		uint64_t *dst = reinterpret_cast<uint64_t *>(o);
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			dst[k] = hd.q[k];
+	}
 }
 
 __device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
@@ -1472,18 +1505,48 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 // the first writes and the second reads back (profiles/r02_v4/pmc_secondary.json: the two moved 2.0 GB per
 // 1.29 M packets, of which the packets themselves are 0.5 GB).  One lane per hit; the captured length is the
 // gather's: min(max_length, 3125, symbols left in the stream), and d_in[i].length is ignored.
-__global__ __launch_bounds__(256) void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
+//
+// A lane walking its packet word by word from HBM fetched 753 B per packet for ~300 needed (every 8-byte read
+// drags a 64-byte sector through the L2, profiles/traffic_secondary.json, round 2).  Now the wave brings the
+// packets in together: every lane first reads its header (symbols 68 .. 121, at most two words) and works out the
+// packet type for its clock -- how many symbols a packet of that type can have is all the decoders will look at --
+// then the 64 packets are copied to LDS one after the other, 64 lanes = 64 consecutive words = whole sectors, and
+// decoded from there.  s_bits() takes words the staging did not cover (a budget of DH_STAGE_WORDS per wave) from
+// the stream as before, so the symbol bound only decides where a word comes from, never what it is.
+#ifndef DH_STAGE_WORDS
+#define DH_STAGE_WORDS 384u                  // LDS words per wave for staged packets (3 KiB; 4 waves per workgroup)
+#endif
+__device__ __forceinline__ uint32_t symbols_of_type(uint32_t type)
+{
+	// 122 symbols of access code + trailer + header, then the longest payload of the type (FEC 2/3: 15 symbols per
+	// 10 bits): bluetooth_packet.c:771-1196.  Single-slot types 366, three-slot 1626, five-slot the whole capture.
+	if (type == 10 || type == 11 || type == 12 || type == 13)
+		return 1626;
+	if (type == 14 || type == 15)
+		return BTBBX_MAX_SYMBOLS;
+	return 366;
+}
+
+#ifndef DH_WAVES_PER_EU
+#define DH_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH_WAVES_PER_EU, DH_WAVES_PER_EU)))
+void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
 							  const uint32_t *d_count, uint32_t max_length, btbbx_pkt_out *outs,
 							  uint32_t *lengths, uint32_t mode)
 {
+	__shared__ uint64_t stage[4][DH_STAGE_WORDS];
 	chain_lds_init();
-	const uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
 		n_packets = min(n_packets, *d_count);
-	if (pkt >= n_packets)
-		return;
-	const btbbx_hit h = hits[pkt];
+	const bool live = pkt < n_packets;
+	btbbx_hit h;
+	h.offset = 0;
+	h.stream = 0;
+	if (live)
+		h = hits[pkt];
 	const uint64_t total_bits = n_words * 64;
 	const uint64_t avail = h.offset < total_bits ? total_bits - h.offset : 0;
 	uint32_t len = avail < max_length ? (uint32_t)avail : max_length;
@@ -1495,9 +1558,71 @@ __global__ __launch_bounds__(256) void decode_hits_kernel(const uint64_t *words,
 	s.sh = (uint32_t)(h.offset & 63);
 	s.wlimit = first_word < n_words ? (uint32_t)(n_words - first_word < 64 ? n_words - first_word : 64) : 0;
 	s.direct = true;
-	s.length = (int)len;
-	btbbx_pkt_in pi = in[pkt];
+	s.length = live ? (int)len : 0;
+	btbbx_pkt_in pi;
+	pi.length = 0; pi.clkn = 0; pi.flags = 0; pi.uap = 0; pi.type = 0; pi.llid = 0; pi.flow = 0;
+	if (live)
+		pi = in[pkt];
 	pi.length = len;
+
+	// how much of the packet the decoders can want: the type the header yields under this packet's clock
+	uint32_t want = 0;
+	if (live) {
+		want = len < 126 ? len : 126;
+		if ((mode & DEC_PAYLOAD) && len > 126) {
+			s.flags = pi.flags;
+			uint32_t dis;
+			const uint32_t hdr = header_fec13(s, dis);
+			uint32_t type = pi.type;
+			if (mode & DEC_HEADER)
+				type = ((hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18)) >> 3) & 0xf;
+			const uint32_t bound = symbols_of_type(type);
+			want = len < bound ? len : bound;
+		}
+	}
+	uint32_t nw = live ? (s.sh + want + 63) / 64 : 0;              // words of the stream that hold those symbols
+	if (nw > s.wlimit)
+		nw = s.wlimit;
+	// LDS slots in lane order; a packet that does not fit the wave's budget any more stays in the stream
+	uint32_t before = nw;
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(before, d);
+		if (lane >= (uint32_t)d)
+			before += t;
+	}
+	before -= nw;
+	if (before + nw > DH_STAGE_WORDS)
+		nw = 0;
+	typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+	const uint32_t stage_base = (uint32_t)(uintptr_t)(lds_u64_t *)(&stage[wave][0]);
+	// packet j of the wave: its words, one per lane.  Sixteen packets' loads are issued before the first of them is
+	// written to LDS: one packet at a time the wave sat out 64 HBM latencies in a row (67 us of wave life time, 80 %
+	// of it in s_waitcnt, profiles/r03_chain/pmc_decode_before.json).
+	for (uint32_t j0 = 0; j0 < 64; j0 += 16) {
+		uint64_t val[16];
+		uint32_t cnt[16], dst[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			cnt[k] = __shfl(nw, j0 + k);
+			dst[k] = __shfl(before, j0 + k);
+			const uint64_t src = __shfl((uint64_t)(uintptr_t)s.w, j0 + k);
+			val[k] = 0;
+			if (lane < cnt[k])
+				val[k] = reinterpret_cast<const uint64_t *>((uintptr_t)src)[lane];
+		}
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			if (lane < cnt[k])
+				stage[wave][dst[k] + lane] = val[k];
+	}
+	s.staged = nw;
+	s.stage_off = stage_base + 8u * before;
+
+	// (Sorting the workgroup's packets by type, so that a wave runs one decoder with all lanes instead of four with a
+	// quarter each, was built and measured: no gain, 365 vs 357 us -- the kernel waits, it does not issue.  What helps
+	// is waves: profiles/r03_chain/pmc_decode_before.json has 80 % of the wave-cycles in s_waitcnt at 16 waves per CU.)
+	if (!live)
+		return;
 	decode_view(s, pi, outs + pkt, mode);
 	if (lengths)
 		lengths[pkt] = len;
