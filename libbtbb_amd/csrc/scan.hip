@@ -1082,6 +1082,12 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 // counter atomic per 64 hits (a single counter word saturates near 88 M atomics/s on this
 // chip, which a dense hit stream would otherwise run into).
 #define KRING 128
+#ifndef KL_WORDS
+#define KL_WORDS 2                             // stream words per lane and tile (tile = KL_WORDS x 256 words)
+#endif
+#ifndef KL_PREFETCH
+#define KL_PREFETCH 1
+#endif
 struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per staged hit
 
 // LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
@@ -1093,7 +1099,8 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	KnownHit *ring = ring_mem[tid >> 6];
-	const uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
+	uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
+	asm volatile("" : "+v"(ac_lo), "+v"(ac_hi));          // (an SGPR operand halves the issue rate of the XORs in the survivor pass)
 	// the planes of the filter are XORed with all-ones where the sync word has a 1: sixteen masks, kept in
 	// VGPRs on purpose -- they are wave-uniform, and a VALU instruction with an SGPR source issues at half rate
 	// (tools/valu_rate.hip: 4.2 against 2.5 cycles)
@@ -1158,54 +1165,105 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		t -= tiles_per_stream;
 		stream++;
 	}
-	while (stream < a.n_streams) {
-		const uint64_t word = (uint64_t)t * 256 + tid;
-		const uint64_t *base = a.words + (uint64_t)stream * a.pitch_words;
-		uint64_t lo, hi, valid = FULL_MASK;
-		if (t < a.full_tiles) {                         // wave-uniform: every word, halo word and offset of the tile is in range
-			lo = base[word];
-			hi = base[word + 1];
-		} else {
-			lo = load_word(base, word, a.n_words);
-			hi = load_word(base, word + 1, a.n_words);
-			const uint64_t first_off = word * 64;
-			valid = first_off >= a.search_bits ? 0ULL
-				: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+	// a tile is KL_WORDS x 256 words: every lane owns KL_WORDS words 256 apart.  The next tile's words are loaded while
+	// this one is worked on (KL_PREFETCH): the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per
+	// SIMD taking turns at their loads (profiles/r03_chain/pmc_known_before.json).
+	uint64_t nlo[KL_WORDS], nhi[KL_WORDS], nvalid[KL_WORDS], nword[KL_WORDS];
+	auto fetch = [&](uint32_t ft, uint32_t fstream) {
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++) {
+			nlo[u] = nhi[u] = 0;
+			nvalid[u] = 0;
+			nword[u] = ((uint64_t)ft * KL_WORDS + u) * 256 + tid;
 		}
-		__builtin_amdgcn_s_setprio(0);                  // bit-sliced filter: lowest (see PRIO_FILTER above)
-		const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32);
-		const uint32_t d2 = (uint32_t)hi, d3 = (uint32_t)(hi >> 32);
-		uint32_t mA, mB;
-		if (wide) {
-			mA = top16_filter(d1, d2, flip, limit);
-			mB = top16_filter(d2, d3, flip, limit);
-		} else {
-			mA = top12_filter(d1, d2, flip, limit);
-			mB = top12_filter(d2, d3, flip, limit);
-		}
-		mA &= (uint32_t)valid;
-		mB &= (uint32_t)(valid >> 32);
-		__builtin_amdgcn_s_setprio(3);                  // survivors, hit staging, flush and the next tile's loads: highest
-		// wave-uniform survivor loop, one offset of each half per pass
-		while (__ballot((mA | mB) != 0)) {
-			const uint32_t pA = __builtin_ctz(mA | 0x80000000u), pB = __builtin_ctz(mB | 0x80000000u);
-			const int eA = __popc(alignbit(d1, d0, pA) ^ ac_lo) + __popc(alignbit(d2, d1, pA) ^ ac_hi);   // :433
-			const int eB = __popc(alignbit(d2, d1, pB) ^ ac_lo) + __popc(alignbit(d3, d2, pB) ^ ac_hi);
-			const bool hitA = mA != 0 && eA <= limit, hitB = mB != 0 && eB <= limit;
-			if (__ballot(hitA || hitB)) {
-				stage(hitA, stream, word * 64 + pA, (uint32_t)eA);
-				stage(hitB, stream, word * 64 + 32 + pB, (uint32_t)eB);
+		if (fstream >= a.n_streams)
+			return;
+		const uint64_t *fbase = a.words + (uint64_t)fstream * a.pitch_words;
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++) {
+			nvalid[u] = FULL_MASK;
+			if (ft < a.full_tiles) {                    // wave-uniform: every word, halo word and offset of the tile is in range
+				nlo[u] = fbase[nword[u]];
+				nhi[u] = fbase[nword[u] + 1];
+			} else {
+				nlo[u] = load_word(fbase, nword[u], a.n_words);
+				nhi[u] = load_word(fbase, nword[u] + 1, a.n_words);
+				const uint64_t first_off = nword[u] * 64;
+				nvalid[u] = first_off >= a.search_bits ? 0ULL
+					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 			}
-			mA &= mA - 1;
-			mB &= mB - 1;
 		}
-		while (q_tail - q_head >= 64)
-			flush(64);
+	};
+	fetch(t, stream);
+	while (stream < a.n_streams) {
+		uint64_t word[KL_WORDS];
+		uint32_t d[KL_WORDS][4], m[KL_WORDS][2];
+		uint64_t lo[KL_WORDS], hi[KL_WORDS], valid[KL_WORDS];
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++) {
+			word[u] = nword[u];
+			lo[u] = nlo[u];
+			hi[u] = nhi[u];
+			valid[u] = nvalid[u];
+		}
+		const uint32_t this_stream = stream;
 		t += gridDim.x;
-		while (t >= tiles_per_stream) {
+		while (t >= tiles_per_stream && stream < a.n_streams) {
 			t -= tiles_per_stream;
 			stream++;
 		}
+		if (KL_PREFETCH)
+			fetch(t, stream);
+		__builtin_amdgcn_s_setprio(0);                  // bit-sliced filter: lowest (see PRIO_FILTER above)
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++) {
+			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
+			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			if (wide) {
+				m[u][0] = top16_filter(d[u][1], d[u][2], flip, limit);
+				m[u][1] = top16_filter(d[u][2], d[u][3], flip, limit);
+			} else {
+				m[u][0] = top12_filter(d[u][1], d[u][2], flip, limit);
+				m[u][1] = top12_filter(d[u][2], d[u][3], flip, limit);
+			}
+			m[u][0] &= (uint32_t)valid[u];
+			m[u][1] &= (uint32_t)(valid[u] >> 32);
+		}
+		__builtin_amdgcn_s_setprio(3);                  // survivors, hit staging, flush and the next tile's loads: highest
+		// wave-uniform survivor loop, one offset of every 32-offset half per pass
+		for (;;) {
+			uint32_t any = 0;
+#pragma unroll
+			for (int u = 0; u < KL_WORDS; u++)
+				any |= m[u][0] | m[u][1];
+			if (!__ballot(any != 0))
+				break;
+			uint32_t p[KL_WORDS][2];
+			int e[KL_WORDS][2];
+			bool hit[KL_WORDS][2], anyhit = false;
+#pragma unroll
+			for (int u = 0; u < KL_WORDS; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					p[u][h] = __builtin_ctz(m[u][h] | 0x80000000u);
+					e[u][h] = __popc(alignbit(d[u][h + 1], d[u][h], p[u][h]) ^ ac_lo)
+						+ __popc(alignbit(d[u][h + 2], d[u][h + 1], p[u][h]) ^ ac_hi);          // :433
+					hit[u][h] = m[u][h] != 0 && e[u][h] <= limit;
+					anyhit |= hit[u][h];
+					m[u][h] &= m[u][h] - 1;
+				}
+			if (__ballot(anyhit)) {
+#pragma unroll
+				for (int u = 0; u < KL_WORDS; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						stage(hit[u][h], this_stream, word[u] * 64 + 32 * h + p[u][h], (uint32_t)e[u][h]);
+			}
+		}
+		while (q_tail - q_head >= 64)
+			flush(64);
+		if (!KL_PREFETCH)
+			fetch(t, stream);
 	}
 	if (q_tail != q_head)
 		flush(q_tail - q_head);
@@ -1387,10 +1445,11 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	} else {
 		a.syncword = host_gen_syncword(lap & 0xffffff);
 		a.lap = lap;
-		a.tiles_per_stream = (search_words + 255) / 256;
+		const uint64_t kl_tile = 256ull * KL_WORDS;
+		a.tiles_per_stream = (search_words + kl_tile - 1) / kl_tile;
 		a.n_tiles = a.tiles_per_stream * n_streams;
-		{	// tile t (256 words) is full iff (t + 1) * 256 + 1 <= n_words and (t + 1) * 16384 <= search_bits
-			const uint64_t by_words = n_words ? (n_words - 1) / 256 : 0, by_bits = search_bits / (256 * 64ull);
+		{	// tile t (kl_tile words) is full iff (t + 1) * kl_tile + 1 <= n_words and (t + 1) * kl_tile * 64 <= search_bits
+			const uint64_t by_words = n_words ? (n_words - 1) / kl_tile : 0, by_bits = search_bits / (kl_tile * 64ull);
 			const uint64_t full = by_words < by_bits ? by_words : by_bits;
 			a.full_tiles = full > 0xffffffffull ? 0xffffffffu : (uint32_t)full;
 		}
