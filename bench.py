@@ -696,12 +696,19 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # HBM traffic per launch: NOT measured in this run -- the value of the last rocprofv3 --pmc passes over
         # this same command (separate passes, FETCH_SIZE doubled as the guide prescribes), see the file named
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         fp = csrc_fingerprint()
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if abs(args.gib - 4.0) < 1e-9 and tj.get("csrc_sha16") == fp:
                 traffic = int(tj["bytes_per_launch"])
+                v = tj.get("valu") or {}
+                if v.get("insts_per_launch"):
+                    # what the kernel is really bound by: fraction of the VALU-issue ceiling = wave-instructions x cycles per
+                    # instruction / (SIMDs x clock) / kernel time (instruction count from the PMC run named in traffic_source)
+                    busy_s = v["insts_per_launch"] * v["cycles_per_inst"] / (v["simds"] * v["clock_ghz"] * 1e9)
+                    valu = {"insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
+                            "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kern_ms * 1e-3), 4)}
                 traffic_source = "profiles/traffic.json (%s), same sources as this build (csrc_sha16 %s); not re-measured in this run" % (
                     tj.get("source", "rocprofv3 --pmc"), fp)
             else:
@@ -722,7 +729,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_slide_kernel", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "valu": valu},
             "csrc_sha16": fp,
         }
         cpu = host_cpu()

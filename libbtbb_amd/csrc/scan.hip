@@ -93,9 +93,18 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uin
 	}
 }
 
+// Stream words are read once: STREAM_NT loads them non-temporally (they then do not push the L2-resident tables of the
+// >= 4-error kernels -- the 2^26-bit second-level bitmap -- out of the cache).
+#ifndef STREAM_NT
+#define STREAM_NT 0
+#endif
+__device__ __forceinline__ uint64_t stream_ld(const uint64_t *p)
+{
+	return STREAM_NT ? __builtin_nontemporal_load(p) : *p;
+}
 __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, uint64_t n_words)
 {
-	return j < n_words ? base[j] : 0ULL;
+	return j < n_words ? stream_ld(base + j) : 0ULL;
 }
 
 // The exact acceptance rule of promiscuous_packet_search for one offset that passed the
@@ -502,12 +511,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			return;
 		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SCAN_THREADS;   // uniform
 		if (tile_full(c.t)) {
-			lo = tp[tid];
-			hi = tp[tid + 1];
+			lo = stream_ld(tp + tid);
+			hi = stream_ld(tp + tid + 1);
 		} else {
 			const uint64_t w = (uint64_t)c.t * SCAN_THREADS + tid;
-			lo = w < a.n_words ? tp[tid] : 0;
-			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
+			lo = w < a.n_words ? stream_ld(tp + tid) : 0;
+			hi = w + 1 < a.n_words ? stream_ld(tp + tid + 1) : 0;
 		}
 	};
 
@@ -707,7 +716,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #define SLIDE_SET_BYTES  (4u * SLIDE_SET_WORDS)
 template <int WGS> struct SlideGeom {
 	static constexpr uint32_t RING = WGS == 2 ? 64 : 128;               // ring entries per wave
-	static constexpr uint32_t LDS_BYTES = SLIDE_SET_BYTES + CAND_BYTES * (SLIDE_THREADS / 64) * RING;
+	static constexpr uint32_t RING_END = SLIDE_SET_BYTES + CAND_BYTES * (SLIDE_THREADS / 64) * RING;
+#ifdef SCAN_PROFILE
+	static constexpr uint32_t LDS_BYTES = RING_END + 128u * (SLIDE_THREADS / 64);     // 32 phase counters per wave
+#else
+	static constexpr uint32_t LDS_BYTES = RING_END;
+#endif
 };
 
 template <int TILES, int WGS>
@@ -742,6 +756,15 @@ void scan_slide_kernel(ScanArgs a)
 	}
 	__syncthreads();
 
+#ifdef SCAN_PROFILE
+	// phases: 0 = tile loads + barker filter + check stream, 1 .. 13 = survivor pass k, 16 = loop exit, 18 = ring drain,
+	// 19 = hand-over to the next trip
+	const uint32_t prof_off = SlideGeom<WGS>::RING_END + 128u * wave;
+	if (lane < 32)
+		lds_st(prof_off + 4u * lane, 0u);
+	uint64_t prof_t;
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t) : : "memory");
+#endif
 	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
 	// code = (tile iteration << 12) | (lane that owns the word << 6) | offset in the word
 	auto code_word = [&](uint32_t code, uint32_t &stream) {
@@ -840,12 +863,12 @@ void scan_slide_kernel(ScanArgs a)
 			return;
 		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SLIDE_THREADS;   // uniform
 		if (tile_full(c.t)) {
-			lo = tp[tid];
-			hi = tp[tid + 1];
+			lo = stream_ld(tp + tid);
+			hi = stream_ld(tp + tid + 1);
 		} else {
 			const uint64_t w = (uint64_t)c.t * SLIDE_THREADS + tid;
-			lo = w < a.n_words ? tp[tid] : 0;
-			hi = w + 1 < a.n_words ? tp[tid + 1] : 0;
+			lo = w < a.n_words ? stream_ld(tp + tid) : 0;
+			hi = w + 1 < a.n_words ? stream_ld(tp + tid + 1) : 0;
 		}
 	};
 
@@ -906,6 +929,9 @@ void scan_slide_kernel(ScanArgs a)
 				any |= m[u][0] | m[u][1];
 			return __ballot(any != 0) != 0;
 		};
+		// (Dropping the "this lane has a survivor" bit from the first passes of a trip, where practically every chain has one,
+		// and sorting idle lanes out inside the event instead: 3.59 against 3.53 ms for three such passes, 3.69 for six --
+		// an idle lane whose junk index happens to be in the set triggers an event in EVERY pass.  profiles/r03_ab.)
 		auto pass = [&]() {
 			Stage g;
 #pragma unroll
@@ -940,7 +966,9 @@ void scan_slide_kernel(ScanArgs a)
 						const uint32_t room = RING - (q_tail - q_head);
 						const uint32_t n = min((uint32_t)__popcll(cm), room);
 						if (cand) {
-							const uint32_t code = ((it + u) << 12) | (lane << 6) | (h << 5) | (g.p[u][h] & 31);
+							uint32_t lane6 = lane << 6;
+							asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
+							const uint32_t code = ((it + u) << 12) | lane6 | (h << 5) | (g.p[u][h] & 31);
 							const uint32_t wlo = alignbit(d[u][h + 1], d[u][h], g.p[u][h]);
 							const uint32_t whi = alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]);
 							const u32x4 rec = {code, wlo, whi, 0u};
@@ -953,8 +981,9 @@ void scan_slide_kernel(ScanArgs a)
 								if (rank < room) {
 									lds_st4(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
 								} else {
-									uint32_t stream, lap, nerr;
-									const uint64_t word = code_word(code, stream);
+									uint32_t stream, lap, nerr, cold = code;
+									asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
+									const uint64_t word = code_word(cold, stream);
 									if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
 										emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
 								}
@@ -964,15 +993,32 @@ void scan_slide_kernel(ScanArgs a)
 					}
 			}
 		};
+#ifdef SCAN_PROFILE
+#pragma unroll
+		for (int u = 0; u < TILES; u++) {
+			PROF_PIN(m[u][0]); PROF_PIN(m[u][1]); PROF_PIN(c[u][0]); PROF_PIN(c[u][1]); PROF_PIN(c[u][2]);
+		}
+#endif
+		PROF_MARK(0);
 		__builtin_amdgcn_s_setprio(PRIO_LOOP);
+		uint32_t pass_no = 1;
 #pragma unroll 1
-		for (int k = 0; k < SLIDE_FIXED; k++)       // practically every trip needs these (TILES * 128 chains of ~4 survivors)
+		for (int k = 0; k < SLIDE_FIXED; k++) {     // practically every trip needs these (TILES * 128 chains of ~4 survivors)
 			pass();
-		while (any_left())
+			PROF_MARK(pass_no < 13 ? pass_no : 13);
+			pass_no++;
+		}
+		while (any_left()) {
 			pass();
+			PROF_MARK(pass_no < 13 ? pass_no : 13);
+			pass_no++;
+		}
+		(void)pass_no;
 		__builtin_amdgcn_s_setprio(PRIO_CAND);
+		PROF_MARK(16);
 		if (q_tail - q_head >= (RING == 64 ? 48u : 64u))
 			drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+		PROF_MARK(18);
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
 			if (SLIDE_PREFETCH) {
@@ -985,10 +1031,15 @@ void scan_slide_kernel(ScanArgs a)
 				advance(cur);
 			}
 		}
+		PROF_MARK(19);
 	}
 	while (q_tail != q_head)
 		drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
 	flush_hits();
+#ifdef SCAN_PROFILE
+	if (lane < 32)
+		atomicAdd(&g_scan_prof[lane], (unsigned long long)lds_ld(prof_off + 4u * lane));
+#endif
 }
 
 

@@ -32,6 +32,13 @@ json.dump({
                   "gfx950 and as calibrated on this kernel's own load shape (profiles/r01_calib: 0.5105 of the true bytes)",
     "FETCH_SIZE_KB": pmc[name]["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc[name]["WRITE_SIZE"]["mean_per_launch"],
     "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": round(b / alg, 3), "kernel": name + ", 4 GiB LAP_ANY bench workload",
+    # the VALU-issue ceiling bench.py quotes next to the HBM roofline (roofline.valu): wave-instructions per launch from the same
+    # PMC run; cycles per instruction = the kernel's static mix (28 % of its VALU instructions are half-rate ones: v_alignbit,
+    # v_ffbl, v_mbcnt ...) priced with tools/valu_rate.bin (profiles/r03_ab/valu_rate.txt: 2.65 / 4.35 cycles at 2.4 GHz)
+    "valu": {"insts_per_launch": pmc[name].get("SQ_INSTS_VALU", {}).get("mean_per_launch"), "cycles_per_inst": 3.1,
+             "simds": 1024, "clock_ghz": 2.4,
+             "lds_insts_per_launch": pmc[name].get("SQ_INSTS_LDS", {}).get("mean_per_launch"),
+             "salu_insts_per_launch": pmc[name].get("SQ_INSTS_SALU", {}).get("mean_per_launch")},
 }, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / alg))
 
