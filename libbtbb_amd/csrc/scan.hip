@@ -712,6 +712,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #ifndef SLIDE_FIXED
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (0: +3 %)
 #endif
+#ifndef SLIDE_DRAIN_AT
+#define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
+#endif
 #define SLIDE_SET_WORDS  (1u << (SLIDE_BITS - 5))
 #define SLIDE_SET_BYTES  (4u * SLIDE_SET_WORDS)
 template <int WGS> struct SlideGeom {
@@ -1016,7 +1019,7 @@ void scan_slide_kernel(ScanArgs a)
 		(void)pass_no;
 		__builtin_amdgcn_s_setprio(PRIO_CAND);
 		PROF_MARK(16);
-		if (q_tail - q_head >= (RING == 64 ? 48u : 64u))
+		if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
 			drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
 		PROF_MARK(18);
 #pragma unroll

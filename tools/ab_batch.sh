@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B batch on the GPU box: scan tests for the listed builds, then the headline bench for every variant, twice.
-#   tools/r3_batch.sh <out-dir-name> "<so files to test>"
+#   tools/ab_batch.sh <out-dir-name> "<so files to test>"
 out=gpurun_out/$1; mkdir -p $out
 for so in $2; do
   echo "== $so" >> $out/tests.txt
