@@ -39,6 +39,7 @@ struct ScanArgs {
 	uint64_t tiles_per_stream;
 	uint64_t n_tiles;
 	uint32_t xcd_tiles;      // LAP_ANY: tiles per XCD share (0 = plain round robin over workgroups)
+	uint32_t ring_margin;    // scan_slide_kernel: free ring entries below which the pass loop is left for a drain
 	uint32_t full_tiles;     // leading tiles of a stream whose words, halo word and offsets are all in range
 	uint32_t n_streams;
 	uint32_t lap;            // known-LAP mode
@@ -727,7 +728,11 @@ template <int WGS> struct SlideGeom {
 #endif
 };
 
-template <int TILES, int WGS>
+// DENSE: tables for 3 errors, where 6 % of the survivors are candidates (0.3 % for <= 2 errors) and a trip fills the ring --
+// the pass loop then watches the ring's room and is left for a drain; the sparse form runs six passes blind and checks in
+// place the few candidates a full ring turns away (measured: the room test in every pass costs the sparse case 4 %, the
+// in-place path costs the dense case a factor of three).
+template <int TILES, int WGS, bool DENSE>
 __global__ __launch_bounds__(SLIDE_THREADS) __attribute__((amdgpu_waves_per_eu(SLIDE_WAVES_PER_EU, SLIDE_WAVES_PER_EU)))
 void scan_slide_kernel(ScanArgs a)
 {
@@ -1003,24 +1008,49 @@ void scan_slide_kernel(ScanArgs a)
 		}
 #endif
 		PROF_MARK(0);
-		__builtin_amdgcn_s_setprio(PRIO_LOOP);
 		uint32_t pass_no = 1;
+		if (!DENSE) {
+			__builtin_amdgcn_s_setprio(PRIO_LOOP);
 #pragma unroll 1
-		for (int k = 0; k < SLIDE_FIXED; k++) {     // practically every trip needs these (TILES * 128 chains of ~4 survivors)
-			pass();
-			PROF_MARK(pass_no < 13 ? pass_no : 13);
-			pass_no++;
-		}
-		while (any_left()) {
-			pass();
-			PROF_MARK(pass_no < 13 ? pass_no : 13);
-			pass_no++;
+			for (int k = 0; k < SLIDE_FIXED; k++) { // practically every trip needs these (TILES * 128 chains of ~4 survivors)
+				pass();
+				PROF_MARK(pass_no < 13 ? pass_no : 13);
+				pass_no++;
+			}
+			while (any_left()) {
+				pass();
+				PROF_MARK(pass_no < 13 ? pass_no : 13);
+				pass_no++;
+			}
+			__builtin_amdgcn_s_setprio(PRIO_CAND);
+			PROF_MARK(16);
+			if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
+				drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+		} else {
+			// The pass loop is left when the ring gets short of room (a.ring_margin entries: what a pass may add), drained at
+			// the one site behind it and re-entered; candidates that still find no room are checked in place.  (With the
+			// drain inside the pass loop its hit registers would be loop-carried through every pass.)
+			for (;;) {
+				__builtin_amdgcn_s_setprio(PRIO_LOOP);
+				bool more = true;
+				while (q_tail - q_head + a.ring_margin <= RING) {
+					if (!any_left()) {
+						more = false;
+						break;
+					}
+					pass();
+					PROF_MARK(pass_no < 13 ? pass_no : 13);
+					pass_no++;
+				}
+				__builtin_amdgcn_s_setprio(PRIO_CAND);
+				PROF_MARK(16);
+				if (more || q_tail - q_head >= 32u)
+					drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+				if (!more)
+					break;
+			}
 		}
 		(void)pass_no;
-		__builtin_amdgcn_s_setprio(PRIO_CAND);
-		PROF_MARK(16);
-		if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
-			drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
 		PROF_MARK(18);
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
@@ -1441,6 +1471,7 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	a.hit_count = d_hit_count;
 	a.first = d_first;
 	a.xcd_tiles = 0;
+	a.ring_margin = 4;
 	a.t = c.scan;
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
@@ -1477,10 +1508,17 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		case 8: LAUNCH_VARIANT(8); break;
 		case 9: LAUNCH_VARIANT(9); break;
 		case 1: {
+			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS>),
-						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-			hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+			if (c.table_errors >= 3) {
+				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>),
+							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+			} else {
+				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, false>),
+							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, false>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+			}
 			break;
 		}
 		default: LAUNCH_VARIANT(0); break;
