@@ -713,6 +713,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #ifndef SLIDE_FIXED
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (0: +3 %)
 #endif
+#ifndef SLIDE_FOR_4
+#define SLIDE_FOR_4 0                      // 1: tables for 4 errors through scan_slide_kernel<1, WGS, DENSE> -- measured 6.26 ms per GiB
+                                           // against 3.27 for scan_lap_any_kernel<9>: 58 % of the survivors are candidates there, and the
+                                           // full exact check per candidate costs more than that kernel's in-loop probe of the L2 bitmap
+#endif
+#ifndef SLIDE_MARGIN_4
+#define SLIDE_MARGIN_4 44u
+#endif
 #ifndef SLIDE_DRAIN_AT
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
 #endif
@@ -1480,7 +1488,7 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		// runs the sliding-check kernel
 		int run_variant = SCAN_SLIDE ? 1 : 0;
 		if (c.scan.bitmap2 && c.table_errors >= 4)
-			run_variant = c.table_errors == 4 ? 9 : 8;
+			run_variant = c.table_errors == 4 ? (SLIDE_FOR_4 ? 1 : 9) : 8;
 		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : SCAN_THREADS;      // one word per thread
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
@@ -1510,7 +1518,15 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		case 1: {
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
-			if (c.table_errors >= 3) {
+			if (c.table_errors >= 4) {
+				// 4 errors: 58 % of the survivors pass the 2^19-bit set -- one tile per trip (two chains), the ring drained after
+				// practically every pass, every candidate through the 2^26-bit second-level bitmap in L2 (verify_lap_any) at
+				// full lanes instead of one probe per surviving lane inside the lock-step loop (scan_lap_any_kernel<9>)
+				a.ring_margin = SLIDE_MARGIN_4;
+				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<1, SLIDE_WGS, true>),
+							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+				hipLaunchKernelGGL((scan_slide_kernel<1, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+			} else if (c.table_errors >= 3) {
 				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>),
 							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
