@@ -1206,6 +1206,16 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	if (limit < 0)
 		return;
 	const bool wide = limit >= 2;               // launch-uniform choice of the pre-filter
+#ifdef SCAN_PROFILE
+	// phases: 0 = wait for the tile's words, 1 = bit-sliced filter, 2 = survivor passes + hit staging, 3 = ring flush + tile cursor,
+	// 4 = issuing the next tile's loads
+	__shared__ uint32_t kl_prof[4][32];
+	const uint32_t prof_off = (uint32_t)(uintptr_t)(lds_u32_t *)&kl_prof[tid >> 6][0];
+	if (lane < 32)
+		kl_prof[tid >> 6][lane] = 0;
+	uint64_t prof_t;
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t) : : "memory");
+#endif
 	uint32_t q_head = 0, q_tail = 0;                // wave-uniform, free running
 
 	auto flush = [&](uint32_t n) {                  // n <= 64 oldest entries -> global hit list
@@ -1260,43 +1270,46 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	// a tile is KL_WORDS x 256 words: every lane owns KL_WORDS words 256 apart.  The next tile's words are loaded while
 	// this one is worked on (KL_PREFETCH): the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per
 	// SIMD taking turns at their loads (profiles/r03_chain/pmc_known_before.json).
-	uint64_t nlo[KL_WORDS], nhi[KL_WORDS], nvalid[KL_WORDS], nword[KL_WORDS];
+	uint64_t nlo[KL_WORDS], nhi[KL_WORDS];
 	auto fetch = [&](uint32_t ft, uint32_t fstream) {
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++) {
+		for (int u = 0; u < KL_WORDS; u++)
 			nlo[u] = nhi[u] = 0;
-			nvalid[u] = 0;
-			nword[u] = ((uint64_t)ft * KL_WORDS + u) * 256 + tid;
-		}
 		if (fstream >= a.n_streams)
 			return;
-		const uint64_t *fbase = a.words + (uint64_t)fstream * a.pitch_words;
+		// wave-uniform tile pointer + the lane's constant index: no 64-bit address arithmetic per lane and tile (issuing
+		// the loads had been 8.5 % of the wave time, profiles/r03_chain/known_lap_phases.txt)
+		const uint64_t *tp = a.words + (uint64_t)fstream * a.pitch_words + (uint64_t)ft * (KL_WORDS * 256);
 #pragma unroll
 		for (int u = 0; u < KL_WORDS; u++) {
-			nvalid[u] = FULL_MASK;
 			if (ft < a.full_tiles) {                    // wave-uniform: every word, halo word and offset of the tile is in range
-				nlo[u] = fbase[nword[u]];
-				nhi[u] = fbase[nword[u] + 1];
+				nlo[u] = tp[u * 256 + tid];
+				nhi[u] = tp[u * 256 + tid + 1];
 			} else {
-				nlo[u] = load_word(fbase, nword[u], a.n_words);
-				nhi[u] = load_word(fbase, nword[u] + 1, a.n_words);
-				const uint64_t first_off = nword[u] * 64;
-				nvalid[u] = first_off >= a.search_bits ? 0ULL
-					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+				const uint64_t w = ((uint64_t)ft * KL_WORDS + u) * 256 + tid;
+				nlo[u] = w < a.n_words ? tp[u * 256 + tid] : 0;
+				nhi[u] = w + 1 < a.n_words ? tp[u * 256 + tid + 1] : 0;
 			}
 		}
 	};
 	fetch(t, stream);
 	while (stream < a.n_streams) {
+		// word index and validity of this tile's offsets from the (wave-uniform) tile number: nothing per lane is carried
+		// from the fetch but the words themselves
 		uint64_t word[KL_WORDS];
 		uint32_t d[KL_WORDS][4], m[KL_WORDS][2];
 		uint64_t lo[KL_WORDS], hi[KL_WORDS], valid[KL_WORDS];
 #pragma unroll
 		for (int u = 0; u < KL_WORDS; u++) {
-			word[u] = nword[u];
+			word[u] = ((uint64_t)t * KL_WORDS + u) * 256 + tid;
 			lo[u] = nlo[u];
 			hi[u] = nhi[u];
-			valid[u] = nvalid[u];
+			valid[u] = FULL_MASK;
+			if (t >= a.full_tiles) {
+				const uint64_t first_off = word[u] * 64;
+				valid[u] = first_off >= a.search_bits ? 0ULL
+					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+			}
 		}
 		const uint32_t this_stream = stream;
 		t += gridDim.x;
@@ -1306,6 +1319,13 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 		if (KL_PREFETCH)
 			fetch(t, stream);
+		PROF_MARK(4);
+#ifdef SCAN_PROFILE
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++)
+			asm volatile("" : "+v"(lo[u]), "+v"(hi[u]));        // this tile's words have arrived
+		PROF_MARK(0);
+#endif
 		__builtin_amdgcn_s_setprio(0);                  // bit-sliced filter: lowest (see PRIO_FILTER above)
 #pragma unroll
 		for (int u = 0; u < KL_WORDS; u++) {
@@ -1321,6 +1341,14 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			m[u][0] &= (uint32_t)valid[u];
 			m[u][1] &= (uint32_t)(valid[u] >> 32);
 		}
+#ifdef SCAN_PROFILE
+#pragma unroll
+		for (int u = 0; u < KL_WORDS; u++) {
+			PROF_PIN(m[u][0]);
+			PROF_PIN(m[u][1]);
+		}
+		PROF_MARK(1);
+#endif
 		__builtin_amdgcn_s_setprio(3);                  // survivors, hit staging, flush and the next tile's loads: highest
 		// wave-uniform survivor loop, one offset of every 32-offset half per pass
 		for (;;) {
@@ -1352,13 +1380,19 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 						stage(hit[u][h], this_stream, word[u] * 64 + 32 * h + p[u][h], (uint32_t)e[u][h]);
 			}
 		}
+		PROF_MARK(2);
 		while (q_tail - q_head >= 64)
 			flush(64);
 		if (!KL_PREFETCH)
 			fetch(t, stream);
+		PROF_MARK(3);
 	}
 	if (q_tail != q_head)
 		flush(q_tail - q_head);
+#ifdef SCAN_PROFILE
+	if (lane < 32)
+		atomicAdd(&g_scan_prof[lane], (unsigned long long)kl_prof[tid >> 6][lane]);
+#endif
 }
 
 // ---- symbol <-> packed conversion ---------------------------------------------------------
@@ -1575,6 +1609,17 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 		case 4: hipLaunchKernelGGL(scan_known_lap_kernel<4>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
 		default: hipLaunchKernelGGL(scan_known_lap_kernel<-1>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
 		}
+#ifdef SCAN_PROFILE
+		{
+			unsigned long long prof[32], total = 0;
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_scan_prof), sizeof(prof)));
+			for (int k = 0; k < 32; k++) total += prof[k];
+			fprintf(stderr, "known-LAP profile (%% of wave time; cumulative over launches):");
+			for (int k = 0; k < 5; k++) fprintf(stderr, " %d:%.1f", k, 100.0 * (double)prof[k] / (double)(total ? total : 1));
+			fprintf(stderr, "\n");
+		}
+#endif
 	}
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
