@@ -721,6 +721,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #ifndef SLIDE_MARGIN_4
 #define SLIDE_MARGIN_4 44u
 #endif
+#ifndef SLIDE_SPARSE_TAIL
+#define SLIDE_SPARSE_TAIL 1                // passes behind the fixed ones skip chains that are empty wave-wide
+#endif
 #ifndef SLIDE_DRAIN_AT
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
 #endif
@@ -945,6 +948,46 @@ void scan_slide_kernel(ScanArgs a)
 				any |= m[u][0] | m[u][1];
 			return __ballot(any != 0) != 0;
 		};
+		auto events = [&](const Stage &g, const uint32_t (&bit)[TILES][2]) {   // append the wave's candidates of one pass to its ring
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const bool cand = (bit[u][h] & g.live[u][h] & 1) != 0;
+					const uint64_t cm = __ballot(cand);
+					if (!cm)
+						continue;
+					// ring entries left for this chain; candidates ranked beyond them (a stream made of
+					// sync words: tests/test_gpu_scan.py adversarial cases) go through the exact rule in place
+					const uint32_t room = RING - (q_tail - q_head);
+					const uint32_t n = min((uint32_t)__popcll(cm), room);
+					if (cand) {
+						uint32_t lane6 = lane << 6;
+						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
+						const uint32_t code = ((it + u) << 12) | lane6 | (h << 5) | (g.p[u][h] & 31);
+						const uint32_t wlo = alignbit(d[u][h + 1], d[u][h], g.p[u][h]);
+						const uint32_t whi = alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]);
+						const u32x4 rec = {code, wlo, whi, 0u};
+						if (SLIDE_SINGLE && (cm & (cm - 1)) == 0 && room) {
+							// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
+							lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
+						} else {
+							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
+									__builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0));
+							if (rank < room) {
+								lds_st4(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
+							} else {
+								uint32_t stream, lap, nerr, cold = code;
+								asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
+								const uint64_t word = code_word(cold, stream);
+								if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
+									emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
+							}
+						}
+					}
+					q_tail += n;
+				}
+		};
 		// (Dropping the "this lane has a survivor" bit from the first passes of a trip, where practically every chain has one,
 		// and sorting idle lanes out inside the event instead: 3.59 against 3.53 ms for three such passes, 3.69 for six --
 		// an idle lane whose junk index happens to be in the set triggers an event in EVERY pass.  profiles/r03_ab.)
@@ -968,45 +1011,39 @@ void scan_slide_kernel(ScanArgs a)
 					bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
 					anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 				}
-			if (__ballot(anybit & 1)) {              // some lane of the wave holds a candidate (a third of the passes)
+			if (__ballot(anybit & 1))                // some lane of the wave holds a candidate (half of the passes)
+				events(g, bit);
+		};
+		// Behind the fixed passes a handful of the wave's 2 * TILES * 64 chains still hold survivors (0.8 % have seven or more):
+		// a pass then looks at the chains one by one and skips those that are empty wave-wide (the same ballots are the
+		// loop's exit test), instead of paying the full pass for two or three lanes.
+		auto sparse_tail = [&]() {
+			for (;;) {
+				Stage g;
+				uint32_t anybit = 0, bit[TILES][2];
+				bool any = false;
 #pragma unroll
 				for (int u = 0; u < TILES; u++)
 #pragma unroll
 					for (int h = 0; h < 2; h++) {
-						const bool cand = (bit[u][h] & g.live[u][h] & 1) != 0;
-						const uint64_t cm = __ballot(cand);
-						if (!cm)
+						g.p[u][h] = 0;
+						g.live[u][h] = 0;
+						bit[u][h] = 0;
+						if (!__ballot(m[u][h] != 0))
 							continue;
-						// ring entries left for this chain; candidates ranked beyond them (a stream made of
-						// sync words: tests/test_gpu_scan.py adversarial cases) go through the exact rule in place
-						const uint32_t room = RING - (q_tail - q_head);
-						const uint32_t n = min((uint32_t)__popcll(cm), room);
-						if (cand) {
-							uint32_t lane6 = lane << 6;
-							asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
-							const uint32_t code = ((it + u) << 12) | lane6 | (h << 5) | (g.p[u][h] & 31);
-							const uint32_t wlo = alignbit(d[u][h + 1], d[u][h], g.p[u][h]);
-							const uint32_t whi = alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]);
-							const u32x4 rec = {code, wlo, whi, 0u};
-							if (SLIDE_SINGLE && (cm & (cm - 1)) == 0 && room) {
-								// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
-								lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
-							} else {
-								const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
-										__builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0));
-								if (rank < room) {
-									lds_st4(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
-								} else {
-									uint32_t stream, lap, nerr, cold = code;
-									asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
-									const uint64_t word = code_word(cold, stream);
-									if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
-										emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
-								}
-							}
-						}
-						q_tail += n;
+						any = true;
+						g.p[u][h] = lowest_bit(m[u][h]);
+						g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
+						g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
+						g.live[u][h] = m[u][h] >> g.p[u][h];
+						m[u][h] &= m[u][h] - 1;
+						bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
+						anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 					}
+				if (!any)
+					break;
+				if (__ballot(anybit & 1))
+					events(g, bit);
 			}
 		};
 #ifdef SCAN_PROFILE
@@ -1025,10 +1062,15 @@ void scan_slide_kernel(ScanArgs a)
 				PROF_MARK(pass_no < 13 ? pass_no : 13);
 				pass_no++;
 			}
-			while (any_left()) {
-				pass();
+			if (SLIDE_SPARSE_TAIL) {
+				sparse_tail();
 				PROF_MARK(pass_no < 13 ? pass_no : 13);
-				pass_no++;
+			} else {
+				while (any_left()) {
+					pass();
+					PROF_MARK(pass_no < 13 ? pass_no : 13);
+					pass_no++;
+				}
 			}
 			__builtin_amdgcn_s_setprio(PRIO_CAND);
 			PROF_MARK(16);
