@@ -43,16 +43,24 @@ SEED = 20260926
 STRIDE = 4096
 
 
-def csrc_fingerprint():
+def csrc_fingerprint(csrc_dir=None):
     """sha256 (16 hex digits) over the kernel / library sources the loaded .so is built from (libbtbb_amd/csrc: *.hip,
-    *.cpp, *.h, Makefile, in name order).  profiles/traffic*.json carry the fingerprint of the build their PMC passes
-    measured; a line whose build differs prints traffic: null instead of a number that belongs to another kernel."""
+    *.cpp, *.h, Makefile, in name order) with comments and white space taken out, so that only changes the compiler
+    sees change it.  profiles/traffic*.json carry the fingerprint of the build their PMC passes measured; a line whose
+    build differs prints traffic: null instead of a number that belongs to another kernel."""
     import hashlib
-    d = os.path.join(ROOT, "libbtbb_amd", "csrc")
+    import re
+    d = csrc_dir or os.path.join(ROOT, "libbtbb_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
-            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read())
+            text = open(os.path.join(d, name), "r", errors="replace").read()
+            if name != "Makefile":
+                text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
+                text = re.sub(r"//[^\n]*", " ", text)                       # line comments
+            else:
+                text = re.sub(r"#[^\n]*", " ", text)
+            h.update(name.encode() + b"\0" + " ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

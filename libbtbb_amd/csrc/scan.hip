@@ -5,26 +5,27 @@
 // btbb_find_ac() (:444-464).  Input is the PACKED stream (1 bit per symbol); one
 // lane owns the 64 bit-offsets that start in one 64-bit word.
 //
-// LAP_ANY, per lane and word:
+// LAP_ANY, per lane and word (scan_slide_kernel; tables built for 4 / 5 errors: scan_lap_any_kernel<9> / <8>, which
+// probe two syndrome tables + a bitmap per survivor instead of step 2):
 //   1. bit-sliced barker pre-filter: seven funnel-shifted copies of the stream give the
 //      7-bit window (LAP MSB + 6 barker bits, :378-385) of all 32 offsets of a dword at
 //      once; a carry-save adder counts mismatches against 0x27 and `count in {0,1,6,7}`
 //      is BARKER_DISTANCE[window] <= 1.  1/8 of the offsets survive.
-//   2. per survivor: 64-bit window by two v_alignbit, barker correction + `^ pn`
-//      (:390-393) folded into table constants, low 32 syndrome bits from two
-//      LDS-resident tables (gen_syndrome, :147-159, is GF(2)-linear), then one probe of
-//      an LDS bitmap holding the 18-bit projection of every acceptable syndrome
-//      (the syndrome map of :161-185 and the zero syndrome).  ~0.65 % pass.
-//   3. candidates go to a per-wave LDS ring and are verified 64 at a time with the
+//   2. bit-sliced check stream (slide.h): the (64,30) code is cyclic, so ONE sparse parity check slides over the
+//      window; 19 consecutive bits of the check stream at a survivor's offset are its candidate index -- one
+//      funnel shift and ONE read of a 2^19-bit set in LDS per survivor (the set = every index a window the
+//      reference accepts can have: gen_syndrome :147-159 and the map of :161-185 are linear in the same code).
+//      0.30 % pass.
+//   3. candidates go straight to a per-wave LDS ring and are verified up to 64 at a time with the
 //      exact reference rule: full 34-bit syndrome, open-addressing lookup of the
 //      error pattern, popcount <= max_ac_errors, LAP from the corrected word
-//      (:396-416).  Results are therefore bit-exact, the bitmap only prunes.
-// Known LAP: a bit-sliced mismatch count of the top 12 sync-word bits prunes (1.9 % left for
+//      (:396-416).  Results are therefore bit-exact, the set only prunes.
+// Known LAP: a bit-sliced mismatch count of the top 16 (12 for max_ac_errors < 2) sync-word bits prunes (0.2 % left for
 // max_ac_errors = 2), the survivors get the full popcount(window ^ syncword) of :433.
 //
-// One persistent 1024-thread workgroup per CU (16 wave64) keeps the 88 KiB of tables in
-// LDS; workgroups stride over 64 KiB-bit tiles of the stream(s).  Pure integer work, no
-// MFMA; bound by VALU/LDS issue, not by HBM (see DESIGN.md for the roofline accounting).
+// scan_slide_kernel: two persistent 768-thread workgroups per CU (6 waves per SIMD; 64 KiB set + 12 KiB rings of LDS
+// each) stride over tiles of 768 words; scan_known_lap_kernel: 256-thread workgroups, tiles of 512 words.  Pure integer
+// work, no MFMA; bound by VALU issue, not by HBM (see DESIGN.md 3.1 / 6.3 for the roofline accounting).
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
