@@ -1527,6 +1527,13 @@ __device__ __forceinline__ uint32_t symbols_of_type(uint32_t type)
 	return 366;
 }
 
+#ifdef DH_PROFILE
+__device__ unsigned long long g_dh_prof[8];
+#define DH_MARK(k) do { uint64_t now_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); \
+	__builtin_amdgcn_sched_barrier(0); dh_acc[k] += (uint32_t)(now_ - dh_t); dh_t = now_; } while (0)
+#else
+#define DH_MARK(k) do { } while (0)
+#endif
 #ifndef DH_WAVES_PER_EU
 #define DH_WAVES_PER_EU 6
 #endif
@@ -1542,6 +1549,11 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
 		n_packets = min(n_packets, *d_count);
 	const bool live = pkt < n_packets;
+#ifdef DH_PROFILE
+	uint32_t dh_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint64_t dh_t;
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dh_t) : : "memory");
+#endif
 	btbbx_hit h;
 	h.offset = 0;
 	h.stream = 0;
@@ -1565,6 +1577,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		pi = in[pkt];
 	pi.length = len;
 
+	asm volatile("" : "+v"(pi.clkn), "+v"(len));
+	DH_MARK(0);                                         // hit + btbbx_pkt_in loaded
 	// how much of the packet the decoders can want: the type the header yields under this packet's clock
 	uint32_t want = 0;
 	if (live) {
@@ -1580,6 +1594,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			want = len < bound ? len : bound;
 		}
 	}
+	asm volatile("" : "+v"(want));
+	DH_MARK(1);                                         // header read from the stream, type known
 	uint32_t nw = live ? (s.sh + want + 63) / 64 : 0;              // words of the stream that hold those symbols
 	if (nw > s.wlimit)
 		nw = s.wlimit;
@@ -1617,15 +1633,27 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	}
 	s.staged = nw;
 	s.stage_off = stage_base + 8u * before;
+	DH_MARK(2);                                         // packets staged
 
 	// (Sorting the workgroup's packets by type, so that a wave runs one decoder with all lanes instead of four with a
 	// quarter each, was built and measured: no gain, 365 vs 357 us -- the kernel waits, it does not issue.  What helps
 	// is waves: profiles/r03_chain/pmc_decode_before.json has 80 % of the wave-cycles in s_waitcnt at 16 waves per CU.)
+#ifdef DH_PROFILE
+	if (live)
+		decode_view(s, pi, outs + pkt, mode);
+	DH_MARK(3);                                         // decoded, results stored
+	if (live && lengths)
+		lengths[pkt] = len;
+	if (lane == 0)
+		for (int k = 0; k < 4; k++)
+			atomicAdd(&g_dh_prof[k], (unsigned long long)dh_acc[k]);
+#else
 	if (!live)
 		return;
 	decode_view(s, pi, outs + pkt, mode);
 	if (lengths)
 		lengths[pkt] = len;
+#endif
 }
 
 // 64 symbols, one per byte (bit 0 counts), -> one packed word
@@ -2101,5 +2129,15 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 			   d_words, n_words, pitch_words, d_hits, d_in, cap, d_count, max_length, d_out, d_lengths,
 			   DEC_HEADER | DEC_PAYLOAD);
 	HIP_TRY(hipGetLastError());
+#ifdef DH_PROFILE
+	{
+		unsigned long long prof[8], total = 0;
+		HIP_TRY(hipDeviceSynchronize());
+		HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_dh_prof), sizeof(prof)));
+		for (int k = 0; k < 4; k++) total += prof[k];
+		fprintf(stderr, "decode_hits profile (%% of wave time, cumulative): loads %.1f header %.1f staging %.1f decode %.1f\n",
+			100.0 * prof[0] / total, 100.0 * prof[1] / total, 100.0 * prof[2] / total, 100.0 * prof[3] / total);
+	}
+#endif
 	return BTBBX_OK;
 }
