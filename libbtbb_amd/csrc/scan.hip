@@ -1129,24 +1129,51 @@ void scan_slide_kernel(ScanArgs a)
 
 // ---- known LAP --------------------------------------------------------------------------
 
+// Truth table of a three-input function whose inputs are (compile-time) inverted: index = a*4 + b*2 + c as v_bitop3 wants it.
+// The sync word's top seven bits are the LAP's MSB and the barker code that follows from it (bluetooth_packet.c:81-113), so for
+// a given class the mismatch planes of window bits 57..63 are the stream planes themselves or their complements -- the
+// complement goes into the adders' truth tables instead of costing an XOR per plane (CLS = 0 / 1; -1 = every plane XORed with
+// its run-time flip mask as before).
+constexpr uint32_t tt3(uint32_t base, bool ia, bool ib, bool ic)
+{
+	uint32_t t = 0;
+	for (uint32_t idx = 0; idx < 8; idx++) {
+		const uint32_t a = ((idx >> 2) & 1) ^ (ia ? 1u : 0u), b = ((idx >> 1) & 1) ^ (ib ? 1u : 0u), c = (idx & 1) ^ (ic ? 1u : 0u);
+		t |= ((base >> (a * 4 + b * 2 + c)) & 1) << idx;
+	}
+	return t;
+}
+// sync-word bit 57 + j of class CLS: 0x27 = 0100111b for LAP MSB 1, its complement for 0 (BARKER1 / BARKER0, common.h)
+constexpr bool barker_bit(int cls, int j) { return (((cls ? BARKER1 : BARKER0) >> j) & 1) != 0; }
+// (the truth table of v_bitop3 is an immediate: it has to reach the builtin as a template constant)
+template <uint32_t TT>
+__device__ __forceinline__ uint32_t bitop3_tt(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+
 // bit-sliced "mismatches in sync-word bits 52..63 <= limit" for 32 offsets: twelve planes
 // (window bit 52 + k of offset p is bit p + 20 + k of dh:dm), a carry-save adder tree to a 4-bit
 // count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
 // 79 / 4096 = 1.9 % of the offsets of a random stream.
+template <int CLS>
 __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
 	if (limit >= 12)
 		return 0xffffffffu;
 	uint32_t m[12];
 #pragma unroll
-	for (int k = 0; k < 12; k++)
-		m[k] = alignbit(dh, dm, 20 + k) ^ flip[4 + k];
+	for (int k = 0; k < 12; k++) {                      // plane k = window bit 52 + k; 5 .. 11 are the class bits 57 .. 63
+		m[k] = alignbit(dh, dm, 20 + k);
+		if (CLS < 0 || k < 5)
+			m[k] ^= flip[4 + k];
+	}
+	constexpr bool K = CLS >= 0;
+#define INV(k) (K && barker_bit(CLS, (k) - 5))
 #define FA_SUM(a, b, c) BITOP3((a), (b), (c), 0x96)
 #define FA_CARRY(a, b, c) BITOP3((a), (b), (c), 0xe8)
 	const uint32_t s0 = FA_SUM(m[0], m[1], m[2]), c0 = FA_CARRY(m[0], m[1], m[2]);
-	const uint32_t s1 = FA_SUM(m[3], m[4], m[5]), c1 = FA_CARRY(m[3], m[4], m[5]);
-	const uint32_t s2 = FA_SUM(m[6], m[7], m[8]), c2 = FA_CARRY(m[6], m[7], m[8]);
-	const uint32_t s3 = FA_SUM(m[9], m[10], m[11]), c3 = FA_CARRY(m[9], m[10], m[11]);
+	const uint32_t s1 = bitop3_tt<tt3(0x96, false, false, INV(5))>(m[3], m[4], m[5]), c1 = bitop3_tt<tt3(0xe8, false, false, INV(5))>(m[3], m[4], m[5]);
+	const uint32_t s2 = bitop3_tt<tt3(0x96, INV(6), INV(7), INV(8))>(m[6], m[7], m[8]), c2 = bitop3_tt<tt3(0xe8, INV(6), INV(7), INV(8))>(m[6], m[7], m[8]);
+	const uint32_t s3 = bitop3_tt<tt3(0x96, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]), c3 = bitop3_tt<tt3(0xe8, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]);
+#undef INV
 	const uint32_t o1 = FA_SUM(s0, s1, s2), k0 = FA_CARRY(s0, s1, s2);
 	const uint32_t ones = o1 ^ s3, k1 = o1 & s3;
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);
@@ -1170,24 +1197,31 @@ __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const
 // The same over the top sixteen sync-word bits (48..63): five more adders, but for limit >= 2 it
 // leaves a tenth of the survivors (0.2 % instead of 1.9 % at limit 2), which is worth more than it
 // costs; for limit <= 1 the twelve-plane filter is already sparse enough and cheaper.
+template <int CLS>
 __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
 	if (limit >= 16)
 		return 0xffffffffu;
 	uint32_t m[16];
 #pragma unroll
-	for (int k = 0; k < 16; k++)
-		m[k] = alignbit(dh, dm, 16 + k) ^ flip[k];
+	for (int k = 0; k < 16; k++) {                      // plane k = window bit 48 + k; 9 .. 15 are the class bits 57 .. 63
+		m[k] = alignbit(dh, dm, 16 + k);
+		if (CLS < 0 || k < 9)
+			m[k] ^= flip[k];
+	}
+	constexpr bool K = CLS >= 0;
+#define INV(k) (K && barker_bit(CLS, (k) - 9))
 #define FA_SUM(a, b, c) BITOP3((a), (b), (c), 0x96)
 #define FA_CARRY(a, b, c) BITOP3((a), (b), (c), 0xe8)
 	// weight 1
 	const uint32_t s0 = FA_SUM(m[0], m[1], m[2]), c0 = FA_CARRY(m[0], m[1], m[2]);
 	const uint32_t s1 = FA_SUM(m[3], m[4], m[5]), c1 = FA_CARRY(m[3], m[4], m[5]);
 	const uint32_t s2 = FA_SUM(m[6], m[7], m[8]), c2 = FA_CARRY(m[6], m[7], m[8]);
-	const uint32_t s3 = FA_SUM(m[9], m[10], m[11]), c3 = FA_CARRY(m[9], m[10], m[11]);
-	const uint32_t s4 = FA_SUM(m[12], m[13], m[14]), c4 = FA_CARRY(m[12], m[13], m[14]);
+	const uint32_t s3 = bitop3_tt<tt3(0x96, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]), c3 = bitop3_tt<tt3(0xe8, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]);
+	const uint32_t s4 = bitop3_tt<tt3(0x96, INV(12), INV(13), INV(14))>(m[12], m[13], m[14]), c4 = bitop3_tt<tt3(0xe8, INV(12), INV(13), INV(14))>(m[12], m[13], m[14]);
 	const uint32_t o1 = FA_SUM(s0, s1, s2), k0 = FA_CARRY(s0, s1, s2);
-	const uint32_t o2 = FA_SUM(s3, s4, m[15]), k1 = FA_CARRY(s3, s4, m[15]);
+	const uint32_t o2 = bitop3_tt<tt3(0x96, false, false, INV(15))>(s3, s4, m[15]), k1 = bitop3_tt<tt3(0xe8, false, false, INV(15))>(s3, s4, m[15]);
+#undef INV
 	const uint32_t ones = o1 ^ o2, k2 = o1 & o2;
 	// weight 2: c0..c4, k0, k1, k2
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);
@@ -1227,7 +1261,8 @@ struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per s
 
 // LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
 // and / andn of the count planes; with the limit in a register it is sixteen instructions with SGPR masks), -1 = any
-template <int LIMIT>
+// CLS = bit 23 of the LAP (the barker class of its sync word), -1 = not specialised
+template <int LIMIT, int CLS>
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
 	__shared__ KnownHit ring_mem[4][KRING];
@@ -1375,11 +1410,11 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
 			if (wide) {
-				m[u][0] = top16_filter(d[u][1], d[u][2], flip, limit);
-				m[u][1] = top16_filter(d[u][2], d[u][3], flip, limit);
+				m[u][0] = top16_filter<CLS>(d[u][1], d[u][2], flip, limit);
+				m[u][1] = top16_filter<CLS>(d[u][2], d[u][3], flip, limit);
 			} else {
-				m[u][0] = top12_filter(d[u][1], d[u][2], flip, limit);
-				m[u][1] = top12_filter(d[u][2], d[u][3], flip, limit);
+				m[u][0] = top12_filter<CLS>(d[u][1], d[u][2], flip, limit);
+				m[u][1] = top12_filter<CLS>(d[u][2], d[u][3], flip, limit);
 			}
 			m[u][0] &= (uint32_t)valid[u];
 			m[u][1] &= (uint32_t)(valid[u] >> 32);
@@ -1644,14 +1679,18 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 			set_error("btbbx_scan: stream too long for one launch (split it)");
 			return BTBBX_E_ARG;
 		}
+		const bool cls1 = ((a.syncword >> 57) & 1) != 0;          // = bit 23 of the LAP
+#define LAUNCH_KNOWN(L) do { if (cls1) hipLaunchKernelGGL((scan_known_lap_kernel<L, 1>), dim3((uint32_t)grid), dim3(256), 0, stream, a); \
+		else hipLaunchKernelGGL((scan_known_lap_kernel<L, 0>), dim3((uint32_t)grid), dim3(256), 0, stream, a); } while (0)
 		switch (max_ac_errors) {
-		case 0: hipLaunchKernelGGL(scan_known_lap_kernel<0>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
-		case 1: hipLaunchKernelGGL(scan_known_lap_kernel<1>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
-		case 2: hipLaunchKernelGGL(scan_known_lap_kernel<2>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
-		case 3: hipLaunchKernelGGL(scan_known_lap_kernel<3>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
-		case 4: hipLaunchKernelGGL(scan_known_lap_kernel<4>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
-		default: hipLaunchKernelGGL(scan_known_lap_kernel<-1>, dim3((uint32_t)grid), dim3(256), 0, stream, a); break;
+		case 0: LAUNCH_KNOWN(0); break;
+		case 1: LAUNCH_KNOWN(1); break;
+		case 2: LAUNCH_KNOWN(2); break;
+		case 3: LAUNCH_KNOWN(3); break;
+		case 4: LAUNCH_KNOWN(4); break;
+		default: LAUNCH_KNOWN(-1); break;
 		}
+#undef LAUNCH_KNOWN
 #ifdef SCAN_PROFILE
 		{
 			unsigned long long prof[32], total = 0;
