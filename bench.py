@@ -297,9 +297,9 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
     def chain():
         # scan -> (stream, offset) order -> decode, all queued on one stream: the number of hits never leaves the
         # device (btbbx_order_hits_device and btbbx_decode_hits_counted_device read the scan's counter from HBM)
-        scan()
-        bt.check(lib.btbbx_order_scan_hits_device(hits.data_ptr(), cnt.data_ptr(), cap, nch, nbits, order_scratch.data_ptr(),
-                                                  order_bytes, hs))
+        cnt.zero_()
+        bt.check(lib.btbbx_scan_ordered_device(d3.data_ptr(), wpc, wpc, nch, nbits, lap, 2, hits.data_ptr(), cap, cnt.data_ptr(),
+                                               order_scratch.data_ptr(), order_bytes, hs))
         # pkt_in per packet, on the device: CLK1-6 from the slot number, flags WHITENED | UAP_VALID |
         # CLK6_VALID, the piconet's UAP (the captured length is worked out by the decode call itself);
         # computed for the whole buffer -- entries behind the count are never read

@@ -183,6 +183,12 @@ int btbbx_order_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t
  * pass that looks for the list's largest stream number and offset */
 int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap, uint32_t n_streams,
 				 uint64_t search_bits, void *d_scratch, size_t scratch_bytes, void *hip_stream);
+/* btbbx_scan_device with the list coming back in (stream, offset) order: the scan kernels count every record they write in
+ * the bucket the ordering will put it in, so the list is not read again for a histogram.  Arguments as btbbx_scan_device plus
+ * the ordering scratch (btbbx_order_hits_scratch_bytes(cap)); cap >= 2; nothing is synchronised. */
+int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
+			      uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
+			      uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream);
 
 /* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
  * ceil(n_symbols / 64), the tail of the last word is zero */

@@ -50,6 +50,11 @@ struct ScanArgs {
 	uint32_t hit_cap;
 	uint32_t *hit_count;
 	unsigned long long *first;   // first-match mode (atomicMin target) or nullptr
+	// btbbx_scan_ordered_device: every record written is also counted in the bucket the ordering (sort.hip) will put it in
+	// -- the list then needs no histogram pass -- bucket = (stream * bucket_mul + offset) >> bucket_shift; null = off
+	uint32_t *bucket_cnt;
+	uint64_t bucket_mul;
+	uint32_t bucket_shift;
 	ScanTables t;
 };
 
@@ -75,6 +80,12 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
 	return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+__device__ __forceinline__ void count_bucket(const ScanArgs &a, uint32_t stream, uint64_t offset)
+{
+	if (a.bucket_cnt)
+		atomicAdd(&a.bucket_cnt[((uint64_t)stream * a.bucket_mul + offset) >> a.bucket_shift], 1u);
+}
+
 __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uint64_t offset,
 					 uint32_t lap, uint32_t nerr)
 {
@@ -92,6 +103,7 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uin
 		h.reserved = 0;
 		h.stream = (uint16_t)stream;
 		a.hits[idx] = h;
+		count_bucket(a, stream, offset);
 	}
 }
 
@@ -404,6 +416,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			rec.z = h_lap >> 8;
 			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
 			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+			count_bucket(a, h_hi >> 16, ((uint64_t)(h_hi & 0xffff) << 32) | h_off);
 		}
 		pend = 0;
 	};
@@ -815,6 +828,7 @@ void scan_slide_kernel(ScanArgs a)
 			rec.z = h_lap >> 8;
 			rec.w = (h_lap & 0xff) | (h_hi & 0xffff0000u);
 			reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+			count_bucket(a, h_hi >> 16, ((uint64_t)(h_hi & 0xffff) << 32) | h_off);
 		}
 		pend = 0;
 	};
@@ -1312,6 +1326,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 				h.reserved = 0;
 				h.stream = (uint16_t)(k.stream_err >> 8);
 				a.hits[idx] = h;
+				count_bucket(a, h.stream, h.offset);
 			}
 		}
 		q_head += n;
@@ -1559,10 +1574,11 @@ static int check_scan_args(uint64_t n_words, uint64_t pitch_words, uint32_t n_st
 	return BTBBX_OK;
 }
 
-static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
-		       uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
-		       btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
-		       unsigned long long *d_first, hipStream_t stream)
+int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+		uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
+		btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
+		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt = nullptr, uint64_t bucket_mul = 0,
+		uint32_t bucket_shift = 0)
 {
 	int rc = ctx_require();
 	if (rc)
@@ -1590,6 +1606,9 @@ static int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch
 	a.hit_cap = hit_cap;
 	a.hit_count = d_hit_count;
 	a.first = d_first;
+	a.bucket_cnt = bucket_cnt;
+	a.bucket_mul = bucket_mul;
+	a.bucket_shift = bucket_shift;
 	a.xcd_tiles = 0;
 	a.ring_margin = 4;
 	a.t = c.scan;

@@ -96,20 +96,27 @@ __global__ __launch_bounds__(256) void order_extent_kernel(const btbbx_hit *hits
 	}
 }
 
+// bucket shift for a key space of n_streams x (max_offset + 1) keys and 2^nb_log2 buckets (host and device)
+__host__ __device__ inline uint32_t order_shift(unsigned long long n_streams, unsigned long long mul, uint32_t nb_log2)
+{
+	uint32_t T = 64;
+	const unsigned __int128 total = (unsigned __int128)n_streams * mul;
+	if (!(total >> 64)) {
+		const unsigned long long t = (unsigned long long)total;
+		T = t > 1 ? 64 - __builtin_clzll(t - 1) : 0;
+	}
+	return T > nb_log2 ? T - nb_log2 : 0;
+}
+
 // the caller knows the bounds of the list (stream count and search length of the scan that produced it): one thread
 // writes the parameters the extent pass would have derived
 __global__ void order_bounds_kernel(const uint32_t *d_count, uint32_t n_imm, uint32_t cap, uint32_t nb_log2, uint32_t n_streams,
 				    unsigned long long max_offset, OrderParams *p)
 {
-	const unsigned long long mul = max_offset + 1, ms = n_streams ? n_streams - 1 : 0;
-	uint32_t T = 64;
-	if (__umul64hi(ms + 1, mul) == 0) {
-		const unsigned long long total = (ms + 1) * mul;
-		T = total > 1 ? 64 - __builtin_clzll(total - 1) : 0;
-	}
+	const unsigned long long mul = max_offset + 1;
 	p->mul = mul;
 	p->n = d_count ? min(*d_count, cap) : n_imm;
-	p->shift = T > nb_log2 ? T - nb_log2 : 0;
+	p->shift = order_shift(n_streams ? n_streams : 1, mul, nb_log2);
 }
 
 __global__ __launch_bounds__(256) void order_hist_kernel(const btbbx_hit *hits, const OrderParams *p, uint32_t *cnt)
@@ -202,7 +209,8 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hit
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
 		const btbbx_hit h = hits[i];
 		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
-		const uint32_t pos = start[b] + atomicAdd(&cursor[b], 1u);
+		const uint32_t s0 = start[b], k = start[b + 1] - s0;      // a bucket of one (more than half of the records) needs no cursor
+		const uint32_t pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
 		reinterpret_cast<HitRec *>(grouped)[pos] = *reinterpret_cast<const HitRec *>(&h);
 	}
 }
@@ -374,7 +382,8 @@ extern "C" size_t btbbx_order_hits_scratch_bytes(uint32_t cap)
 }
 
 static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_imm, uint32_t cap, void *d_scratch,
-			size_t scratch_bytes, hipStream_t stream, uint32_t n_streams = 0, uint64_t max_offset = 0)
+			size_t scratch_bytes, hipStream_t stream, uint32_t n_streams = 0, uint64_t max_offset = 0,
+			bool counted_by_scan = false)
 {
 	if (cap < 2)
 		return BTBBX_OK;
@@ -388,15 +397,18 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	uint32_t *start = (uint32_t *)(base + L.start), *cursor = (uint32_t *)(base + L.cursor), *sums = (uint32_t *)(base + L.sums);
 	btbbx_hit *grouped = (btbbx_hit *)(base + L.grouped);
 	const uint32_t nb = 1u << L.nb_log2;
-	// parameters, bucket counters and cursors are contiguous: one memset
-	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
+	// parameters, bucket counters and cursors are contiguous: one memset (done by btbbx_scan_ordered_device BEFORE its scan
+	// when the scan kernel itself counts the buckets)
+	if (!counted_by_scan)
+		HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)cap + 255) / 256, 2048);
 	if (n_streams)
 		hipLaunchKernelGGL(order_bounds_kernel, dim3(1), dim3(1), 0, stream, d_count, n_imm, cap, L.nb_log2, n_streams,
 				   (unsigned long long)max_offset, p);
 	else
 		hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
-	hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
+	if (!counted_by_scan)
+		hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
 	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
 	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
@@ -433,6 +445,38 @@ extern "C" int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d
 		return BTBBX_E_ARG;
 	}
 	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, (hipStream_t)hip_stream, n_streams, search_bits - 1);
+}
+
+// Scan and order in one call: the scan kernels count every record they write in its bucket (one more atomic beside the
+// record, no pass over the list afterwards), then scan of the counts, scatter, rank as above.  The arguments are
+// btbbx_scan_device's plus the ordering scratch; d_hits comes back in (stream, offset) order, *d_count as btbbx_scan_device
+// leaves it.  Nothing is synchronised.
+int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams, uint64_t search_bits,
+		uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
+		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift);
+
+extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
+					 uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
+					 uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream)
+{
+	if (!d_words || !d_hits || !d_count || !n_streams || !search_bits || cap < 2) {
+		set_error("btbbx_scan_ordered_device: bad argument");
+		return BTBBX_E_ARG;
+	}
+	const OrderLayout L = order_layout(cap);
+	if (!d_scratch || scratch_bytes < L.total || ((uintptr_t)d_scratch & 15)) {
+		set_error("btbbx_scan_ordered_device: scratch of %zu bytes (16-byte aligned) needed, %zu given", L.total, scratch_bytes);
+		return BTBBX_E_ARG;
+	}
+	hipStream_t stream = (hipStream_t)hip_stream;
+	char *base = (char *)d_scratch;
+	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
+	const uint32_t shift = order_shift(n_streams, search_bits, L.nb_log2);
+	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, d_hits, cap, d_count, nullptr,
+			     stream, (uint32_t *)(base + L.start), search_bits, shift);
+	if (rc)
+		return rc;
+	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, stream, n_streams, search_bits - 1, true);
 }
 
 // one scratch block per device for the signature without caller scratch

@@ -433,6 +433,44 @@ def test_device_hit_order_with_the_count_in_hbm():
         run(hits(np.arange(n, dtype=np.uint64) * 77, 0), cap=max(n, 4))
 
 
+@pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33, 0x1E8B33])
+def test_scan_ordered_device(lap):
+    """btbbx_scan_ordered_device: one call, the list comes back in (stream, offset) order and equals the oracle's per
+    stream -- LAP_ANY and known LAPs of both barker classes, several streams with a pitch, a hit buffer smaller than the
+    number of matches (the records kept are then some subset, still ordered, and the counter says how many there were)."""
+    lib = bt.lib()
+    kw = dict(stride=512) if lap == bt.LAP_ANY else dict(stride=512, lap=lap)
+    n_streams, nwords, pitch = 5, 3000 + 7, 3100
+    rows, want = [], []
+    for ch in range(n_streams):
+        words, sym, _ = stream(140 + ch, nwords, **kw)
+        rows.append(np.concatenate([words, np.zeros(pitch - nwords, np.uint64)]))
+        n = len(sym) - 63 - 11
+        want += [(ch, o, l, e) for (o, l, e) in _libs.orc_find_all(sym, n, lap if lap != bt.LAP_ANY else _libs.LAP_ANY, 2)]
+    buf = np.concatenate(rows)
+    d_w = bt.DeviceBuffer(buf.nbytes).upload(buf)
+    for cap in (len(want) + 100, len(want) // 3):
+        d_h = bt.DeviceBuffer(cap * 16).zero()
+        d_c = bt.DeviceBuffer(16).zero()
+        sb = lib.btbbx_order_hits_scratch_bytes(cap)
+        d_s = bt.DeviceBuffer(sb)
+        bt.check(lib.btbbx_scan_ordered_device(d_w.ptr, nwords, pitch, n_streams, nwords * 64 - 63 - 11, lap, 2, d_h.ptr, cap, d_c.ptr,
+                                               d_s.ptr, sb, None), "btbbx_scan_ordered_device")
+        bt.check(lib.btbbx_sync(None))
+        cnt = int(d_c.download(np.uint32, 4)[0])
+        got = d_h.download(bt.HIT_DTYPE, cap)[:min(cnt, cap)]
+        for b in (d_h, d_c, d_s):
+            b.free()
+        assert cnt == len(want) > 500
+        tup = [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in got]
+        assert tup == sorted(tup)
+        if cap >= cnt:
+            assert tup == want
+        else:
+            assert len(tup) == cap and set(tup) <= set(want)
+    d_w.free()
+
+
 @pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33])
 def test_sharded_product_scan_equals_single_scan(lap):
     """btbbx_scan_host_multi (the C-ABI form of the N-GPU path): the library's own shard plan --
