@@ -313,6 +313,32 @@ __device__ void chain_lds_init()
 
 // ---- packet state -----------------------------------------------------------------------------
 
+// Where a decoder's payload words go: HBM, or (decode_hits_kernel, small packets) the wave's LDS.  Two address spaces
+// behind one generic pointer would make every access a FLAT instruction, which counts on both vmcnt and lgkmcnt: each
+// table lookup behind a payload store then waits for the store to come back from the memory pipeline.
+struct OutRef {
+	uint64_t *g = nullptr;
+	uint32_t l = 0;          // LDS byte address + 1, or 0
+	__device__ OutRef() {}
+	__device__ OutRef(uint64_t *p) : g(p) {}
+	__device__ __forceinline__ static OutRef lds(uint32_t byte_address) { OutRef r; r.l = byte_address + 1; return r; }
+	__device__ __forceinline__ uint64_t ld(uint32_t k) const
+	{
+		if (l)
+			return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>(l - 1 + 8u * k);
+		return g[k];
+	}
+	__device__ __forceinline__ void st(uint32_t k, uint64_t v) const
+	{
+		if (l)
+			*reinterpret_cast<__attribute__((address_space(3))) uint64_t *>(l - 1 + 8u * k) = v;
+		else
+			g[k] = v;
+	}
+};
+#ifndef DH_CUT
+#define DH_CUT 0
+#endif
 struct PState {
 	const uint64_t *w;       // 50 packed words (a gathered packet), or -- `direct` -- the stream word the packet starts in
 	// direct mode (decode_hits_kernel): the packet is bits [sh, sh + length) of w[0 .. wlimit)
@@ -331,7 +357,7 @@ struct PState {
 	uint32_t ph_written;     // how many payload_header chars were written
 	uint32_t llid, flow;
 	// payload writer
-	uint64_t *out;           // 43 words or nullptr
+	OutRef out;              // 43 words or nothing
 	uint32_t written;        // payload bits written (prefix)
 	// which fields a trial assigned (replay_kernel merges 64 trials by "last writer wins")
 	uint32_t dirty;          // D_* bits
@@ -374,8 +400,8 @@ struct Sink {
 	uint32_t crc;
 	uint64_t oacc = 0;
 	uint32_t onacc = 0, oword = 0;
-	uint64_t *out;
-	__device__ Sink(uint32_t seed, uint64_t *o) : crc(seed), out(o) {}
+	OutRef out;
+	__device__ Sink(uint32_t seed, OutRef o) : crc(seed), out(o) {}
 	__device__ __forceinline__ void push(uint64_t bits, uint32_t n)   // n <= 32
 	{
 		if (n == 32 && nacc == 0) {                                   // whole word on a byte boundary
@@ -393,7 +419,7 @@ struct Sink {
 			oacc |= bits << onacc;
 			onacc += n;
 			if (onacc >= 64) {
-				out[oword++] = oacc;
+				out.st(oword++, oacc);
 				onacc -= 64;
 				oacc = onacc ? bits >> (n - onacc) : 0;
 			}
@@ -404,7 +430,7 @@ struct Sink {
 	{
 		if (WRITE && onacc) {
 			uint64_t keep = ~0ULL << onacc;
-			out[oword] = (out[oword] & keep) | oacc;
+			out.st(oword, (out.ld(oword) & keep) | oacc);
 		}
 	}
 };
@@ -416,20 +442,80 @@ __device__ __forceinline__ uint64_t wh(const PState &s, uint32_t idx, uint32_t n
 	return whitened(s) ? wh_bits(idx, n) : 0ULL;
 }
 
+// Four consecutive (15,10) blocks from symbol `pos` on, their symbols and table reads issued together (a lane that decodes
+// block after block waits for four dependent LDS round trips per block; decode_hits_kernel is bound by exactly those waits).
+// ok bit j = block j decodes; blocks behind `count` are not looked at.
+__device__ __forceinline__ uint32_t fec23_blocks4(const PState &s, uint32_t pos, uint32_t count, uint32_t (&data)[4])
+{
+	uint32_t blk[4], diff[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		blk[j] = (uint32_t)j < count ? (uint32_t)s_bits(s, pos + 15 * j, 15) : 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		data[j] = blk[j] & 0x3ff;
+		diff[j] = (blk[j] >> 10) ^ g_lds.par23[data[j]];
+	}
+	uint32_t ok = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int fix = g_lds.fix23[diff[j] & 31];
+		if (fix >= 0)
+			data[j] ^= 1u << fix;
+		if (fix != -2)
+			ok |= 1u << j;
+	}
+	return ok;
+}
+
 // all FEC-2/3 blocks of `nblocks` decodable?
 __device__ __forceinline__ bool fec23_ok(const PState &s, uint32_t pos, uint32_t nblocks)
 {
-	for (uint32_t k = 0; k < nblocks; k++) {
-		uint32_t d;
-		if (!fec23_block((uint32_t)s_bits(s, pos + 15 * k, 15), d))
+	for (uint32_t k = 0; k < nblocks; k += 4) {
+		uint32_t d[4];
+		const uint32_t cnt = nblocks - k < 4 ? nblocks - k : 4;
+		if ((fec23_blocks4(s, pos + 15 * k, cnt, d) & ((1u << cnt) - 1)) != (1u << cnt) - 1)
 			return false;
 	}
 	return true;
 }
 
 // fhs (:783-818)
+// The same for a caller that only looks at the register at the end (DM): bytes go through the CRC four at a time -- one
+// step of four independent table reads instead of four dependent ones -- and finish() takes the last one to three.
 template <bool WRITE>
-__device__ int do_fhs(PState &s, uint32_t clock)
+struct SinkW : Sink<WRITE> {
+	__device__ SinkW(uint32_t seed, OutRef o) : Sink<WRITE>(seed, o) {}
+	__device__ __forceinline__ void push(uint64_t bits, uint32_t n)   // n <= 32
+	{
+		this->acc |= bits << this->nacc;
+		this->nacc += n;
+		if (this->nacc >= 32) {
+			this->crc = crc_word(this->crc, (uint32_t)this->acc);
+			this->acc >>= 32;
+			this->nacc -= 32;
+		}
+		if (WRITE) {
+			this->oacc |= bits << this->onacc;
+			this->onacc += n;
+			if (this->onacc >= 64) {
+				this->out.st(this->oword++, this->oacc);
+				this->onacc -= 64;
+				this->oacc = this->onacc ? bits >> (n - this->onacc) : 0;
+			}
+		}
+	}
+	__device__ __forceinline__ void finish()
+	{
+		while (this->nacc >= 8) {
+			this->crc = crc_byte(this->crc, (uint32_t)this->acc & 0xff);
+			this->acc >>= 8;
+			this->nacc -= 8;
+		}
+	}
+};
+template <bool WRITE>
+__device__ __forceinline__ int do_fhs(PState &s, uint32_t clock)
 {
 	int size = s.length - 122;
 	s.plen = 20;
@@ -437,14 +523,19 @@ __device__ int do_fhs(PState &s, uint32_t clock)
 	if (size < 240)
 		return 1;
 	uint64_t corr[3] = {0, 0, 0};
-	for (uint32_t k = 0; k < 16; k++) {
-		uint32_t d;
-		if (!fec23_block((uint32_t)s_bits(s, 122 + 15 * k, 15), d))
-			return 0;
-		uint32_t bit = 10 * k;
-		corr[bit >> 6] |= (uint64_t)d << (bit & 63);
-		if ((bit & 63) > 54)
-			corr[(bit >> 6) + 1] |= (uint64_t)d >> (64 - (bit & 63));
+#pragma unroll
+	for (uint32_t k = 0; k < 16; k += 4) {
+		uint32_t d4[4];
+		const uint32_t ok = fec23_blocks4(s, 122 + 15 * k, 4, d4);
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			if (!((ok >> j) & 1))
+				return 0;
+			const uint32_t d = d4[j], bit = 10 * (k + j);
+			corr[bit >> 6] |= (uint64_t)d << (bit & 63);
+			if ((bit & 63) > 54)
+				corr[(bit >> 6) + 1] |= (uint64_t)d >> (64 - (bit & 63));
+		}
 	}
 	int rv = 0;
 	uint32_t c = clock;
@@ -458,13 +549,13 @@ __device__ int do_fhs(PState &s, uint32_t clock)
 			uint32_t n = i < 2 ? 64 : 32;
 			pl[i] = corr[i] ^ wh(s, idx, n);
 			idx = (idx + n) % 127u;
-			for (uint32_t b = 0; b < n; b += 8)
-				crc = crc_byte(crc, (uint32_t)(pl[i] >> b) & 0xff);
+			for (uint32_t b = 0; b < n; b += 32)                  // 20 bytes = five words
+				crc = crc_word(crc, (uint32_t)(pl[i] >> b));
 		}
 		if (WRITE) {
-			s.out[0] = pl[0];
-			s.out[1] = pl[1];
-			s.out[2] = (s.out[2] & ~0xffffffffULL) | pl[2];
+			s.out.st(0, pl[0]);
+			s.out.st(1, pl[1]);
+			s.out.st(2, (s.out.ld(2) & ~0xffffffffULL) | pl[2]);
 			if (s.written < 160) s.written = 160;
 		}
 		if (crc == 0) {
@@ -477,7 +568,7 @@ __device__ int do_fhs(PState &s, uint32_t clock)
 
 // decode_payload_header (:821-895)
 template <bool WRITE>
-__device__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int header_bytes, int size, bool fec)
+__device__ __forceinline__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int header_bytes, int size, bool fec)
 {
 	uint32_t hbits = header_bytes == 2 ? 16 : 8;
 	if (size < (int)hbits)
@@ -521,7 +612,7 @@ __device__ bool do_payload_header(PState &s, uint32_t pos, uint32_t clock, int h
 
 // DM (:898-958)
 template <bool WRITE>
-__device__ int do_DM(PState &s, uint32_t clock)
+__device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 {
 	uint32_t pos = 122;
 	int size = s.length - 122;
@@ -543,18 +634,27 @@ __device__ int do_DM(PState &s, uint32_t clock)
 	uint32_t nblocks = (nbits + 9) / 10;
 	if (WRITE && !fec23_ok(s, pos, nblocks))      // the reference writes nothing on failure
 		return 0;
-	Sink<WRITE> sink(crc_seed(s.uap), s.out);
+	SinkW<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
 	int left = nbits;
-	for (uint32_t k = 0; k < nblocks; k++) {
-		uint32_t d;
-		if (!fec23_block((uint32_t)s_bits(s, pos + 15 * k, 15), d))
-			return 0;
-		uint32_t n = left < 10 ? left : 10;
-		sink.push((d ^ (uint32_t)wh(s, idx, 10)) & ((1u << n) - 1), n);
-		idx = (idx + 10) % 127u;
-		left -= n;
+	for (uint32_t k = 0; k < nblocks; k += 4) {             // four blocks = 40 data bits per step
+		uint32_t d[4];
+		const uint32_t cnt = nblocks - k < 4 ? nblocks - k : 4;
+		const uint32_t ok = fec23_blocks4(s, pos + 15 * k, cnt, d);
+		const uint64_t w40 = wh(s, idx, 40);
+		idx = idx + 40 >= 127 ? idx + 40 - 127 : idx + 40;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			if (j >= cnt)
+				break;
+			if (!((ok >> j) & 1))
+				return 0;
+			const uint32_t n = left < 10 ? left : 10;
+			sink.push((d[j] ^ (uint32_t)(w40 >> (10 * j))) & ((1u << n) - 1), n);
+			left -= n;
+		}
 	}
+	sink.finish();
 	sink.flush();
 	if (WRITE && s.written < (uint32_t)nbits) s.written = nbits;
 	return sink.crc == 0 ? 10 : 2;
@@ -562,7 +662,7 @@ __device__ int do_DM(PState &s, uint32_t clock)
 
 // DH (:962-1011)
 template <bool WRITE>
-__device__ int do_DH(PState &s, uint32_t clock)
+__device__ __forceinline__ int do_DH(PState &s, uint32_t clock)
 {
 	const uint32_t pos = 122;
 	int size = s.length - 122;
@@ -597,7 +697,7 @@ __device__ int do_DH(PState &s, uint32_t clock)
 
 // EV3 (:1013-1042) / EV5 (:1099-1128)
 template <bool WRITE>
-__device__ int do_EV35(PState &s, uint32_t clock, int maxlength)
+__device__ __forceinline__ int do_EV35(PState &s, uint32_t clock, int maxlength)
 {
 	int size = s.length - 122;
 	uint32_t first8 = (uint32_t)s_bits(s, 122, 8);
@@ -629,7 +729,7 @@ __device__ int do_EV35(PState &s, uint32_t clock, int maxlength)
 
 // EV4 (:1044-1097)
 template <bool WRITE>
-__device__ int do_EV4(PState &s, uint32_t clock)
+__device__ __forceinline__ int do_EV4(PState &s, uint32_t clock)
 {
 	int size = s.length - 122;
 	uint32_t crc = crc_seed(s.uap);
@@ -651,7 +751,7 @@ __device__ int do_EV4(PState &s, uint32_t clock)
 			oacc |= ten << onacc;
 			onacc += 10;
 			if (onacc >= 64) {
-				s.out[oword++] = oacc;
+				s.out.st(oword++, oacc);
 				onacc -= 64;
 				oacc = onacc ? ten >> (10 - onacc) : 0;
 			}
@@ -669,7 +769,7 @@ __device__ int do_EV4(PState &s, uint32_t clock)
 	}
 	if (WRITE && onacc) {
 		uint64_t keep = ~0ULL << onacc;
-		s.out[oword] = (s.out[oword] & keep) | oacc;
+		s.out.st(oword, (s.out.ld(oword) & keep) | oacc);
 	}
 	s.plen = L;
 	s.dirty |= D_PLEN;
@@ -678,7 +778,7 @@ __device__ int do_EV4(PState &s, uint32_t clock)
 
 // HV (:1131-1174)
 template <bool WRITE>
-__device__ int do_HV(PState &s, uint32_t clock)
+__device__ __forceinline__ int do_HV(PState &s, uint32_t clock)
 {
 	int size = s.length - 122;
 	s.phl = 0;
@@ -1309,7 +1409,7 @@ __global__ __launch_bounds__(64) void trials_wide_kernel(const uint64_t *packets
 	s.flow = pi.flow;
 	s.plen = 0; s.phl = 0; s.ph16 = 0; s.ph_written = 0; s.dirty = 0; s.ph_mask = 0;
 	s.lt_addr = s.hdr_flags = s.hec = s.header18 = 0;
-	s.out = nullptr;
+	s.out = OutRef();
 	s.written = 0;
 	uint32_t dis;
 	const uint32_t hdr = header_fec13(s.w, dis);
@@ -1376,10 +1476,22 @@ __global__ __launch_bounds__(256) void uap_table_kernel(const uint64_t *packets,
 // (DEC_TRIALS -- leave the packet as a set of try_clock / crc_check calls leaves it -- is
 //  replay_kernel / trials_state_kernel + trials_merge_kernel below)
 
+#ifdef DH_PROFILE
+__device__ unsigned long long g_dh_prof[8];
+#define DH_MARK(k) do { uint64_t now_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); \
+	__builtin_amdgcn_sched_barrier(0); dh_acc[k] += (uint32_t)(now_ - dh_t); dh_t = now_; } while (0)
+#define DH_PARAMS , uint32_t *dh_acc, uint64_t &dh_t
+#define DH_PASS , dh_acc, dh_t
+#else
+#define DH_MARK(k) do { } while (0)
+#define DH_PARAMS
+#define DH_PASS
+#endif
 // header_present + decode_header / decode_payload of one packet (w = its 50 packed words)
 // `s` arrives with its view of the packet set (w, length and, for a packet read straight from the stream, sh /
 // wlimit / direct); everything else of the entry state comes from pi and *o
-__device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode)
+__device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode,
+					    OutRef pay_out, uint64_t *head_out DH_PARAMS)
 {
 
 	s.flags = pi.flags;
@@ -1413,11 +1525,13 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 	s.dirty = 0;
 	s.ph_mask = 0;
 	s.lt_addr = hd.f.lt_addr; s.hdr_flags = hd.f.hdr_flags; s.hec = hd.f.hec; s.header18 = hd.f.header_packed;
-	s.out = o->payload;
+	s.out = (pay_out.l || pay_out.g) ? pay_out : OutRef(o->payload);
 	s.written = 0;
 
 	int header_rv = 0, payload_rv = 0;
+	DH_MARK(3);
 	hd.f.header_present = (uint8_t)do_header_present(s);
+	DH_MARK(4);
 
 	{
 		bool go = true;
@@ -1440,11 +1554,12 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 				}
 			}
 		}
+		DH_MARK(5);
 		if ((mode & DEC_PAYLOAD) && go) {
 			// btbb_decode_payload (:1223-1297)
 			uint32_t clock = pi.clkn;
 			s.phl = 0;
-			switch (s.type) {
+			switch (DH_CUT == 3 ? 0 : s.type) {
 			case 0: case 1: s.plen = 0; payload_rv = 1; break;
 			case 2:  payload_rv = do_fhs<true>(s, clock); break;
 			case 3: case 8: case 10: case 14: payload_rv = do_DM<true>(s, clock); break;
@@ -1461,6 +1576,7 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 			s.flags |= F_HAS_PAYLOAD;
 		}
 	}
+	DH_MARK(6);
 	hd.f.header_rv = header_rv;
 	hd.f.payload_rv = payload_rv;
 	hd.f.payload_length = s.plen;
@@ -1476,7 +1592,7 @@ __device__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o,
 	hd.f.uap = (uint8_t)s.uap;
 	hd.f.payload_header = s.ph16;
 	{
-		uint64_t *dst = reinterpret_cast<uint64_t *>(o);
+		uint64_t *dst = head_out ? head_out : reinterpret_cast<uint64_t *>(o);
 #pragma unroll
 		for (int k = 0; k < 5; k++)
 			dst[k] = hd.q[k];
@@ -1488,7 +1604,11 @@ __device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_
 	PState s;
 	s.w = w;
 	s.length = (int)pi.length;
-	decode_view(s, pi, o, mode);
+#ifdef DH_PROFILE
+	uint32_t dh_acc[8];
+	uint64_t dh_t = 0;
+#endif
+	decode_view(s, pi, o, mode, OutRef(), nullptr DH_PASS);
 }
 
 __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
@@ -1527,13 +1647,54 @@ __device__ __forceinline__ uint32_t symbols_of_type(uint32_t type)
 	return 366;
 }
 
-#ifdef DH_PROFILE
-__device__ unsigned long long g_dh_prof[8];
-#define DH_MARK(k) do { uint64_t now_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); \
-	__builtin_amdgcn_sched_barrier(0); dh_acc[k] += (uint32_t)(now_ - dh_t); dh_t = now_; } while (0)
-#else
-#define DH_MARK(k) do { } while (0)
+#ifndef DH_SORT
+#define DH_SORT 1
 #endif
+// which payload decoder a type runs (decode_view's switch)
+__device__ __forceinline__ uint32_t decoder_of_type(uint32_t type)
+{
+	// 0 none, 1 FHS, 2 DM, 3 DH, 4 HV, 5 EV3 (+ HV), 6 EV4, 7 EV5: a nibble per type
+	return (uint32_t)(0x3276323254432100ULL >> (4 * type)) & 0xf;
+}
+#ifndef DH_OUT_WORDS
+#define DH_OUT_WORDS 3u                      // payload words per lane that leave through LDS
+#endif
+// How many symbols of the packet the payload decoder of `type` will look at under this clock, and whether what it
+// writes fits DH_OUT_WORDS words.  DM / DH / AUX1 / DV carry their length in the payload header (do_payload_header, the
+// decoders' own first step, on a scratch copy of the state): a DM3 with twelve bytes in it is 6 words of stream, not
+// the 26 its type could have -- with the type's bound alone a wave with sixteen DM3 in it ran out of its LDS stage
+// and half its lanes read their packets from HBM word by word.  An estimate that is too small only sends s_bits() to
+// the stream for the rest; it never changes what is read.
+__device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t type, uint32_t clock, bool &small)
+{
+	bool fec = false;
+	int header_bytes = 2;
+	uint32_t pos = 122;
+	switch (type) {
+	case 3:  fec = true; header_bytes = 1; break;
+	case 8:  fec = true; header_bytes = 1; pos = 202; break;
+	case 10: case 14: fec = true; break;
+	case 4: case 9: header_bytes = 1; break;
+	case 11: case 15: break;
+	default: {
+		// payload bits the other single-slot decoders write at most: nothing for NULL / POLL, FHS 160, HV1 80,
+		// HV2 160, HV3 240 (type 7 tries EV3 first: 256); EV4 / EV5 run over several slots
+		const uint32_t bits = (0x85300500u >> (4 * (type & 7)) & 0xf) * 32u;   // (rounded up to 32; types >= 8 never get here as small)
+		small = type < 8 && bits <= 64 * DH_OUT_WORDS;
+		return symbols_of_type(type);
+	}
+	}
+	PState s = s0;
+	s.type = type;
+	s.ph16 = 0; s.ph_mask = 0; s.dirty = 0; s.ph_written = 0;
+	small = true;
+	if (!do_payload_header<false>(s, pos, clock, header_bytes, s.length - (int)pos, fec))
+		return pos + 30;
+	const uint32_t nbits = (uint32_t)s.plen * 8;
+	small = nbits <= 64 * DH_OUT_WORDS;
+	return pos + (fec ? 15 * ((nbits + 9) / 10) : nbits);
+}
+
 #ifndef DH_WAVES_PER_EU
 #define DH_WAVES_PER_EU 6
 #endif
@@ -1544,11 +1705,15 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 							  uint32_t *lengths, uint32_t mode)
 {
 	__shared__ uint64_t stage[4][DH_STAGE_WORDS];
+	__shared__ uint64_t ostage[4][64 * DH_OUT_WORDS];
 	chain_lds_init();
-	const uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t pkt = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
 		n_packets = min(n_packets, *d_count);
-	const bool live = pkt < n_packets;
+	bool live = pkt < n_packets;
+	if (blockIdx.x * blockDim.x >= n_packets)
+		return;
 #ifdef DH_PROFILE
 	uint32_t dh_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t dh_t;
@@ -1580,7 +1745,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	asm volatile("" : "+v"(pi.clkn), "+v"(len));
 	DH_MARK(0);                                         // hit + btbbx_pkt_in loaded
 	// how much of the packet the decoders can want: the type the header yields under this packet's clock
-	uint32_t want = 0;
+	uint32_t want = 0, dtype = 0;
+	bool small = false;                                 // a single-slot type: its payload fits DH_OUT_WORDS words
 	if (live) {
 		want = len < 126 ? len : 126;
 		if ((mode & DEC_PAYLOAD) && len > 126) {
@@ -1590,12 +1756,81 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			uint32_t type = pi.type;
 			if (mode & DEC_HEADER)
 				type = ((hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18)) >> 3) & 0xf;
-			const uint32_t bound = symbols_of_type(type);
+			const uint32_t bound = payload_extent(s, type, pi.clkn, small);
 			want = len < bound ? len : bound;
+			dtype = type;
 		}
 	}
 	asm volatile("" : "+v"(want));
+	if (live && lengths)
+		lengths[pkt] = len;
+#if DH_SORT
+	// The workgroup's 256 packets change hands so that a wave decodes packets of one kind and about one length: a wave
+	// with DM, DH and FHS packets in it runs the three decoders one after the other with a third of its lanes each,
+	// and a loop over FEC blocks runs as long as its longest packet.  (With the stores, the staging and the exact
+	// extents fixed the kernel issues vector instructions 68 % of the time, profiles/r03_chain/pmc_decode_after.json;
+	// while it sat in s_waitcnt the same sort gained nothing.)  Counting sort on (decoder, symbols wanted); what a
+	// thread knows about its packet goes to the thread that takes it over through the input stage, which is still empty.
+	{
+		__shared__ uint32_t sort_cnt[64];
+		__shared__ uint8_t perm[256];
+		uint64_t *const xch = &stage[0][0];
+		const uint32_t tid = threadIdx.x;
+		if (tid < 64)
+			sort_cnt[tid] = 0;
+		__syncthreads();
+		uint32_t key = 63;
+		if (live) {
+			const uint32_t cls = want <= 126 ? 0 : decoder_of_type(dtype);
+			const uint32_t lb = want <= 126 ? 0 : (want - 122) >> 5;
+			key = cls * 8 + (lb < 7 ? lb : 7);
+		}
+		const uint32_t r = atomicAdd(&sort_cnt[key], 1u);
+		xch[tid] = h.offset;
+		xch[256 + tid] = (uint64_t)h.stream | (uint64_t)want << 16 | (uint64_t)small << 30 | (uint64_t)live << 31 | (uint64_t)pi.clkn << 32;
+		xch[512 + tid] = (uint64_t)pi.flags | (uint64_t)pi.uap << 32 | (uint64_t)pi.type << 40 | (uint64_t)pi.llid << 48 | (uint64_t)pi.flow << 56;
+		__syncthreads();
+		uint32_t c = sort_cnt[lane], incl = c;
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t u = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d)
+				incl += u;
+		}
+		perm[__shfl(incl - c, key) + r] = (uint8_t)tid;
+		__syncthreads();
+		const uint32_t q = perm[tid];
+		const uint64_t x0 = xch[q], x1 = xch[256 + q], x2 = xch[512 + q];
+		__syncthreads();                                // the stage is free again
+		pkt = blockIdx.x * blockDim.x + q;
+		h.offset = x0;
+		h.stream = (uint16_t)x1;
+		want = (uint32_t)(x1 >> 16) & 0x3fff;
+		small = (x1 >> 30) & 1;
+		live = (x1 >> 31) & 1;
+		pi.clkn = (uint32_t)(x1 >> 32);
+		pi.flags = (uint32_t)x2;
+		pi.uap = (uint8_t)(x2 >> 32); pi.type = (uint8_t)(x2 >> 40); pi.llid = (uint8_t)(x2 >> 48); pi.flow = (uint8_t)(x2 >> 56);
+		const uint64_t avail2 = h.offset < total_bits ? total_bits - h.offset : 0;
+		len = avail2 < max_length ? (uint32_t)avail2 : max_length;
+		if (len > BTBBX_MAX_SYMBOLS)
+			len = BTBBX_MAX_SYMBOLS;
+		const uint64_t fw = h.offset >> 6;
+		s.w = words + (uint64_t)h.stream * pitch_words + fw;
+		s.sh = (uint32_t)(h.offset & 63);
+		s.wlimit = fw < n_words ? (uint32_t)(n_words - fw < 64 ? n_words - fw : 64) : 0;
+		s.length = live ? (int)len : 0;
+		pi.length = len;
+	}
+#endif
 	DH_MARK(1);                                         // header read from the stream, type known
+	if (DH_CUT == 1) { if (live) outs[pkt].payload[0] = (uint64_t)want + s.sh + pi.clkn + len; return; }
+	// Results leave through LDS.  A lane storing its own packet's words touches 64 different sectors per
+	// instruction and every one of them costs the memory system a whole sector: nine such stores per packet (five
+	// words of head, about four of payload) were 100 of the kernel's 290 us.  The payload words of a single-slot
+	// packet (<= 256 bits: FHS 160, DM1 / DH1 / AUX1 / DV <= 240, HV 240, EV3 256) are collected in ostage, the head
+	// in the input stage once every lane is done reading it, and the wave stores head + payload of packet after
+	// packet as consecutive words.  ostage starts from what the record holds, so bits the decoders leave alone stay.
+	const uint64_t small_mask = __ballot(small), live_mask = __ballot(live);
 	uint32_t nw = live ? (s.sh + want + 63) / 64 : 0;              // words of the stream that hold those symbols
 	if (nw > s.wlimit)
 		nw = s.wlimit;
@@ -1611,48 +1846,80 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		nw = 0;
 	typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 	const uint32_t stage_base = (uint32_t)(uintptr_t)(lds_u64_t *)(&stage[wave][0]);
-	// packet j of the wave: its words, one per lane.  Sixteen packets' loads are issued before the first of them is
-	// written to LDS: one packet at a time the wave sat out 64 HBM latencies in a row (67 us of wave life time, 80 %
-	// of it in s_waitcnt, profiles/r03_chain/pmc_decode_before.json).
-	for (uint32_t j0 = 0; j0 < 64; j0 += 16) {
-		uint64_t val[16];
-		uint32_t cnt[16], dst[16];
+	// The words go from HBM to LDS without passing through registers (global_load_lds_dword: the wave's LDS base is
+	// uniform, lane i fills dword i): packet j of the wave is one instruction -- lanes below twice its word count --
+	// and all 64 packets' loads are in flight together, one HBM latency per wave.  (Round 3 first staged one packet at
+	// a time through registers -- the wave sat out 64 latencies in a row, 80 % of its life in s_waitcnt,
+	// profiles/r03_chain/pmc_decode_before.json -- then sixteen at a time, which cost 48 registers.)
+	typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+	typedef __attribute__((address_space(1))) const uint32_t glb_u32_t;
+	{
+		// what the records hold in the payload words the small packets will leave through ostage
+		lds_u32_t *const obase = (lds_u32_t *)(lds_u64_t *)(&ostage[wave][0]);
 #pragma unroll
-		for (int k = 0; k < 16; k++) {
-			cnt[k] = __shfl(nw, j0 + k);
-			dst[k] = __shfl(before, j0 + k);
-			const uint64_t src = __shfl((uint64_t)(uintptr_t)s.w, j0 + k);
-			val[k] = 0;
-			if (lane < cnt[k])
-				val[k] = reinterpret_cast<const uint64_t *>((uintptr_t)src)[lane];
+		for (uint32_t t = 0; t < 2 * DH_OUT_WORDS; t++) {
+			const uint32_t f = t * 64 + lane, p = f / (2 * DH_OUT_WORDS), k = f % (2 * DH_OUT_WORDS);
+			const uint32_t pkt_p = __shfl(pkt, p);
+			if ((small_mask >> p) & 1)
+				__builtin_amdgcn_global_load_lds((glb_u32_t *)(uintptr_t)(reinterpret_cast<const uint32_t *>(outs + pkt_p) + 10 + k),
+								 obase + t * 64, 4, 0, 0);
 		}
-#pragma unroll
-		for (int k = 0; k < 16; k++)
-			if (lane < cnt[k])
-				stage[wave][dst[k] + lane] = val[k];
 	}
+	{
+		// The staged packets lie back to back in the wave's stage, so the stage is one run of dwords and instruction
+		// i fills dwords 64 i .. 64 i + 63 of it, whichever packets they belong to: every packet first writes its lane
+		// number into the slots it will get, the lane that loads dword D reads the owner from there and takes the
+		// owner's stream address.  (One instruction per packet was 64 rounds of readlanes and compares: 820 of the
+		// kernel's 2 700 vector instructions per wave.)
+		lds_u32_t *const sbase = (lds_u32_t *)(lds_u64_t *)(&stage[wave][0]);
+		const uint64_t staged_mask = __ballot(nw > 0);
+		const uint32_t last = staged_mask ? 63u - (uint32_t)__builtin_clzll(staged_mask) : 0u;
+		const uint32_t total2 = staged_mask ? 2u * (uint32_t)__builtin_amdgcn_readlane(before + nw, last) : 0u;
+		for (uint32_t k = 0; __ballot(k < nw); k++)
+			if (k < nw)
+				sbase[2 * (before + k)] = lane;
+		const uint64_t adj = (uint64_t)(uintptr_t)s.w - 8ull * before;        // dword D of the stage is at adj + 4 D
+		for (uint32_t d0 = 0; d0 < total2; d0 += 64) {
+			const uint32_t d = d0 + lane;
+			const uint32_t owner = d < total2 ? sbase[d & ~1u] : 0u;
+			const uint64_t a = __shfl(adj, owner) + 4ull * d;            // (every lane takes part in the shuffle)
+			if (d < total2)
+				__builtin_amdgcn_global_load_lds((glb_u32_t *)(uintptr_t)a, sbase + d0, 4, 0, 0);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+	__builtin_amdgcn_wave_barrier();
 	s.staged = nw;
 	s.stage_off = stage_base + 8u * before;
 	DH_MARK(2);                                         // packets staged
+	if (DH_CUT == 2) { if (live) outs[pkt].payload[0] = s_bits(s, 0, 64) + want + pi.clkn; return; }
 
-	// (Sorting the workgroup's packets by type, so that a wave runs one decoder with all lanes instead of four with a
-	// quarter each, was built and measured: no gain, 365 vs 357 us -- the kernel waits, it does not issue.  What helps
-	// is waves: profiles/r03_chain/pmc_decode_before.json has 80 % of the wave-cycles in s_waitcnt at 16 waves per CU.)
-#ifdef DH_PROFILE
+	uint64_t head[5] = {0, 0, 0, 0, 0};
 	if (live)
-		decode_view(s, pi, outs + pkt, mode);
-	DH_MARK(3);                                         // decoded, results stored
-	if (live && lengths)
-		lengths[pkt] = len;
+		decode_view(s, pi, outs + pkt, mode,
+			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head DH_PASS);
+	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
+#pragma unroll
+	for (int k = 0; k < 5; k++)
+		stage[wave][lane * 5 + k] = head[k];
+	__builtin_amdgcn_wave_barrier();
+#pragma unroll
+	for (uint32_t t = 0; t < 5 + DH_OUT_WORDS; t++) {
+		const uint32_t f = t * 64 + lane, p = f / (5 + DH_OUT_WORDS), k = f % (5 + DH_OUT_WORDS);
+		const uint32_t pkt_p = __shfl(pkt, p);
+		if ((live_mask >> p) & 1) {
+			uint64_t *dst = reinterpret_cast<uint64_t *>(outs + pkt_p);
+			if (k < 5)
+				dst[k] = stage[wave][p * 5 + k];
+			else if ((small_mask >> p) & 1)
+				dst[k] = ostage[wave][p * DH_OUT_WORDS + k - 5];
+		}
+	}
+	DH_MARK(7);                                         // decoded, results stored
+#ifdef DH_PROFILE
 	if (lane == 0)
-		for (int k = 0; k < 4; k++)
+		for (int k = 0; k < 8; k++)
 			atomicAdd(&g_dh_prof[k], (unsigned long long)dh_acc[k]);
-#else
-	if (!live)
-		return;
-	decode_view(s, pi, outs + pkt, mode);
-	if (lengths)
-		lengths[pkt] = len;
 #endif
 }
 
@@ -2134,9 +2401,13 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 		unsigned long long prof[8], total = 0;
 		HIP_TRY(hipDeviceSynchronize());
 		HIP_TRY(hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_dh_prof), sizeof(prof)));
-		for (int k = 0; k < 4; k++) total += prof[k];
-		fprintf(stderr, "decode_hits profile (%% of wave time, cumulative): loads %.1f header %.1f staging %.1f decode %.1f\n",
-			100.0 * prof[0] / total, 100.0 * prof[1] / total, 100.0 * prof[2] / total, 100.0 * prof[3] / total);
+		for (int k = 0; k < 8; k++) total += prof[k];
+		fprintf(stderr, "decode_hits profile (%% of wave time): loads %.1f type %.1f staging %.1f head-load %.1f present %.1f header %.1f payload %.1f store %.1f; s_memtime ticks per wave %.0f\n",
+			100.0 * prof[0] / total, 100.0 * prof[1] / total, 100.0 * prof[2] / total, 100.0 * prof[3] / total,
+			100.0 * prof[4] / total, 100.0 * prof[5] / total, 100.0 * prof[6] / total, 100.0 * prof[7] / total,
+			(double)total / ((cap + 63) / 64));
+		unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dh_prof), zero, sizeof(zero)));
 	}
 #endif
 	return BTBBX_OK;
