@@ -281,10 +281,14 @@ __device__ __forceinline__ uint32_t fec13(uint64_t v, uint32_t n, uint32_t &disa
 		dis &= keep;
 	}
 	disagree = __popcll(dis);
-	uint32_t out = 0;
-	for (uint32_t i = 0; i < n; i++)
-		out |= (uint32_t)((maj >> (3 * i)) & 1) << i;
-	return out;
+	// bit 3 i -> bit i: pairs, nibbles, bytes, ... close ranks (five shift / or / and steps instead of n)
+	uint64_t x = maj;
+	x = (x | x >> 2) & 0x30c30c30c30c30c3ULL;
+	x = (x | x >> 4) & 0xf00f00f00f00f00fULL;
+	x = (x | x >> 8) & 0x00ff0000ff0000ffULL;
+	x = (x | x >> 16) & 0xffff00000000ffffULL;
+	x = (x | x >> 32) & 0xffffffffULL;
+	return (uint32_t)x;
 }
 
 // one (15,10) block: 15 symbols in -> 10 corrected data bits, false if uncorrectable (:602-646)
@@ -347,6 +351,9 @@ struct PState {
 	uint32_t staged = 0;     // direct mode: w[0 .. staged) have a copy in LDS at LDS byte address `stage_off`
 	uint32_t stage_off = 0;
 	bool direct = false;
+	// the FEC 1/3 decoded header and its disagreeing triples, when the caller has them already (decode_hits_kernel)
+	bool has_pre = false;
+	uint32_t pre_hdr = 0, pre_dis = 0;
 	int length;              // pkt->length
 	uint32_t flags;
 	uint32_t uap, type;
@@ -358,6 +365,7 @@ struct PState {
 	uint32_t llid, flow;
 	// payload writer
 	OutRef out;              // 43 words or nothing
+	bool spoiled = false;    // out is the caller's scratch copy (LDS) and holds a payload the reference would not have written
 	uint32_t written;        // payload bits written (prefix)
 	// which fields a trial assigned (replay_kernel merges 64 trials by "last writer wins")
 	uint32_t dirty;          // D_* bits
@@ -448,9 +456,10 @@ __device__ __forceinline__ uint64_t wh(const PState &s, uint32_t idx, uint32_t n
 __device__ __forceinline__ uint32_t fec23_blocks4(const PState &s, uint32_t pos, uint32_t count, uint32_t (&data)[4])
 {
 	uint32_t blk[4], diff[4];
+	const uint64_t sym60 = s_bits(s, pos, 60);             // (symbols behind `length` read as 0 either way)
 #pragma unroll
 	for (int j = 0; j < 4; j++)
-		blk[j] = (uint32_t)j < count ? (uint32_t)s_bits(s, pos + 15 * j, 15) : 0;
+		blk[j] = (uint32_t)j < count ? (uint32_t)(sym60 >> (15 * j)) & 0x7fff : 0;
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		data[j] = blk[j] & 0x3ff;
@@ -632,7 +641,9 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 	if (nbits > size)
 		return 1;
 	uint32_t nblocks = (nbits + 9) / 10;
-	if (WRITE && !fec23_ok(s, pos, nblocks))      // the reference writes nothing on failure
+	// The reference writes nothing when a block fails.  Into HBM that takes a pass over all blocks first; a scratch copy
+	// is written as the blocks decode and marked as not to be kept when one fails.
+	if (WRITE && !s.out.l && !fec23_ok(s, pos, nblocks))
 		return 0;
 	SinkW<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
@@ -647,8 +658,11 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 		for (uint32_t j = 0; j < 4; j++) {
 			if (j >= cnt)
 				break;
-			if (!((ok >> j) & 1))
+			if (!((ok >> j) & 1)) {
+				if (WRITE)
+					s.spoiled = true;
 				return 0;
+			}
 			const uint32_t n = left < 10 ? left : 10;
 			sink.push((d[j] ^ (uint32_t)(w40 >> (10 * j))) & ((1u << n) - 1), n);
 			left -= n;
@@ -889,16 +903,23 @@ __device__ __forceinline__ uint32_t do_try_clock(PState &s, uint32_t clock, uint
 }
 
 // btbb_header_present (:1371-1408)
-__device__ __forceinline__ int do_header_present(const PState &s)
+// (dis: the disagreeing triples of the header, header_fec13)
+__device__ __forceinline__ int do_header_present(const PState &s, uint32_t dis)
 {
 	if (s.length < 122)
 		return 0;
-	uint32_t msb = (uint32_t)s_bits(s, 63, 1);
-	uint32_t tr = (uint32_t)s_bits(s, 64, 4);
+	const uint32_t five = (uint32_t)s_bits(s, 63, 5);
+	uint32_t msb = five & 1;
+	uint32_t tr = five >> 1;
 	uint32_t want = msb ? 0xAu : 0x5u;          // !m, m, !m, m  (LSB first)
-	uint32_t errs = __popc(tr ^ want), dis;
-	(void)fec13(s_bits(s, 68, 54), 18, dis);
+	uint32_t errs = __popc(tr ^ want);
 	return (errs + dis) < 5;
+}
+__device__ __forceinline__ int do_header_present(const PState &s)
+{
+	uint32_t dis;
+	(void)fec13(s_bits(s, 68, 54), 18, dis);
+	return do_header_present(s, dis);
 }
 
 // ---- kernels --------------------------------------------------------------------------------
@@ -1530,15 +1551,21 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 
 	int header_rv = 0, payload_rv = 0;
 	DH_MARK(3);
-	hd.f.header_present = (uint8_t)do_header_present(s);
+	uint32_t hraw, hdis;
+	if (s.has_pre) {
+		hraw = s.pre_hdr;
+		hdis = s.pre_dis;
+	} else {
+		hraw = header_fec13(s, hdis);
+	}
+	hd.f.header_present = (uint8_t)do_header_present(s, hdis);
 	DH_MARK(4);
 
 	{
 		bool go = true;
 		if (mode & DEC_HEADER) {
 			// btbb_decode_header (:1198-1221)
-			uint32_t dis;
-			uint32_t hdr = header_fec13(s, dis);
+			const uint32_t dis = hdis, hdr = hraw;
 			go = false;
 			if ((s.flags & F_CLK6_VALID) && dis < 4) {
 				uint32_t clear = hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18);
@@ -1747,12 +1774,12 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	// how much of the packet the decoders can want: the type the header yields under this packet's clock
 	uint32_t want = 0, dtype = 0;
 	bool small = false;                                 // a single-slot type: its payload fits DH_OUT_WORDS words
+	uint32_t hdr = 0, dis = 0;
 	if (live) {
 		want = len < 126 ? len : 126;
+		s.flags = pi.flags;
+		hdr = header_fec13(s, dis);
 		if ((mode & DEC_PAYLOAD) && len > 126) {
-			s.flags = pi.flags;
-			uint32_t dis;
-			const uint32_t hdr = header_fec13(s, dis);
 			uint32_t type = pi.type;
 			if (mode & DEC_HEADER)
 				type = ((hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18)) >> 3) & 0xf;
@@ -1789,6 +1816,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		xch[tid] = h.offset;
 		xch[256 + tid] = (uint64_t)h.stream | (uint64_t)want << 16 | (uint64_t)small << 30 | (uint64_t)live << 31 | (uint64_t)pi.clkn << 32;
 		xch[512 + tid] = (uint64_t)pi.flags | (uint64_t)pi.uap << 32 | (uint64_t)pi.type << 40 | (uint64_t)pi.llid << 48 | (uint64_t)pi.flow << 56;
+		xch[768 + tid] = (uint64_t)hdr | (uint64_t)dis << 32;
 		__syncthreads();
 		uint32_t c = sort_cnt[lane], incl = c;
 		for (int d = 1; d < 64; d <<= 1) {
@@ -1799,7 +1827,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		perm[__shfl(incl - c, key) + r] = (uint8_t)tid;
 		__syncthreads();
 		const uint32_t q = perm[tid];
-		const uint64_t x0 = xch[q], x1 = xch[256 + q], x2 = xch[512 + q];
+		const uint64_t x0 = xch[q], x1 = xch[256 + q], x2 = xch[512 + q], x3 = xch[768 + q];
 		__syncthreads();                                // the stage is free again
 		pkt = blockIdx.x * blockDim.x + q;
 		h.offset = x0;
@@ -1820,8 +1848,13 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		s.wlimit = fw < n_words ? (uint32_t)(n_words - fw < 64 ? n_words - fw : 64) : 0;
 		s.length = live ? (int)len : 0;
 		pi.length = len;
+		hdr = (uint32_t)x3;
+		dis = (uint32_t)(x3 >> 32);
 	}
 #endif
+	s.has_pre = true;
+	s.pre_hdr = hdr;
+	s.pre_dis = dis;
 	DH_MARK(1);                                         // header read from the stream, type known
 	if (DH_CUT == 1) { if (live) outs[pkt].payload[0] = (uint64_t)want + s.sh + pi.clkn + len; return; }
 	// Results leave through LDS.  A lane storing its own packet's words touches 64 different sectors per
@@ -1899,6 +1932,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		decode_view(s, pi, outs + pkt, mode,
 			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head DH_PASS);
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
+	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
 	for (int k = 0; k < 5; k++)
 		stage[wave][lane * 5 + k] = head[k];
@@ -1911,7 +1945,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			uint64_t *dst = reinterpret_cast<uint64_t *>(outs + pkt_p);
 			if (k < 5)
 				dst[k] = stage[wave][p * 5 + k];
-			else if ((small_mask >> p) & 1)
+			else if ((keep_mask >> p) & 1)
 				dst[k] = ostage[wave][p * DH_OUT_WORDS + k - 5];
 		}
 	}
