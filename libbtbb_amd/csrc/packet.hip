@@ -1512,7 +1512,7 @@ __device__ unsigned long long g_dh_prof[8];
 // `s` arrives with its view of the packet set (w, length and, for a packet read straight from the stream, sh /
 // wlimit / direct); everything else of the entry state comes from pi and *o
 __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, btbbx_pkt_out *o, uint32_t mode,
-					    OutRef pay_out, uint64_t *head_out DH_PARAMS)
+					    OutRef pay_out, uint64_t *head_out, const uint64_t *head_in DH_PARAMS)
 {
 
 	s.flags = pi.flags;
@@ -1534,7 +1534,7 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 		} f;
 	} hd;
 	{
-		const uint64_t *src = reinterpret_cast<const uint64_t *>(o);
+		const uint64_t *src = head_in ? head_in : reinterpret_cast<const uint64_t *>(o);
 #pragma unroll
 		for (int k = 0; k < 5; k++)
 			hd.q[k] = src[k];
@@ -1635,7 +1635,7 @@ __device__ void decode_one(const uint64_t *w, const btbbx_pkt_in &pi, btbbx_pkt_
 	uint32_t dh_acc[8];
 	uint64_t dh_t = 0;
 #endif
-	decode_view(s, pi, o, mode, OutRef(), nullptr DH_PASS);
+	decode_view(s, pi, o, mode, OutRef(), nullptr, nullptr DH_PASS);
 }
 
 __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
@@ -1775,6 +1775,20 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	uint32_t want = 0, dtype = 0;
 	bool small = false;                                 // a single-slot type: its payload fits DH_OUT_WORDS words
 	uint32_t hdr = 0, dis = 0;
+	typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+	{
+		// the header and the payload header (symbols 68 .. 232 of the packet) are in its words 1 .. 4: four loads in
+		// flight together, parked in the input stage, instead of one s_bits() after the other going to the stream
+		uint64_t hw[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++)
+			hw[k] = live && k + 1 < s.wlimit ? s.w[k + 1] : 0ULL;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++)
+			stage[wave][lane * 5 + k + 1] = hw[k];
+		s.staged = s.wlimit < 5 ? s.wlimit : 5;
+		s.stage_off = (uint32_t)(uintptr_t)(lds_u64_t *)(&stage[wave][lane * 5]);
+	}
 	if (live) {
 		want = len < 126 ? len : 126;
 		s.flags = pi.flags;
@@ -1789,6 +1803,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 	}
 	asm volatile("" : "+v"(want));
+	s.staged = 0;
 	if (live && lengths)
 		lengths[pkt] = len;
 #if DH_SORT
@@ -1864,6 +1879,13 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	// in the input stage once every lane is done reading it, and the wave stores head + payload of packet after
 	// packet as consecutive words.  ostage starts from what the record holds, so bits the decoders leave alone stay.
 	const uint64_t small_mask = __ballot(small), live_mask = __ballot(live);
+	// the record's head (entry state of the decoders): on its way while the packets are staged
+	uint64_t head_in[5] = {0, 0, 0, 0, 0};
+	if (live) {
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			head_in[k] = reinterpret_cast<const uint64_t *>(outs + pkt)[k];
+	}
 	uint32_t nw = live ? (s.sh + want + 63) / 64 : 0;              // words of the stream that hold those symbols
 	if (nw > s.wlimit)
 		nw = s.wlimit;
@@ -1877,7 +1899,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	before -= nw;
 	if (before + nw > DH_STAGE_WORDS)
 		nw = 0;
-	typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 	const uint32_t stage_base = (uint32_t)(uintptr_t)(lds_u64_t *)(&stage[wave][0]);
 	// The words go from HBM to LDS without passing through registers (global_load_lds_dword: the wave's LDS base is
 	// uniform, lane i fills dword i): packet j of the wave is one instruction -- lanes below twice its word count --
@@ -1930,7 +1951,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	uint64_t head[5] = {0, 0, 0, 0, 0};
 	if (live)
 		decode_view(s, pi, outs + pkt, mode,
-			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head DH_PASS);
+			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head, head_in DH_PASS);
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
 	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
