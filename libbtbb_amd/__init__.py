@@ -394,16 +394,19 @@ def run_decode(packet_words, pkt_in):
     return d_out.download(PKTOUT_DTYPE, n)
 
 
-def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gather=False):
+def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gather=False, init_out=None):
     """Decode the packets that start at `hits` (HIT_DTYPE: stream, offset) of the packed streams
     stream_words[n_streams, n_words] -> (PKTOUT_DTYPE array, captured lengths).  via_gather=True takes
-    the two-step route (btbbx_gather_packets_device + btbbx_decode_device) for comparison."""
+    the two-step route (btbbx_gather_packets_device + btbbx_decode_device) for comparison.  init_out: what the
+    records hold on entry (a PKTOUT_DTYPE array; zeros if None) -- the decoders leave alone what they do not assign."""
     stream_words = np.ascontiguousarray(stream_words, dtype=np.uint64)
     n_streams, n_words = stream_words.shape
     n = len(hits)
     d_w = DeviceBuffer(stream_words.nbytes).upload(stream_words)
     d_h = DeviceBuffer(max(hits.nbytes, 16)).upload(hits)
     d_out = DeviceBuffer(n * PKTOUT_DTYPE.itemsize).zero()
+    if init_out is not None:
+        d_out.upload(np.ascontiguousarray(init_out, dtype=PKTOUT_DTYPE))
     d_len = DeviceBuffer(n * 4).zero()
     pkt_in = np.array(pkt_in, copy=True)
     d_in = d_pk = None

@@ -340,9 +340,6 @@ struct OutRef {
 			g[k] = v;
 	}
 };
-#ifndef DH_CUT
-#define DH_CUT 0
-#endif
 struct PState {
 	const uint64_t *w;       // 50 packed words (a gathered packet), or -- `direct` -- the stream word the packet starts in
 	// direct mode (decode_hits_kernel): the packet is bits [sh, sh + length) of w[0 .. wlimit)
@@ -1586,7 +1583,7 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 			// btbb_decode_payload (:1223-1297)
 			uint32_t clock = pi.clkn;
 			s.phl = 0;
-			switch (DH_CUT == 3 ? 0 : s.type) {
+			switch (s.type) {
 			case 0: case 1: s.plen = 0; payload_rv = 1; break;
 			case 2:  payload_rv = do_fhs<true>(s, clock); break;
 			case 3: case 8: case 10: case 14: payload_rv = do_DM<true>(s, clock); break;
@@ -1814,8 +1811,9 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	// while it sat in s_waitcnt the same sort gained nothing.)  Counting sort on (decoder, symbols wanted); what a
 	// thread knows about its packet goes to the thread that takes it over through the input stage, which is still empty.
 	{
-		__shared__ uint32_t sort_cnt[64];
-		__shared__ uint8_t perm[256];
+		// (the counters and the permutation live in ostage, which nothing uses before the sort is over)
+		uint32_t *const sort_cnt = reinterpret_cast<uint32_t *>(&ostage[0][0]);
+		uint8_t *const perm = reinterpret_cast<uint8_t *>(&ostage[0][32]);
 		uint64_t *const xch = &stage[0][0];
 		const uint32_t tid = threadIdx.x;
 		if (tid < 64)
@@ -1871,7 +1869,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	s.pre_hdr = hdr;
 	s.pre_dis = dis;
 	DH_MARK(1);                                         // header read from the stream, type known
-	if (DH_CUT == 1) { if (live) outs[pkt].payload[0] = (uint64_t)want + s.sh + pi.clkn + len; return; }
 	// Results leave through LDS.  A lane storing its own packet's words touches 64 different sectors per
 	// instruction and every one of them costs the memory system a whole sector: nine such stores per packet (five
 	// words of head, about four of payload) were 100 of the kernel's 290 us.  The payload words of a single-slot
@@ -1946,7 +1943,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	s.staged = nw;
 	s.stage_off = stage_base + 8u * before;
 	DH_MARK(2);                                         // packets staged
-	if (DH_CUT == 2) { if (live) outs[pkt].payload[0] = s_bits(s, 0, 64) + want + pi.clkn; return; }
 
 	uint64_t head[5] = {0, 0, 0, 0, 0};
 	if (live)

@@ -146,6 +146,47 @@ def test_batch_decode():
     assert good > 30
 
 
+def test_decode_from_the_streams_many_workgroups_dirty_records():
+    """The same identity at a size where decode_hits_kernel's workgroups are full and sort their packets by decoder
+    and length (2 600 hits, every type, lengths mixed), with enough symbol errors that FEC 2/3 blocks fail in the
+    middle of DM payloads (the reference then writes no payload at all), and with records that hold random bytes on
+    entry: whatever the decoders do not assign must still be there afterwards."""
+    rng = np.random.default_rng(_libs.seed(59))
+    n_streams, n_words = 5, 1 << 15
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    pk = _pkt.random_packets(rng, 2600, max_sym_errors=9)
+    rows = []
+    pos = [64 + int(rng.integers(0, 64)) for _ in range(n_streams)]
+    for i, (s, meta) in enumerate(pk):
+        st = i % n_streams
+        s = s[:bt.MAX_SYMBOLS]
+        if pos[st] + len(s) + 200 > n_words * 64:
+            continue
+        sym[st, pos[st]:pos[st] + len(s)] = s
+        rows.append((st, pos[st], meta))
+        pos[st] += len(s) + int(rng.integers(1, 90))
+    assert len(rows) > 1500
+    hits = np.zeros(len(rows), bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(len(rows), bt.PKTIN_DTYPE)
+    pin["clkn"] = [r[2]["clk6"] for r in rows]
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    dirty = np.frombuffer(rng.integers(0, 256, len(rows) * bt.PKTOUT_DTYPE.itemsize, dtype=np.uint8).tobytes(),
+                          dtype=bt.PKTOUT_DTYPE).copy()
+    dirty["payload_length"] &= 0x1ff
+    dirty["payload_header_length"] &= 3
+    direct, len_d = bt.run_decode_hits(words, hits, pin, init_out=dirty)
+    two_step, len_g = bt.run_decode_hits(words, hits, pin, via_gather=True, init_out=dirty)
+    assert np.array_equal(len_d, len_g)
+    bad = [i for i in range(len(rows)) if direct[i].tobytes() != two_step[i].tobytes()]
+    assert not bad, (len(bad), bad[:5], [rows[i][2].get("type") for i in bad[:5]])
+    rv = direct["payload_rv"]
+    assert (rv == 10).sum() > 100 and (rv == 0).sum() > 50 and (direct["header_rv"] == 1).sum() > 500
+
+
 def test_decode_from_the_streams_equals_gather_then_decode():
     """btbbx_decode_hits_device reads the packets where they lie: same btbbx_pkt_out, byte for byte, as cutting
     them out first -- for every bit alignment, for captures cut short by the end of the stream (the decoders
