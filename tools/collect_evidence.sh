@@ -12,18 +12,18 @@ out=${1:-gpurun_out/evidence}
 mkdir -p $out
 export TMPDIR=/tmp
 python -c "import bench; print(bench.csrc_fingerprint())" > $out/csrc_sha16.txt
-python bench.py 2>/dev/null | tail -1 > $out/bench.json
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu > /dev/null 2>&1 )
+timeout 200 python bench.py 2>/dev/null | tail -1 > $out/bench.json
+( cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu > /dev/null 2>&1 )
 find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/stats
-python tools/pmc_collect.py --out $out/pmc --kernel scan_ --groups FETCH_SIZE WRITE_SIZE \
+timeout 200 python tools/pmc_collect.py --out $out/pmc --kernel scan_ --groups FETCH_SIZE WRITE_SIZE \
   SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES \
   SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
   -- python bench.py --steps 4 --warmup 1 --no-cpu --no-secondary > $out/pmc_scan.json 2> $out/pmc.err
 rm -rf $out/pmc
-python tools/pmc_collect.py --out $out/pmc2 --kernel "" --groups FETCH_SIZE WRITE_SIZE \
+timeout 200 python tools/pmc_collect.py --out $out/pmc2 --kernel "" --groups FETCH_SIZE WRITE_SIZE \
   SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_WAVE_CYCLES SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
   -- python bench.py --steps 2 --warmup 1 --no-cpu > $out/pmc_secondary.json 2> $out/pmc2.err
 rm -rf $out/pmc2
-python tools/init_sweep.py 2>/dev/null | tail -1 > $out/init_sweep.json
-python tools/multistream_time.py 2>/dev/null > $out/multistream.txt
+timeout 120 python tools/init_sweep.py 2>/dev/null | tail -1 > $out/init_sweep.json
+timeout 120 python tools/multistream_time.py 2>/dev/null > $out/multistream.txt
