@@ -1807,7 +1807,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	// The workgroup's 256 packets change hands so that a wave decodes packets of one kind and about one length: a wave
 	// with DM, DH and FHS packets in it runs the three decoders one after the other with a third of its lanes each,
 	// and a loop over FEC blocks runs as long as its longest packet.  (With the stores, the staging and the exact
-	// extents fixed the kernel issues vector instructions 68 % of the time, profiles/r03_chain/pmc_decode_after.json;
+	// extents fixed the kernel issues vector instructions 68 % of the time, profiles/r03_chain/pmc_decode_mid.json;
 	// while it sat in s_waitcnt the same sort gained nothing.)  Counting sort on (decoder, symbols wanted); what a
 	// thread knows about its packet goes to the thread that takes it over through the input stage, which is still empty.
 	{

@@ -31,7 +31,8 @@ struct OrderParams {
 	uint32_t n;                                // records in the list = min(*d_count, cap)
 	uint32_t shift;                            // bucket = lin >> shift
 	uint32_t ticket;                           // last workgroup of the extent pass works the parameters out
-	uint32_t pad[3];
+	uint32_t crowded;                          // some bucket has more than ORDER_SMALL members (set by the scan of the counts)
+	uint32_t pad[2];
 };
 
 #define ORDER_SMALL 48u                        // bucket-mates up to here are ranked by a plain loop
@@ -153,15 +154,23 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 	return base + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums)
+__global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums, OrderParams *p)
 {
 	__shared__ uint32_t lds_wave[16];
 	const uint32_t base = blockIdx.x * 1024 * ORDER_SCAN_ITEMS + threadIdx.x * ORDER_SCAN_ITEMS;
 	uint32_t v = 0;
+	bool big = false;
 #pragma unroll
 	for (int k = 0; k < ORDER_SCAN_ITEMS; k++)
-		if (base + k < nb)
-			v += cnt[base + k];
+		if (base + k < nb) {
+			const uint32_t c = cnt[base + k];
+			v += c;
+			big |= c > ORDER_SMALL;
+		}
+	// order_crowded_kernel has nothing to look for when no counter is that large (the usual case: as many buckets as
+	// records): it then skips its pass over all the buckets
+	if (__ballot(big) && (threadIdx.x & 63) == 0)
+		atomicOr(&p->crowded, 1u);
 	uint32_t total;
 	(void)block_exclusive_scan_1024(v, lds_wave, total);
 	if (threadIdx.x == 0)
@@ -245,6 +254,8 @@ __global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *gr
 	__shared__ uint32_t lds_wave[16];
 	__shared__ uint32_t found[1024], n_found;
 	__shared__ unsigned long long win_lo, win_hi;
+	if (!p->crowded)
+		return;
 	const uint32_t shift = p->shift;
 	const unsigned long long mul = p->mul;
 	// 1024 buckets are looked at per step, one per thread (a workgroup stepping through the buckets one by one spent
@@ -410,7 +421,7 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	if (!counted_by_scan)
 		hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
 	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
-	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p);
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
 	hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped);
 	hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
