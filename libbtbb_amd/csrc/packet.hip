@@ -1681,15 +1681,16 @@ __device__ __forceinline__ uint32_t decoder_of_type(uint32_t type)
 	return (uint32_t)(0x3276323254432100ULL >> (4 * type)) & 0xf;
 }
 #ifndef DH_OUT_WORDS
-#define DH_OUT_WORDS 3u                      // payload words per lane that leave through LDS
+#define DH_OUT_WORDS 4u                      // payload words per lane that leave through LDS
 #endif
+#define DH_OUT_SECTOR 3u                     // ... of which these share the 64-byte sector of the record's head
 // How many symbols of the packet the payload decoder of `type` will look at under this clock, and whether what it
-// writes fits DH_OUT_WORDS words.  DM / DH / AUX1 / DV carry their length in the payload header (do_payload_header, the
+// writes fits DH_OUT_WORDS words (small; wide: it needs the last of them, which lies in the record's second sector).  DM / DH / AUX1 / DV carry their length in the payload header (do_payload_header, the
 // decoders' own first step, on a scratch copy of the state): a DM3 with twelve bytes in it is 6 words of stream, not
 // the 26 its type could have -- with the type's bound alone a wave with sixteen DM3 in it ran out of its LDS stage
 // and half its lanes read their packets from HBM word by word.  An estimate that is too small only sends s_bits() to
 // the stream for the rest; it never changes what is read.
-__device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t type, uint32_t clock, bool &small)
+__device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t type, uint32_t clock, bool &small, bool &wide)
 {
 	bool fec = false;
 	int header_bytes = 2;
@@ -1705,6 +1706,7 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 		// HV2 160, HV3 240 (type 7 tries EV3 first: 256); EV4 / EV5 run over several slots
 		const uint32_t bits = (0x85300500u >> (4 * (type & 7)) & 0xf) * 32u;   // (rounded up to 32; types >= 8 never get here as small)
 		small = type < 8 && bits <= 64 * DH_OUT_WORDS;
+		wide = small && bits > 64 * DH_OUT_SECTOR;
 		return symbols_of_type(type);
 	}
 	}
@@ -1712,10 +1714,12 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 	s.type = type;
 	s.ph16 = 0; s.ph_mask = 0; s.dirty = 0; s.ph_written = 0;
 	small = true;
+	wide = false;
 	if (!do_payload_header<false>(s, pos, clock, header_bytes, s.length - (int)pos, fec))
 		return pos + 30;
 	const uint32_t nbits = (uint32_t)s.plen * 8;
 	small = nbits <= 64 * DH_OUT_WORDS;
+	wide = small && nbits > 64 * DH_OUT_SECTOR;
 	return pos + (fec ? 15 * ((nbits + 9) / 10) : nbits);
 }
 
@@ -1770,7 +1774,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	DH_MARK(0);                                         // hit + btbbx_pkt_in loaded
 	// how much of the packet the decoders can want: the type the header yields under this packet's clock
 	uint32_t want = 0, dtype = 0;
-	bool small = false;                                 // a single-slot type: its payload fits DH_OUT_WORDS words
+	bool small = false, wide = false;                   // its payload fits DH_OUT_WORDS words / needs more than DH_OUT_SECTOR
 	uint32_t hdr = 0, dis = 0;
 	typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 	{
@@ -1794,7 +1798,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			uint32_t type = pi.type;
 			if (mode & DEC_HEADER)
 				type = ((hdr ^ (uint32_t)wh(s, wh_start(pi.clkn, 0), 18)) >> 3) & 0xf;
-			const uint32_t bound = payload_extent(s, type, pi.clkn, small);
+			const uint32_t bound = payload_extent(s, type, pi.clkn, small, wide);
 			want = len < bound ? len : bound;
 			dtype = type;
 		}
@@ -1827,7 +1831,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 		const uint32_t r = atomicAdd(&sort_cnt[key], 1u);
 		xch[tid] = h.offset;
-		xch[256 + tid] = (uint64_t)h.stream | (uint64_t)want << 16 | (uint64_t)small << 30 | (uint64_t)live << 31 | (uint64_t)pi.clkn << 32;
+		xch[256 + tid] = (uint64_t)h.stream | (uint64_t)want << 16 | (uint64_t)wide << 28 | (uint64_t)small << 30 | (uint64_t)live << 31 | (uint64_t)pi.clkn << 32;
 		xch[512 + tid] = (uint64_t)pi.flags | (uint64_t)pi.uap << 32 | (uint64_t)pi.type << 40 | (uint64_t)pi.llid << 48 | (uint64_t)pi.flow << 56;
 		xch[768 + tid] = (uint64_t)hdr | (uint64_t)dis << 32;
 		__syncthreads();
@@ -1845,7 +1849,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		pkt = blockIdx.x * blockDim.x + q;
 		h.offset = x0;
 		h.stream = (uint16_t)x1;
-		want = (uint32_t)(x1 >> 16) & 0x3fff;
+		want = (uint32_t)(x1 >> 16) & 0xfff;            // <= 3125
+		wide = (x1 >> 28) & 1;
 		small = (x1 >> 30) & 1;
 		live = (x1 >> 31) & 1;
 		pi.clkn = (uint32_t)(x1 >> 32);
@@ -1875,7 +1880,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	// packet (<= 256 bits: FHS 160, DM1 / DH1 / AUX1 / DV <= 240, HV 240, EV3 256) are collected in ostage, the head
 	// in the input stage once every lane is done reading it, and the wave stores head + payload of packet after
 	// packet as consecutive words.  ostage starts from what the record holds, so bits the decoders leave alone stay.
-	const uint64_t small_mask = __ballot(small), live_mask = __ballot(live);
+	const uint64_t small_mask = __ballot(small), wide_mask = __ballot(wide), live_mask = __ballot(live);
 	// the record's head (entry state of the decoders): on its way while the packets are staged
 	uint64_t head_in[5] = {0, 0, 0, 0, 0};
 	if (live) {
@@ -1911,7 +1916,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		for (uint32_t t = 0; t < 2 * DH_OUT_WORDS; t++) {
 			const uint32_t f = t * 64 + lane, p = f / (2 * DH_OUT_WORDS), k = f % (2 * DH_OUT_WORDS);
 			const uint32_t pkt_p = __shfl(pkt, p);
-			if ((small_mask >> p) & 1)
+			if (((small_mask >> p) & 1) && (k < 2 * DH_OUT_SECTOR || ((wide_mask >> p) & 1)))
 				__builtin_amdgcn_global_load_lds((glb_u32_t *)(uintptr_t)(reinterpret_cast<const uint32_t *>(outs + pkt_p) + 10 + k),
 								 obase + t * 64, 4, 0, 0);
 		}
@@ -1962,7 +1967,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			uint64_t *dst = reinterpret_cast<uint64_t *>(outs + pkt_p);
 			if (k < 5)
 				dst[k] = stage[wave][p * 5 + k];
-			else if ((keep_mask >> p) & 1)
+			else if (((keep_mask >> p) & 1) && (k - 5 < DH_OUT_SECTOR || ((wide_mask >> p) & 1)))
 				dst[k] = ostage[wave][p * DH_OUT_WORDS + k - 5];
 		}
 	}
