@@ -1651,12 +1651,16 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 // gather's: min(max_length, 3125, symbols left in the stream), and d_in[i].length is ignored.
 //
 // A lane walking its packet word by word from HBM fetched 753 B per packet for ~300 needed (every 8-byte read
-// drags a 64-byte sector through the L2, profiles/traffic_secondary.json, round 2).  Now the wave brings the
-// packets in together: every lane first reads its header (symbols 68 .. 121, at most two words) and works out the
-// packet type for its clock -- how many symbols a packet of that type can have is all the decoders will look at --
-// then the 64 packets are copied to LDS one after the other, 64 lanes = 64 consecutive words = whole sectors, and
-// decoded from there.  s_bits() takes words the staging did not cover (a budget of DH_STAGE_WORDS per wave) from
-// the stream as before, so the symbol bound only decides where a word comes from, never what it is.
+// drags a 64-byte sector through the L2, profiles/traffic_secondary.json, round 2) and sat out a latency per step.
+// The kernel's phases now (DESIGN.md 3.4 has the numbers behind each):
+//   A  every lane loads its hit and, in one batch, words 1 .. 4 of its packet; from those it decodes the header and
+//      the payload header under its clock: the packet's type and EXACTLY how many symbols its decoder will read
+//   B  the workgroup's 256 packets change hands (counting sort on decoder and length): one decoder per wave
+//   C  the wave copies its 64 packets into LDS (global_load_lds, a dozen instructions in flight together)
+//   D  one lane per packet decodes from LDS; payloads of up to 256 bits go to a per-lane LDS copy of the record
+//   E  the wave stores head + payload of packet after packet as consecutive words (one 64-byte sector for most)
+// s_bits() takes words the staging did not cover (DH_STAGE_WORDS per wave) from the stream as before, so the extents
+// only decide where a word comes from, never what it is.
 #ifndef DH_STAGE_WORDS
 #define DH_STAGE_WORDS 384u                  // LDS words per wave for staged packets (3 KiB; 4 waves per workgroup)
 #endif
@@ -1685,7 +1689,8 @@ __device__ __forceinline__ uint32_t decoder_of_type(uint32_t type)
 #endif
 #define DH_OUT_SECTOR 3u                     // ... of which these share the 64-byte sector of the record's head
 // How many symbols of the packet the payload decoder of `type` will look at under this clock, and whether what it
-// writes fits DH_OUT_WORDS words (small; wide: it needs the last of them, which lies in the record's second sector).  DM / DH / AUX1 / DV carry their length in the payload header (do_payload_header, the
+// writes fits DH_OUT_WORDS words (small; wide: it needs the last of them, which lies in the record's second sector).
+// DM / DH / AUX1 / DV carry their length in the payload header (do_payload_header, the
 // decoders' own first step, on a scratch copy of the state): a DM3 with twelve bytes in it is 6 words of stream, not
 // the 26 its type could have -- with the type's bound alone a wave with sixteen DM3 in it ran out of its LDS stage
 // and half its lanes read their packets from HBM word by word.  An estimate that is too small only sends s_bits() to
@@ -1874,12 +1879,13 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	s.pre_hdr = hdr;
 	s.pre_dis = dis;
 	DH_MARK(1);                                         // header read from the stream, type known
-	// Results leave through LDS.  A lane storing its own packet's words touches 64 different sectors per
-	// instruction and every one of them costs the memory system a whole sector: nine such stores per packet (five
-	// words of head, about four of payload) were 100 of the kernel's 290 us.  The payload words of a single-slot
-	// packet (<= 256 bits: FHS 160, DM1 / DH1 / AUX1 / DV <= 240, HV 240, EV3 256) are collected in ostage, the head
-	// in the input stage once every lane is done reading it, and the wave stores head + payload of packet after
-	// packet as consecutive words.  ostage starts from what the record holds, so bits the decoders leave alone stay.
+	// Results leave through LDS.  A lane storing its own packet's words touches 64 different sectors per instruction
+	// (the phase after the decoders was 29 % of the wave time, 6 % now).  The payload words of a packet that writes
+	// <= 256 bits (FHS 160, DM1 / DH1 / AUX1 / DV <= 240, HV 240, EV3 256, short multi-slot packets) are collected in
+	// ostage, the head in the input stage once every lane is done reading it, and the wave stores head + payload of
+	// packet after packet as consecutive words.  ostage starts from what the record holds, so bits the decoders leave
+	// alone stay.  Head + three payload words = the record's first 64-byte sector; the fourth word (`wide` packets
+	// only) is in the second.
 	const uint64_t small_mask = __ballot(small), wide_mask = __ballot(wide), live_mask = __ballot(live);
 	// the record's head (entry state of the decoders): on its way while the packets are staged
 	uint64_t head_in[5] = {0, 0, 0, 0, 0};
