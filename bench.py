@@ -292,7 +292,8 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
 
     order_bytes = lib.btbbx_order_hits_scratch_bytes(cap)
     order_scratch = torch.empty(order_bytes, dtype=torch.uint8, device=dev)
-    off_view = hits.view(cap, 2)[:, 0]
+    off_lo32 = hits.view(torch.int32).view(cap, 4)[:, 0]
+    assert wpc * 64 < 2 ** 31
 
     def chain():
         # scan -> (stream, offset) order -> decode, all queued on one stream: the number of hits never leaves the
@@ -300,10 +301,12 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
         cnt.zero_()
         bt.check(lib.btbbx_scan_ordered_device(d3.data_ptr(), wpc, wpc, nch, nbits, lap, 2, hits.data_ptr(), cap, cnt.data_ptr(),
                                                order_scratch.data_ptr(), order_bytes, hs))
-        # pkt_in per packet, on the device: CLK1-6 from the slot number, flags WHITENED | UAP_VALID |
-        # CLK6_VALID, the piconet's UAP (the captured length is worked out by the decode call itself);
-        # computed for the whole buffer -- entries behind the count are never read
-        pin[:, 1] = ((off_view >> 12) & 63).to(torch.int32)
+        # pkt_in per packet, on the device: the clock = the slot number of the hit (btbbx_pkt_in.clkn is CLK1-27; the
+        # decoders look at CLK1-6), flags WHITENED | UAP_VALID | CLK6_VALID, the piconet's UAP (the captured length is
+        # worked out by the decode call itself); ONE element-wise kernel over the whole buffer (offsets are below 2^32:
+        # the low dword of the offset, shifted, written straight into the clkn column) -- entries behind the count
+        # are never read
+        torch.bitwise_right_shift(off_lo32, 12, out=pin[:, 1])
         # header + payload decode straight from the streams (no 400-byte row per packet in between)
         bt.check(lib.btbbx_decode_hits_counted_device(d3.data_ptr(), wpc, wpc, hits.data_ptr(), pin.data_ptr(), cnt.data_ptr(),
                                                       cap, 3125, pout.data_ptr(), ln.data_ptr(), hs))
