@@ -1,0 +1,107 @@
+"""The occupancy every measured number in DESIGN.md rests on, read from the code objects inside the built library:
+registers, LDS and scratch of the hot kernels (the AMDGPU metadata note of each gfx950 code object in .hip_fatbin).
+A change that pushes a kernel over a register or LDS step -- or makes a decoder state live in scratch -- shows up here,
+on the CPU, before a GPU run is spent on it."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "libbtbb_amd", "libbtbb_amd.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+LDS_PER_CU = 160 * 1024
+VGPRS_PER_SIMD_LANE = 512
+
+
+def _kernels():
+    data = open(SO, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = {}, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        p = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            p += 24
+            triple = data[p:p + tl].decode()
+            p += tl
+            if "gfx950" in triple and size:
+                path = "/tmp/btbb_kres_%d_%d.co" % (os.getpid(), len(out))
+                with open(path, "wb") as f:
+                    f.write(data[i + off:i + off + size])
+                notes = subprocess.run([READELF, "--notes", path], capture_output=True, text=True, check=True).stdout
+                os.unlink(path)
+                for block in notes.split("- .agpr_count:")[1:]:
+                    name = re.search(r"\.name:\s+(\S+)", block).group(1)
+                    out[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                                 for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+                                           "group_segment_fixed_size", "max_flat_workgroup_size")}
+        pos = i + 24
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(SO) or not os.path.exists(READELF):
+        pytest.skip("library or llvm-readelf missing")
+    k = _kernels()
+    assert len(k) > 30, sorted(k)
+    return k
+
+
+def _one(kernels, pattern):
+    m = [n for n in kernels if re.search(pattern, n)]
+    assert len(m) == 1, (pattern, m)
+    return kernels[m[0]]
+
+
+def _waves_per_simd(vgprs):
+    return min(8, VGPRS_PER_SIMD_LANE // (-(-vgprs // 8) * 8))
+
+
+def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
+    """2 x 768 threads per CU = 6 waves per SIMD; the set + rings are dynamic LDS (76 KiB per workgroup)."""
+    for pat in (r"scan_slide_kernelILi2ELi2ELb0E", r"scan_slide_kernelILi2ELi2ELb1E"):
+        k = _one(kernels, pat)
+        assert k["vgpr_count"] <= 80 and _waves_per_simd(k["vgpr_count"]) >= 6, k
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        assert k["max_flat_workgroup_size"] == 768, k
+
+
+def test_known_lap_kernel_eight_waves_per_simd(kernels):
+    for cls in (0, 1):
+        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dE" % cls)
+        assert k["vgpr_count"] <= 64 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        assert k["group_segment_fixed_size"] * 8 <= LDS_PER_CU, k
+
+
+def test_decode_hits_kernel_six_workgroups_per_cu(kernels):
+    """256 threads, six workgroups per CU by LDS (stage + result copies + tables), six waves per SIMD by
+    registers; the decoder state lives in registers (a few dwords of spill are tolerated, a PState in scratch is not)."""
+    k = _one(kernels, r"decode_hits_kernel")
+    assert k["vgpr_count"] <= 80, k
+    assert k["group_segment_fixed_size"] * 6 <= LDS_PER_CU, k
+    assert k["private_segment_fixed_size"] <= 32 and k["vgpr_spill_count"] <= 6, k
+
+
+def test_decoders_and_trials_keep_their_state_in_registers(kernels):
+    for pat in (r"^_Z13decode_kernel", r"decode_bytes_kernel", r"trials_wide_kernel", r"trials_state_kernel", r"trials_merge_kernel",
+                r"replay_kernel"):
+        k = _one(kernels, pat)
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (pat, k)
+    k = _one(kernels, r"trials_linear_kernel")              # one 1024-thread workgroup per CU at the 128-register ceiling:
+    assert k["vgpr_count"] <= 128, k                        # the prefetched words of the next batch are parked in scratch
+    assert k["private_segment_fixed_size"] <= 64 and k["group_segment_fixed_size"] <= LDS_PER_CU, k
+
+
+def test_order_kernels_have_no_scratch(kernels):
+    """(order_crowded_kernel, the cold pass over buckets of thousands, keeps one record in private memory)"""
+    for name, k in kernels.items():
+        if "order_" in name and "crowded" not in name:
+            assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
