@@ -60,6 +60,10 @@ def _apply(cols, reg):
     return out
 
 
+def _int_of(bits):
+    return sum(int(b) << j for j, b in enumerate(bits))
+
+
 def _seed(uap):
     return (int("{:08b}".format(uap & 0xFF)[::-1], 2) << 8) & 0xFF00
 
@@ -112,7 +116,9 @@ def dh_wave(sym, clk6, uap, ptype):
     payload = np.concatenate(words)[:nbits] if words else np.zeros(0, np.uint8)
     if ptype == 9:
         return 2, payload
-    return (10 if _wave_crc_is_zero(words, nbits, uap) else 2), payload
+    ok = _wave_crc_is_zero(words, nbits, uap)
+    assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
+    return (10 if ok else 2), payload
 
 
 _F23 = synth._F23
@@ -187,4 +193,29 @@ def dm_wave(sym, clk6, uap, ptype):
         w[keep:] = 0
         words.append(w)
     payload = np.concatenate(words)[:nbits] if words else np.zeros(0, np.uint8)
-    return (10 if _wave_crc_is_zero(words, nbits, uap) else 2), payload
+    ok = _wave_crc_is_zero(words, nbits, uap)
+    assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
+    return (10 if ok else 2), payload
+
+
+def _bits_of(word):
+    return np.array([(word >> j) & 1 for j in range(64)], dtype=np.uint8)
+
+
+def wave_crc_is_zero_u64(words, nbits, uap):
+    """The same with the registers a lane would hold: words[w] = payload bits 64 w .. 64 w + 63 as an integer (bit j =
+    payload bit 64 w + j, zero behind nbits).  With nbits = 64 T + r, lane l's block is the funnel shift
+    (words[T - l - 1] >> r) | (words[T - l] << (64 - r)) of two neighbouring words (words[-1] = 0; r = 0: words[T - 1 - l]),
+    i.e. the 64 payload bits that end 64 l bits in front of the end; the first block starts with zeros."""
+    mask = (1 << 64) - 1
+    T, r = divmod(nbits, 64)
+    get = lambda i: words[i] if 0 <= i < len(words) else 0          # noqa: E731
+    adv = _adv64()
+    total = _crc_step_bits(_seed(uap), np.zeros(nbits, np.uint8))
+    for lane in range((nbits + 63) // 64):
+        if r:
+            block = ((get(T - lane - 1) >> r) | (get(T - lane) << (64 - r))) & mask
+        else:
+            block = get(T - 1 - lane)
+        total ^= _apply(adv[lane], _crc_step_bits(0, _bits_of(block)))
+    return total == 0
