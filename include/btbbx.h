@@ -266,6 +266,16 @@ int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_t n_words, 
 				     const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, const uint32_t *d_count,
 				     uint32_t cap, uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths,
 				     void *hip_stream);
+/* ... for a capture of ONE piconet, without a btbbx_pkt_in per packet: every packet enters with the state of *entry
+ * (a HOST pointer; flags, UAP, type, llid, flow -- what btbb_packet_set_data / btbb_packet_set_uap / the flag setters leave,
+ * lib/src/bluetooth_packet.c:467-480; its length is ignored) and the clock entry->clkn + offset / clk_div: CLK1-27 advances
+ * once per 625 symbols at 1 Msym/s, so a receiver that knows its clock at the first symbol of the buffer knows it for
+ * every access code found in it (the clkn argument of btbb_packet_set_data, lib/src/btbb.h:116).  d_count may be NULL
+ * (then cap records are decoded). */
+int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+				     const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
+				     const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t max_length,
+				     btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream);
 
 /* ---- hop selection and CLK1-27 reversal ------------------------- */
 #define BTBBX_SEQUENCE_LENGTH 134217728u   /* values of CLK1-27, bluetooth_piconet.h:102 */

@@ -123,6 +123,7 @@ SIGNATURES = {
     "btbbx_decode_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_decode_hits_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_decode_hits_counted_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "btbbx_decode_hits_piconet_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_uap_table_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
     "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),
@@ -394,11 +395,12 @@ def run_decode(packet_words, pkt_in):
     return d_out.download(PKTOUT_DTYPE, n)
 
 
-def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gather=False, init_out=None):
+def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gather=False, init_out=None, count=None):
     """Decode the packets that start at `hits` (HIT_DTYPE: stream, offset) of the packed streams
     stream_words[n_streams, n_words] -> (PKTOUT_DTYPE array, captured lengths).  via_gather=True takes
     the two-step route (btbbx_gather_packets_device + btbbx_decode_device) for comparison.  init_out: what the
-    records hold on entry (a PKTOUT_DTYPE array; zeros if None) -- the decoders leave alone what they do not assign."""
+    records hold on entry (a PKTOUT_DTYPE array; zeros if None) -- the decoders leave alone what they do not assign.
+    count: the list's length as a word in HBM (btbbx_decode_hits_counted_device, capacity len(hits))."""
     stream_words = np.ascontiguousarray(stream_words, dtype=np.uint64)
     n_streams, n_words = stream_words.shape
     n = len(hits)
@@ -422,8 +424,18 @@ def run_decode_hits(stream_words, hits, pkt_in, max_length=MAX_SYMBOLS, via_gath
             check(lib().btbbx_decode_device(d_pk.ptr, d_in.ptr, n, d_out.ptr, None), "btbbx_decode_device")
         else:
             d_in = DeviceBuffer(pkt_in.nbytes).upload(pkt_in)
-            check(lib().btbbx_decode_hits_device(d_w.ptr, n_words, n_words, d_h.ptr, d_in.ptr, n, max_length, d_out.ptr,
-                                                 d_len.ptr, None), "btbbx_decode_hits_device")
+            if count is not None:
+                d_cnt = DeviceBuffer(8).upload(np.array([count, 0], dtype=np.uint32))
+                try:
+                    check(lib().btbbx_decode_hits_counted_device(d_w.ptr, n_words, n_words, d_h.ptr, d_in.ptr, d_cnt.ptr, n,
+                                                                 max_length, d_out.ptr, d_len.ptr, None),
+                          "btbbx_decode_hits_counted_device")
+                    check(lib().btbbx_sync(None))
+                finally:
+                    d_cnt.free()
+            else:
+                check(lib().btbbx_decode_hits_device(d_w.ptr, n_words, n_words, d_h.ptr, d_in.ptr, n, max_length, d_out.ptr,
+                                                     d_len.ptr, None), "btbbx_decode_hits_device")
         check(lib().btbbx_sync(None))
         return d_out.download(PKTOUT_DTYPE, n), d_len.download(np.uint32, n)
     finally:

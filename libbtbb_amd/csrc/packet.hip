@@ -52,6 +52,9 @@ __device__ __attribute__((aligned(16))) uint16_t g_lin[LIN_MAXLEN * 16];
 // g_advw[i - 1][h][x]: the CRC register 4 i zero bytes after holding x in its low (h = 0) / high (h = 1) byte,
 // i = 1 .. 7 (linear: XOR the two halves) -- what carries a chunk's start register to a word inside the chunk
 __device__ __attribute__((aligned(16))) uint16_t g_advw[7 * 2 * 256];
+// g_adv64[j][k]: the CRC register 64 j zero bits after holding 1 << k -- the matrix A^(64 j) by columns, what lane j of
+// the long-payload phase of decode_hits_kernel applies to the register of the 64-bit block that has 64 j bits behind it
+__device__ __attribute__((aligned(16))) uint16_t g_adv64[64 * 16];
 
 static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
 {
@@ -155,6 +158,16 @@ int chain_upload(const HostTables &t)
 					advw[((i - 1) * 2 + h) * 256 + x] = (uint16_t)c;
 				}
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_advw), advw, sizeof(advw)));
+		static uint16_t adv64[64 * 16];
+		for (int k = 0; k < 16; k++) {
+			uint32_t c = 1u << k;
+			for (int j = 0; j < 64; j++) {
+				adv64[j * 16 + k] = (uint16_t)c;
+				for (int b = 0; b < 8; b++)
+					c = host_crc_byte(c, 0);
+			}
+		}
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_adv64), adv64, sizeof(adv64)));
 	}
 	ChainTables c;
 	memset(&c, 0, sizeof(c));
@@ -171,6 +184,7 @@ int chain_upload(const HostTables &t)
 #define F_WHITENED    (1u << 0)
 #define F_CLK6_VALID  (1u << 4)
 #define F_HAS_PAYLOAD (1u << 7)
+#define DHL_MIN_BITS  256              // payloads longer than this leave decode_hits_kernel's lanes for its wave phase (= 64 DH_OUT_WORDS)
 
 // ---- bit helpers ----------------------------------------------------------------------------
 
@@ -363,6 +377,11 @@ struct PState {
 	// payload writer
 	OutRef out;              // 43 words or nothing
 	bool spoiled = false;    // out is the caller's scratch copy (LDS) and holds a payload the reference would not have written
+	// decode_hits_kernel: a DM / DH payload of more than 256 bits is not walked by its lane; do_DM / do_DH return after
+	// their checks with the bit count here and the wave works it off afterwards, a group of lanes per packet (long_payloads)
+	bool defer_ok = false;
+	bool def_fec = false;
+	uint32_t def_nbits = 0;
 	uint32_t written;        // payload bits written (prefix)
 	// which fields a trial assigned (replay_kernel merges 64 trials by "last writer wins")
 	uint32_t dirty;          // D_* bits
@@ -387,7 +406,7 @@ __device__ __forceinline__ uint64_t s_bits(const PState &s, uint32_t pos, uint32
 	auto word = [&](uint32_t k) -> uint64_t {
 		if (k < s.staged)
 			return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>(s.stage_off + 8u * k);
-		return k < s.wlimit ? s.w[k] : 0ULL;
+		return k < s.wlimit ? ((const __attribute__((address_space(1))) uint64_t *)(uintptr_t)s.w)[k] : 0ULL;    // (direct mode: the stream in HBM)
 	};
 	uint64_t v = word(i) >> sft;
 	if (sft + n > 64)
@@ -638,6 +657,11 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 	if (nbits > size)
 		return 1;
 	uint32_t nblocks = (nbits + 9) / 10;
+	if (WRITE && s.defer_ok && !s.out.l && nbits > DHL_MIN_BITS) {
+		s.def_nbits = (uint32_t)nbits;
+		s.def_fec = true;
+		return 2;                                           // (replaced by long_payloads' verdict)
+	}
 	// The reference writes nothing when a block fails.  Into HBM that takes a pass over all blocks first; a scratch copy
 	// is written as the blocks decode and marked as not to be kept when one fails.
 	if (WRITE && !s.out.l && !fec23_ok(s, pos, nblocks))
@@ -692,6 +716,11 @@ __device__ __forceinline__ int do_DH(PState &s, uint32_t clock)
 	int nbits = s.plen * 8;
 	if (nbits > size)
 		return 1;
+	if (WRITE && s.defer_ok && !s.out.l && nbits > DHL_MIN_BITS) {
+		s.def_nbits = (uint32_t)nbits;
+		s.def_fec = false;
+		return 2;                                           // (replaced by long_payloads' verdict)
+	}
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
 	for (int done = 0; done < nbits; done += 32) {
@@ -1728,14 +1757,247 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 	return pos + (fec ? 15 * ((nbits + 9) / 10) : nbits);
 }
 
+// ---- long payloads: a group of lanes per packet ---------------------------------------------------------------------
+// A lane that walks a DM3 / DH3 / DM5 / DH5 payload alone reads one stream word and writes one record word per step,
+// each a sector of its own, one latency after the other: 1.4 - 3.5 ms per 1.29 M full-length packets against 0.13 - 0.15
+// for the single-slot types (profiles/r03_chain/decode_by_type.txt).  do_DM / do_DH therefore stop after their checks
+// when the payload has more than DHL_MIN_BITS bits (PState::def_nbits) and the wave works those packets off together:
+// G = 8 / 16 / 32 / 64 lanes per packet (the smallest that covers the stream words of every deferred packet of the
+// wave; the workgroup sort keeps packets of one G together), 64 / G packets per round.  Per round, lane `sub` of a group
+//   1. loads stream word `sub` of its packet (coalesced; the next round's words are requested before this round's
+//      are worked on), zeroes what lies at and behind the captured length (the reference's decoders read zeros there,
+//      bluetooth_packet.c:898-958) and puts it into LDS;
+//   2. DH (:962-1011): payload word `sub` is a funnel shift of two staged words.  DM (:898-958): blocks sub, sub + G, ..
+//      of the (15,10) code are decoded from LDS and their ten bits ORed into the packed payload in LDS (ds_or); one
+//      failing block anywhere in the packet and nothing is written (rv 0), as in the reference;
+//   3. unwhitens its word with the 64 whitening bits from (start + 64 sub) mod 127 and cuts it at payload_length;
+//   4. CRC (:671-690, :772-781): the register is GF(2)-linear, a seed is the same as its bits XORed onto the first
+//      sixteen message bits, and zero bits in front of a message do not move a zero register.  So the payload is cut
+//      into 64-bit blocks aligned to its END (block j = a funnel shift of the output words around word T - j), every
+//      lane runs its block from a zero register (two four-byte steps), carries the result over the 64 j bits behind it
+//      -- the fixed matrix A^(64 j), sixteen 16-bit columns per lane from g_adv64, loaded once per wave -- and the group
+//      XORs its registers: zero <=> the reference's compare of the computed with the received CRC succeeds;
+//   5. stores its word (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
+// tests/_wave_model.py is the numpy model of exactly these steps (pinned against the oracle on the CPU).
+#define DHL_LIST   0u                        // 64 x 3 words: what the owner lanes know about their deferred packets
+#define DHL_STG    192u                      // 66 words: the round's packets as they lie in the stream
+#define DHL_PB     258u                      // 64 words: decoded FEC 2/3 bits, packed
+#define DHL_RV     322u                      // 32 words: verdict per owner lane
+static_assert(DH_STAGE_WORDS >= DHL_RV + 32u, "the long-payload phase lives in the wave's input stage");
+typedef __attribute__((address_space(3))) uint64_t dhl_u64_t;
+typedef __attribute__((address_space(3))) uint32_t dhl_u32_t;
+
+// XOR over the 2^logg lanes of a group (3 <= logg <= 6), every lane gets the result
+__device__ __forceinline__ uint32_t group_xor(uint32_t x, uint32_t logg)
+{
+	x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+	x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+	x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of eight
+	if (logg > 3)
+		x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xf, 0xf, true); // row_mirror: the other eight of sixteen
+	if (logg > 4)
+		x ^= (uint32_t)__shfl_xor((int)x, 16);
+	if (logg > 5)
+		x ^= (uint32_t)__shfl_xor((int)x, 32);
+	return x;
+}
+
+// the register after the matrix whose columns are the sixteen 16-bit halves of c[0..7]
+__device__ __forceinline__ uint32_t apply_columns(const uint32_t (&c)[8], uint32_t reg)
+{
+	uint32_t x = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const uint32_t m0 = 0u - ((reg >> (2 * k)) & 1u), m1 = 0u - ((reg >> (2 * k + 1)) & 1u);
+		x ^= c[k] & ((m0 & 0xffffu) | (m1 & 0xffff0000u));
+	}
+	return (x ^ (x >> 16)) & 0xffffu;
+}
+
+// All 64 lanes; `deferred` lanes own a packet (s, nbits = s.def_nbits, nw = its stream words, pkt = its record).
+// Returns the payload verdict (0 / 2 / 10) to the owner lanes.  `area` = DH_STAGE_WORDS words of LDS of this wave.
+__device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bool deferred, const PState &s,
+					     uint32_t clkn, uint32_t pkt, btbbx_pkt_out *outs, uint32_t lane)
+{
+	dhl_u32_t *const area32 = (dhl_u32_t *)area;
+	// stream words the packet's decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3
+	// blocks may lie behind the captured length (they read as zeros), never behind word 45
+	uint32_t nw = 0;
+	if (deferred) {
+		const uint32_t ext = s.def_fec ? 15u * ((s.def_nbits + 9u) / 10u) : s.def_nbits;
+		nw = (s.sh + 122u + ext + 63u) >> 6;
+	}
+	// lanes per packet
+	const uint32_t logg = __ballot(deferred && nw > 32) ? 6u : __ballot(deferred && nw > 16) ? 5u : __ballot(deferred && nw > 8) ? 4u : 3u;
+	const uint32_t G = 1u << logg, R = 64u >> logg;
+	const uint32_t sub = lane & (G - 1), grp = lane >> logg;
+	const uint32_t n_def = (uint32_t)__popcll(dmask);
+	if (deferred) {
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
+		const uint32_t widx = wh_start(clkn, 18);
+		area[DHL_LIST + 3 * rank] = (uint64_t)(uintptr_t)s.w;
+		area[DHL_LIST + 3 * rank + 1] = (uint64_t)pkt | (uint64_t)s.sh << 32 | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 38
+			| (uint64_t)(uint32_t)s.length << 45 | (uint64_t)lane << 57;
+		area[DHL_LIST + 3 * rank + 2] = (uint64_t)s.def_nbits | (uint64_t)s.def_fec << 12 | (uint64_t)(whitened(s) ? 1u : 0u) << 13 | (uint64_t)widx << 14
+			| (uint64_t)crc_seed(s.uap) << 21;
+	}
+	area[DHL_PB + lane] = 0;
+	if (lane < 2)
+		area[DHL_STG + 64 + lane] = 0;
+	// this lane's matrix: sixteen columns of A^(64 sub)
+	uint32_t col[8];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64) + 2 * sub;
+		const uint4 a = src[0], b = src[1];
+		col[0] = a.x; col[1] = a.y; col[2] = a.z; col[3] = a.w; col[4] = b.x; col[5] = b.y; col[6] = b.z; col[7] = b.w;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t rounds = (n_def + R - 1) >> (6 - logg);
+	// the words of round r on their way: stream word `sub` of the group's packet, and -- the lane that will write a
+	// partial last word -- what the record holds there
+	auto request = [&](uint32_t r, uint64_t &wv, uint64_t &old) {
+		const uint32_t e = r * R + grp;
+		wv = 0;
+		old = 0;
+		if (e < n_def) {
+			const uint64_t a = area[DHL_LIST + 3 * e], b = area[DHL_LIST + 3 * e + 1], c = area[DHL_LIST + 3 * e + 2];
+			const uint32_t p_nw = (uint32_t)(b >> 38) & 127u, p_nbits = (uint32_t)c & 0xfffu;
+			if (sub < p_nw)
+				wv = ((const __attribute__((address_space(1))) uint64_t *)(uintptr_t)a)[sub];
+			if ((p_nbits & 63u) && sub == (p_nbits >> 6))
+				old = outs[(uint32_t)b].payload[sub];
+		}
+	};
+	uint64_t nwv, nold;
+	request(0, nwv, nold);
+	// A round's word is stored at the start of the next round, behind that round's wait for its stream words: gfx9 counts
+	// loads and stores in one in-order counter, so whatever is waited for also waits for every store issued before it --
+	// this way each store and each load has a round's worth of work to complete in.
+	uint64_t st_val = 0;
+	uint32_t st_pkt = 0;
+	bool st_do = false;
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t e = r * R + grp;
+		const bool has = e < n_def;
+		uint64_t pb = 0, pc = 0;
+		if (has) {
+			pb = area[DHL_LIST + 3 * e + 1];
+			pc = area[DHL_LIST + 3 * e + 2];
+		}
+		const uint32_t p_pkt = (uint32_t)pb, p_sh = (uint32_t)(pb >> 32) & 63u, p_len = (uint32_t)(pb >> 45) & 0xfffu, p_owner = (uint32_t)(pb >> 57) & 63u;
+		const uint32_t nbits = (uint32_t)pc & 0xfffu, p_widx = (uint32_t)(pc >> 14) & 127u, p_seed = (uint32_t)(pc >> 21) & 0xffffu;
+		const bool p_fec = (pc >> 12) & 1u, p_wht = (pc >> 13) & 1u;
+		// 1. the stream word, cut at the captured length, into LDS
+		{
+			const uint32_t valid_bits = p_sh + p_len;                   // stream bits of the packet's words that are symbols of the capture
+			const uint32_t here = valid_bits > 64u * sub ? valid_bits - 64u * sub : 0u;
+			uint64_t v = nwv;
+			if (here < 64)
+				v &= (1ULL << here) - 1;
+			area[DHL_STG + lane] = v;
+		}
+		const uint64_t oldw = nold;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if (st_do)
+			outs[st_pkt].payload[sub] = st_val;
+		if (r + 1 < rounds)
+			request(r + 1, nwv, nold);
+		// 2. payload word `sub` of the packet
+		uint64_t word = 0;
+		bool fail = false;
+		const uint32_t T = nbits >> 6, rem = nbits & 63u, nwp = (nbits + 63u) >> 6;
+		const uint64_t any_fec = __ballot(has && p_fec);
+		if (any_fec) {
+			if (has && p_fec) {
+				const uint32_t nblocks = (nbits + 9u) / 10u;
+				for (uint32_t b = sub; b < nblocks; b += G) {
+					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 2u * (grp << logg) + (q >> 5);
+					const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
+					uint32_t data = blk & 0x3ffu;
+					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
+					const int fix = g_lds.fix23[diff & 31u];
+					if (fix == -2)
+						fail = true;
+					if (fix >= 0)
+						data ^= 1u << fix;
+					const uint32_t bit = 10u * b, d = 2u * DHL_PB + 2u * (grp << logg) + (bit >> 5), sft = bit & 31u;
+					__hip_atomic_fetch_or(area32 + d, data << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					if (sft > 22)
+						__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (has && p_fec) {
+			word = area[DHL_PB + lane];
+		} else if (has) {
+			const uint32_t q = p_sh + 122u + 64u * sub, i = DHL_STG + (grp << logg) + (q >> 6), sft = q & 63u;
+			const uint64_t lo = area[i], hi = area[i + 1];
+			word = sft ? (lo >> sft) | (hi << (64u - sft)) : lo;
+		}
+		if (any_fec)
+			area[DHL_PB + lane] = 0;                                // the packed bits are consumed: ready for the next round
+		const uint64_t fail_mask = __ballot(fail);
+		const bool group_fail = ((fail_mask >> (grp << logg)) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
+		// 3. unwhitened, cut at the payload length
+		const bool active = has && sub < nwp;
+		uint64_t out = 0, keep_mask = ~0ULL;
+		if (active) {
+			const uint32_t idx = (p_widx + 64u * sub) % 127u;
+			const uint64_t wbits = p_wht ? wh_bits(idx, 64) : 0ULL;
+			if (sub == T)                                             // (only when rem != 0)
+				keep_mask = (1ULL << rem) - 1;
+			out = (word ^ wbits) & keep_mask;
+		}
+		// 4. CRC: end-aligned blocks through LDS (the staged stream words are used up)
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		area[DHL_STG + lane] = out ^ (sub == 0 ? (uint64_t)p_seed : 0ULL);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		uint32_t reg = 0;
+		if (has && sub < nwp) {
+			// block `sub` ends 64 sub bits in front of the payload's end: bits of words T - sub - 1 (from bit rem) and T - sub
+			const int ia = (int)T - (int)sub - 1, ib = (int)T - (int)sub;
+			const uint32_t base = DHL_STG + (grp << logg);
+			const uint64_t wa = ia >= 0 ? area[base + (uint32_t)ia] : 0ULL;
+			const uint64_t wb = (rem && ib >= 0) ? area[base + (uint32_t)ib] : 0ULL;
+			const uint64_t block = rem ? (wa >> rem) | (wb << (64u - rem)) : wa;
+			reg = crc_word(crc_word(0, (uint32_t)block), (uint32_t)(block >> 32));
+			reg = apply_columns(col, reg);
+		}
+		const uint32_t total = group_xor(reg, logg);
+		int rv = total == 0 ? 10 : 2;
+		if (p_fec && group_fail)
+			rv = 0;
+		// 5. out (nothing when a block failed)
+		st_do = active && rv != 0;
+		st_val = sub == T ? out | (oldw & ~keep_mask) : out;
+		st_pkt = p_pkt;
+		if (has && sub == 0)
+			area32[2u * DHL_RV + p_owner] = (uint32_t)rv;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (st_do)
+		outs[st_pkt].payload[sub] = st_val;
+	return deferred ? (int)area32[2u * DHL_RV + lane] : 0;
+}
+
 #ifndef DH_WAVES_PER_EU
 #define DH_WAVES_PER_EU 6
+#endif
+#ifndef DH_LONG_PHASE
+#define DH_LONG_PHASE 1                      // 0: every lane walks its payload itself, whatever its length (round 3)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH_WAVES_PER_EU, DH_WAVES_PER_EU)))
 void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
 							  const uint32_t *d_count, uint32_t max_length, btbbx_pkt_out *outs,
-							  uint32_t *lengths, uint32_t mode)
+							  uint32_t *lengths, uint32_t mode, btbbx_pkt_in one_in, uint32_t clk_div)
 {
 	__shared__ uint64_t stage[4][DH_STAGE_WORDS];
 	__shared__ uint64_t ostage[4][64 * DH_OUT_WORDS];
@@ -1771,8 +2033,16 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	s.length = live ? (int)len : 0;
 	btbbx_pkt_in pi;
 	pi.length = 0; pi.clkn = 0; pi.flags = 0; pi.uap = 0; pi.type = 0; pi.llid = 0; pi.flow = 0;
-	if (live)
-		pi = in[pkt];
+	if (live) {
+		if (in) {
+			pi = in[pkt];
+		} else {
+			// a capture of one piconet: every packet enters with the same state, its clock follows from where it was found
+			// (CLK1-27 advances once per clk_div symbols: 625 at 1 Msym/s)
+			pi = one_in;
+			pi.clkn = one_in.clkn + (h.offset >> 32 ? (uint32_t)(h.offset / clk_div) : (uint32_t)h.offset / clk_div);
+		}
+	}
 	pi.length = len;
 
 	asm volatile("" : "+v"(pi.clkn), "+v"(len));
@@ -1833,12 +2103,18 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			const uint32_t cls = want <= 126 ? 0 : decoder_of_type(dtype);
 			const uint32_t lb = want <= 126 ? 0 : (want - 122) >> 5;
 			key = cls * 8 + (lb < 7 ? lb : 7);
+			// payloads that go to the wave phase (long_payloads): together, by the lanes a packet takes there (keys that
+			// are all but unused otherwise: class 0 has one length, HV packets that are not cut short another)
+			if (DH_LONG_PHASE && !small && want > 126 && (cls == 2 || cls == 3)) {
+				const uint32_t words = (s.sh + want + 63) >> 6;
+				key = (cls == 2 ? 32u : 1u) + (words > 32 ? 3u : words > 16 ? 2u : words > 8 ? 1u : 0u);
+			}
 		}
 		const uint32_t r = atomicAdd(&sort_cnt[key], 1u);
 		xch[tid] = h.offset;
 		xch[256 + tid] = (uint64_t)h.stream | (uint64_t)want << 16 | (uint64_t)wide << 28 | (uint64_t)small << 30 | (uint64_t)live << 31 | (uint64_t)pi.clkn << 32;
 		xch[512 + tid] = (uint64_t)pi.flags | (uint64_t)pi.uap << 32 | (uint64_t)pi.type << 40 | (uint64_t)pi.llid << 48 | (uint64_t)pi.flow << 56;
-		xch[768 + tid] = (uint64_t)hdr | (uint64_t)dis << 32;
+		xch[768 + tid] = (uint64_t)hdr | (uint64_t)dtype << 24 | (uint64_t)dis << 32;
 		__syncthreads();
 		uint32_t c = sort_cnt[lane], incl = c;
 		for (int d = 1; d < 64; d <<= 1) {
@@ -1871,7 +2147,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		s.wlimit = fw < n_words ? (uint32_t)(n_words - fw < 64 ? n_words - fw : 64) : 0;
 		s.length = live ? (int)len : 0;
 		pi.length = len;
-		hdr = (uint32_t)x3;
+		hdr = (uint32_t)x3 & 0x3ffffu;
+		dtype = (uint32_t)(x3 >> 24) & 0xfu;
 		dis = (uint32_t)(x3 >> 32);
 	}
 #endif
@@ -1897,6 +2174,9 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	uint32_t nw = live ? (s.sh + want + 63) / 64 : 0;              // words of the stream that hold those symbols
 	if (nw > s.wlimit)
 		nw = s.wlimit;
+	// a payload that will be left to the wave phase: its lane reads the header and the payload header, four words
+	if (DH_LONG_PHASE && live && !small && want > 126 && nw > 4 && (decoder_of_type(dtype) == 2 || decoder_of_type(dtype) == 3))
+		nw = 4;
 	// LDS slots in lane order; a packet that does not fit the wave's budget any more stays in the stream
 	uint32_t before = nw;
 	for (int d = 1; d < 64; d <<= 1) {
@@ -1956,10 +2236,21 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	DH_MARK(2);                                         // packets staged
 
 	uint64_t head[5] = {0, 0, 0, 0, 0};
+	s.defer_ok = DH_LONG_PHASE;
 	if (live)
 		decode_view(s, pi, outs + pkt, mode,
 			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head, head_in DH_PASS);
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
+	{
+		// payloads the lanes left to the wave (DM3 / DH3 / DM5 / DH5 beyond 256 bits): a group of lanes per packet
+		const bool deferred = live && s.def_nbits != 0;
+		const uint64_t dmask = __ballot(deferred);
+		if (dmask) {
+			const int rv = long_payloads((dhl_u64_t *)(lds_u64_t *)(&stage[wave][0]), dmask, deferred, s, pi.clkn, pkt, outs, lane);
+			if (deferred)
+				head[0] = (head[0] & 0xffffffffULL) | (uint64_t)(uint32_t)rv << 32;      // payload_rv
+		}
+	}
 	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
 	for (int k = 0; k < 5; k++)
@@ -2430,9 +2721,9 @@ extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_word
 		set_error("btbbx_decode_hits_device: null pointer");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((n_packets + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)n_packets + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
 			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, (const uint32_t *)nullptr, max_length, d_out,
-			   d_lengths, DEC_HEADER | DEC_PAYLOAD);
+			   d_lengths, DEC_HEADER | DEC_PAYLOAD, btbbx_pkt_in{}, 1u);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
@@ -2454,9 +2745,9 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 		set_error("btbbx_decode_hits_counted_device: null pointer");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)cap + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
 			   d_words, n_words, pitch_words, d_hits, d_in, cap, d_count, max_length, d_out, d_lengths,
-			   DEC_HEADER | DEC_PAYLOAD);
+			   DEC_HEADER | DEC_PAYLOAD, btbbx_pkt_in{}, 1u);
 	HIP_TRY(hipGetLastError());
 #ifdef DH_PROFILE
 	{
@@ -2472,5 +2763,31 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dh_prof), zero, sizeof(zero)));
 	}
 #endif
+	return BTBBX_OK;
+}
+
+// A capture of ONE piconet, decoded without a btbbx_pkt_in per packet: every packet enters with the state *entry
+// describes (flags, UAP, ...; its length field is ignored) and the clock entry->clkn + offset / clk_div -- CLK1-27
+// advances once per 625 symbols at 1 Msym/s, so a receiver that knows the clock at the first symbol of its buffer knows
+// it for every access code the scan found in it.  The list's length is read from HBM as above (d_count may be NULL:
+// then `cap` records are decoded).
+extern "C" int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+						const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
+						const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t max_length,
+						btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
+{
+	int rc = ctx_require();
+	if (rc)
+		return rc;
+	if (!cap)
+		return BTBBX_OK;
+	if (!d_words || !d_hits || !entry || !d_out || !clk_div) {
+		set_error("btbbx_decode_hits_piconet_device: null pointer or clk_div = 0");
+		return BTBBX_E_ARG;
+	}
+	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)cap + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+			   d_words, n_words, pitch_words, d_hits, (const btbbx_pkt_in *)nullptr, cap, d_count, max_length, d_out,
+			   d_lengths, DEC_HEADER | DEC_PAYLOAD, *entry, clk_div);
+	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }

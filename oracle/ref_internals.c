@@ -331,6 +331,78 @@ size_t refint_known_lap_chain(char *stream, uint64_t n_symbols, uint32_t lap, in
 	return n;
 }
 
+/* The same chain with what it decoded kept per match, for bench.py's in-run parity of the config-3 lines: one 32-byte
+ * record per access code (at most cap are written; the return value counts all).  payload_hash covers the
+ * payload_length * 8 payload bits the decoder left (LSB-first 64-bit words w_k, sum of w_k * (2 k + 1) mod 2^64) when
+ * the payload decoder returned 2 / 10 / 1000, else 0. */
+struct refint_chain_record {
+	uint64_t offset;
+	uint64_t payload_hash;
+	int32_t payload_rv, payload_length;
+	uint8_t ac_errors, header_rv, type, lt_addr, hdr_flags, hec, header_present, pad;
+};
+size_t refint_known_lap_chain_records(char *stream, uint64_t n_symbols, uint32_t lap, int max_ac_errors, uint8_t uap,
+				      uint32_t clk_div, struct refint_chain_record *rec, size_t cap)
+{
+	size_t n = 0;
+	uint64_t off = 0;
+	const uint64_t search_length = n_symbols - 63;
+	btbb_packet *found = NULL;
+	btbb_packet *pkt = btbb_packet_new();
+	while (off < search_length) {
+		uint64_t left = search_length - off, at, avail;
+		int chunk = left > 0x40000000ULL ? 0x40000000 : (int)left;
+		int r = btbb_find_ac(stream + off, chunk, lap, max_ac_errors, &found);
+		struct refint_chain_record q;
+		if (r < 0) {
+			off += (uint64_t)chunk;
+			continue;
+		}
+		at = off + (uint64_t)r;
+		avail = n_symbols - at;
+		memset(&q, 0, sizeof(q));
+		q.offset = at;
+		q.ac_errors = btbb_packet_get_ac_errors(found);
+		pkt->LAP = lap;
+		pkt->flags = 0;
+		btbb_packet_set_flag(pkt, BTBB_WHITENED, 1);
+		btbb_packet_set_data(pkt, stream + at, avail > MAX_SYMBOLS ? MAX_SYMBOLS : (int)avail, 0,
+				     (uint32_t)(((at / clk_div) & 63) << 1));
+		btbb_packet_set_uap(pkt, uap);
+		btbb_packet_set_flag(pkt, BTBB_CLK6_VALID, 1);
+		q.header_present = (uint8_t)btbb_header_present(pkt);
+		if (q.header_present && btbb_decode_header(pkt)) {
+			int rv = btbb_decode_payload(pkt);
+			q.header_rv = 1;
+			q.payload_rv = rv;
+			q.payload_length = pkt->payload_length;
+			q.type = pkt->packet_type;
+			q.lt_addr = pkt->packet_lt_addr;
+			q.hdr_flags = pkt->packet_flags;
+			q.hec = pkt->packet_hec;
+			if (rv == 2 || rv == 10 || rv == 1000) {
+				int nbits = pkt->payload_length * 8, k, b;
+				uint64_t h = 0;
+				for (k = 0; 64 * k < nbits; k++) {
+					uint64_t w = 0;
+					for (b = 0; b < 64 && 64 * k + b < nbits; b++)
+						w |= (uint64_t)(pkt->payload[64 * k + b] & 1) << b;
+					h += w * (uint64_t)(2 * k + 1);
+				}
+				q.payload_hash = h;
+			}
+		}
+		if (n < cap)
+			rec[n] = q;
+		n++;
+		off = at + 1;
+	}
+	if (found)
+		btbb_packet_unref(found);
+	btbb_packet_unref(pkt);
+	return n;
+}
+
 /* BASELINE config 5: the 64-candidate loop of btbb_uap_from_header (bluetooth_piconet.c:675-690) on
  * n_packets packets of `stride` symbols each: try_clock + crc_check for every CLK1-6 value.  Returns a
  * checksum of the results so that nothing is optimised away; table[p * 64 + c] = uap | rv << 8. */

@@ -190,6 +190,7 @@ def ref():
         "refint_unpack_mt": (C.c_int, [vp, C.c_uint64, vp, C.c_int]),
         "refint_known_lap_chain": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint8, C.c_uint32,
                                                 C.POINTER(C.c_uint64)]),
+        "refint_known_lap_chain_records": (C.c_size_t, [vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint8, C.c_uint32, vp, C.c_size_t]),
         "refint_clk6_trials": (C.c_uint64, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
         "refint_gen_syndrome": (C.c_uint64, [C.c_uint64]),
         "refint_unfec13": (C.c_int, [vp, vp, C.c_int]),

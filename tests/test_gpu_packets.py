@@ -187,6 +187,142 @@ def test_decode_from_the_streams_many_workgroups_dirty_records():
     assert (rv == 10).sum() > 100 and (rv == 0).sum() > 50 and (direct["header_rv"] == 1).sum() > 500
 
 
+LONG_TYPES = (synth.TYPE_DM3, synth.TYPE_DH3, synth.TYPE_DM5, synth.TYPE_DH5)
+LONG_MAXBODY = {synth.TYPE_DM3: 121, synth.TYPE_DH3: 183, synth.TYPE_DM5: 224, synth.TYPE_DH5: 339,
+                synth.TYPE_DM1: 17, synth.TYPE_DH1: 27, synth.TYPE_EV4: 120, synth.TYPE_EV5: 180}
+
+
+def _long_capture(rng, n_packets, n_streams, n_words, others=(synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_FHS, synth.TYPE_EV4, synth.TYPE_EV5)):
+    """Streams of noise with mostly multi-slot DM / DH packets in them: full-length bodies, bodies around the 256-bit
+    boundary where the wave phase of decode_hits_kernel takes over, every payload_length mod 8, symbol errors in the
+    payload (FEC 2/3 blocks that fail), captures cut short; -> (symbols, rows of (stream, offset, meta))."""
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    rows = []
+    pos = [64 + int(rng.integers(0, 64)) for _ in range(n_streams)]
+    for i in range(n_packets):
+        st = i % n_streams
+        t = LONG_TYPES[(i // n_streams) % 4] if i % 5 else others[(i // 5) % len(others)]
+        mb = LONG_MAXBODY.get(t, 0)
+        k = i % 7
+        if k == 0:
+            nb = mb
+        elif k == 1 and t in LONG_TYPES:
+            nb = int(rng.integers(24, 40))                    # payload_length around 32 bytes = 256 bits
+        elif k == 2:
+            nb = max(0, mb - int(rng.integers(0, 9)))         # the last word of the payload at every fill
+        else:
+            nb = int(rng.integers(0, mb + 1))
+        lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+        p = synth.build_packet(lap, uap, clk6, t, lt_addr=int(rng.integers(0, 8)), flags=int(rng.integers(0, 8)),
+                               body=rng.integers(0, 256, nb, dtype=np.uint8).tobytes(), llid=int(rng.integers(0, 4)),
+                               flow=int(rng.integers(0, 2)), voice=rng.integers(0, 256, 10, dtype=np.uint8).tobytes(),
+                               fhs_bits=synth.fhs_payload(lap, uap, 0x1234, i, rng))[:bt.MAX_SYMBOLS]
+        p = p.copy()
+        ne = (0, 0, 1, 2, 4, 9)[i % 6]
+        if ne and len(p) > 140:
+            p[rng.integers(126, len(p), ne)] ^= 1              # payload region: the header stays decodable
+        if pos[st] + len(p) + 300 > n_words * 64:
+            continue
+        sym[st, pos[st]:pos[st] + len(p)] = p
+        rows.append((st, pos[st], dict(lap=lap, uap=uap, clk6=clk6, type=t, nbody=nb)))
+        # now and then the next packet starts inside this one (a capture cut short by another access code is still
+        # decoded to its full window), otherwise a gap of noise
+        pos[st] += len(p) + int(rng.integers(1, 120)) if i % 11 else max(200, len(p) // 2)
+    return sym, rows
+
+
+def test_long_payloads_leave_through_the_wave_phase():
+    """DM3 / DH3 / DM5 / DH5 payloads beyond 256 bits are not walked by a lane but decoded by a group of 8 .. 64 lanes
+    (long_payloads in packet.hip): byte-identical to cutting the packets out and decoding them lane by lane, and equal
+    to the oracle -- full lengths, every payload_length mod 8 around the word boundaries, failing FEC 2/3 blocks (the
+    reference then writes nothing), wrong clocks (noise through the payload header), unwhitened packets, captures cut
+    short by the stream's end and by max_length, and records that hold random bytes on entry."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(83))
+    n_streams, n_words = 6, 1 << 15
+    sym, rows = _long_capture(rng, 2400, n_streams, n_words)
+    # hits whose window runs into the end of the stream, inside long packets put there for it
+    for st in range(n_streams):
+        for back, t in ((2900, synth.TYPE_DH5), (2000, synth.TYPE_DM5), (1200, synth.TYPE_DH3), (700, synth.TYPE_DM3), (400, synth.TYPE_DH5)):
+            lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+            p = synth.build_packet(lap, uap, clk6, t, lt_addr=1, body=rng.integers(0, 256, LONG_MAXBODY[t], dtype=np.uint8).tobytes())
+            off = n_words * 64 - back - 64 * st
+            sym[st, off:off + len(p)] = p[:n_words * 64 - off]
+            rows.append((st, off, dict(lap=lap, uap=uap, clk6=clk6, type=t, nbody=LONG_MAXBODY[t])))
+    assert len(rows) > 1800
+    hits = np.zeros(len(rows), bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(len(rows), bt.PKTIN_DTYPE)
+    clk = np.array([r[2]["clk6"] for r in rows], dtype=np.uint32)
+    clk[::13] ^= 9                                            # wrong clock: the header check decides; some pass by chance
+    pin["clkn"] = clk | (rng.integers(0, 1 << 20, len(rows)).astype(np.uint32) << 6)
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    pin["flags"][::29] &= ~np.uint32(1)                       # not whitened
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    dirty = np.frombuffer(rng.integers(0, 256, len(rows) * bt.PKTOUT_DTYPE.itemsize, dtype=np.uint8).tobytes(),
+                          dtype=bt.PKTOUT_DTYPE).copy()
+    dirty["payload_length"] &= 0x1ff
+    dirty["payload_header_length"] &= 3
+    for max_length in (bt.MAX_SYMBOLS, 1500):
+        direct, len_d = bt.run_decode_hits(words, hits, pin, init_out=dirty, max_length=max_length)
+        two_step, len_g = bt.run_decode_hits(words, hits, pin, via_gather=True, init_out=dirty, max_length=max_length)
+        assert np.array_equal(len_d, len_g)
+        bad = [i for i in range(len(rows)) if direct[i].tobytes() != two_step[i].tobytes()]
+        assert not bad, (max_length, len(bad), [(i, rows[i][2]["type"], rows[i][2]["nbody"], int(direct[i]["payload_rv"]),
+                                                 int(two_step[i]["payload_rv"]), int(direct[i]["payload_length"])) for i in bad[:8]])
+    direct, len_d = bt.run_decode_hits(words, hits, pin)      # records zeroed on entry, as the oracle's packets are
+    seen = {}
+    for i in range(0, len(rows), 3):
+        st, off, meta = rows[i]
+        s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
+        # (the oracle unwhitens whenever asked to decode: only whitened packets are compared with it)
+        if not int(pin["flags"][i]) & 1:
+            continue
+        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        o = direct[i]
+        assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, off, meta)
+        if h:
+            assert int(o["payload_length"]) == stt["payload_length"], (i, meta)
+            bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+            assert (bits == stt["payload"]).all(), (i, meta, np.nonzero(bits != stt["payload"])[0][:8])
+            seen[(int(o["type"]), r)] = seen.get((int(o["type"]), r), 0) + 1
+    for t in LONG_TYPES:
+        assert seen.get((t, 10), 0) >= 15, (t, seen)
+    assert sum(v for (t, r), v in seen.items() if t in (synth.TYPE_DM3, synth.TYPE_DM5) and r == 0) >= 10, seen
+    assert sum(v for (t, r), v in seen.items() if t in LONG_TYPES and r == 2) >= 10, seen
+
+
+def test_decode_with_the_count_in_hbm():
+    """btbbx_decode_hits_counted_device (the list's length is a word in HBM, the launch is sized for the capacity):
+    the first min(count, capacity) records equal btbbx_decode_hits_device's, records behind the count keep every byte
+    they held -- for a count inside a workgroup, on a workgroup boundary, equal to and above the capacity."""
+    rng = np.random.default_rng(_libs.seed(89))
+    n_streams, n_words = 3, 1 << 14
+    sym, rows = _long_capture(rng, 700, n_streams, n_words)
+    n = len(rows)
+    assert n > 520
+    hits = np.zeros(n, bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(n, bt.PKTIN_DTYPE)
+    pin["clkn"] = [r[2]["clk6"] for r in rows]
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    dirty = np.frombuffer(rng.integers(0, 256, n * bt.PKTOUT_DTYPE.itemsize, dtype=np.uint8).tobytes(), dtype=bt.PKTOUT_DTYPE).copy()
+    dirty["payload_length"] &= 0x1ff
+    dirty["payload_header_length"] &= 3
+    full, len_f = bt.run_decode_hits(words, hits, pin, init_out=dirty)
+    for count in (0, 1, 77, 256, 300, 512, n - 1, n, n + 5, 1 << 31):
+        got, len_c = bt.run_decode_hits(words, hits, pin, init_out=dirty, count=count)
+        k = min(count, n)
+        assert got[:k].tobytes() == full[:k].tobytes(), count
+        assert got[k:].tobytes() == dirty[k:].tobytes(), count
+        assert np.array_equal(len_c[:k], len_f[:k]) and not len_c[k:].any(), count
+
+
 def test_decode_from_the_streams_equals_gather_then_decode():
     """btbbx_decode_hits_device reads the packets where they lie: same btbbx_pkt_out, byte for byte, as cutting
     them out first -- for every bit alignment, for captures cut short by the end of the stream (the decoders

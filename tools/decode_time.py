@@ -35,7 +35,12 @@ def case(lib, dev, hs, types, full, seed=7):
         for k in range(slots):
             t_ = types[(k + ch) % len(types)]
             mb = MAXBODY.get(t_, 0)
-            nb = mb if (full or t_ in (synth.TYPE_HV1, synth.TYPE_HV2, synth.TYPE_HV3)) else min(mb, int(rng.integers(1, 17)))
+            if full or t_ in (synth.TYPE_HV1, synth.TYPE_HV2, synth.TYPE_HV3):
+                nb = mb
+            elif len(types) == 1 and mb > 100:
+                nb = int(rng.integers(0, mb + 1))            # a single multi-slot type, "not full": any length
+            else:
+                nb = min(mb, int(rng.integers(1, 17)))
             body = rng.integers(0, 256, nb, dtype=np.uint8).tobytes()
             p = synth.build_packet(lap, uap, k & 63, t_, lt_addr=1 + k % 7, flags=k % 8, body=body,
                                    voice=rng.integers(0, 256, 10, dtype=np.uint8).tobytes(),
@@ -75,7 +80,7 @@ def case(lib, dev, hs, types, full, seed=7):
     res = pout.cpu().numpy().view(bt.PKTOUT_DTYPE)[:n]
     ok = int(((res["payload_rv"] == 10) | (res["payload_rv"] == 1000) | (res["payload_rv"] == 2) | (res["payload_rv"] == 1)).sum())
     us = a.elapsed_time(b) / 5 * 1e3
-    return {"types": "+".join(NAMES[t] for t in types), "payloads": "full" if full else "1-16 bytes", "packets": n,
+    return {"types": "+".join(NAMES[t] for t in types), "payloads": "full" if full else ("0-max bytes" if len(types) == 1 and MAXBODY.get(types[0], 0) > 100 else "1-16 bytes"), "packets": n,
             "decoded": ok, "us": round(us, 1), "G_packets_s": round(n / us / 1e3, 2)}
 
 
@@ -86,9 +91,12 @@ def main():
     hs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     S = synth
     cases = [([S.TYPE_DM1, S.TYPE_DH1, S.TYPE_DM3, S.TYPE_FHS], False), ([S.TYPE_DM1, S.TYPE_DH1, S.TYPE_DM3, S.TYPE_FHS], True),
+             ([S.TYPE_DM1, S.TYPE_DH1, S.TYPE_DM3, S.TYPE_DH3, S.TYPE_DM5, S.TYPE_DH5, S.TYPE_FHS], True),
              (list(range(16)), False), (list(range(16)), True)]
-    for t in (S.TYPE_DM1, S.TYPE_DH1, S.TYPE_FHS, S.TYPE_HV3, S.TYPE_DM3, S.TYPE_DH3, S.TYPE_DM5, S.TYPE_DH5, S.TYPE_EV5):
+    for t in (S.TYPE_DM1, S.TYPE_DH1, S.TYPE_FHS, S.TYPE_HV3, S.TYPE_DM3, S.TYPE_DH3, S.TYPE_DM5, S.TYPE_DH5, S.TYPE_EV4, S.TYPE_EV5):
         cases.append(([t], True))
+    for t in (S.TYPE_DM3, S.TYPE_DH3, S.TYPE_DM5, S.TYPE_DH5):          # random lengths: the wave phase with mixed group sizes
+        cases.append(([t], False))
     only = sys.argv[1:]
     for types, full in cases:
         if only and "+".join(NAMES[t] for t in types) not in only:
