@@ -52,9 +52,10 @@ __device__ __attribute__((aligned(16))) uint16_t g_lin[LIN_MAXLEN * 16];
 // g_advw[i - 1][h][x]: the CRC register 4 i zero bytes after holding x in its low (h = 0) / high (h = 1) byte,
 // i = 1 .. 7 (linear: XOR the two halves) -- what carries a chunk's start register to a word inside the chunk
 __device__ __attribute__((aligned(16))) uint16_t g_advw[7 * 2 * 256];
-// g_adv64[j][k]: the CRC register 64 j zero bits after holding 1 << k -- the matrix A^(64 j) by columns, what lane j of
-// the long-payload phase of decode_hits_kernel applies to the register of the 64-bit block that has 64 j bits behind it
-__device__ __attribute__((aligned(16))) uint16_t g_adv64[64 * 16];
+// g_adv64inv[j][k]: the CRC register that holds 1 << k after 64 j zero bits -- the matrix A^(-64 j) by columns (A = one
+// zero bit through the register: invertible), what lane j of the long-payload phase of decode_hits_kernel applies to the
+// register of payload word j alone
+__device__ __attribute__((aligned(16))) uint16_t g_adv64inv[64 * 16];
 
 static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
 {
@@ -158,16 +159,34 @@ int chain_upload(const HostTables &t)
 					advw[((i - 1) * 2 + h) * 256 + x] = (uint16_t)c;
 				}
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_advw), advw, sizeof(advw)));
-		static uint16_t adv64[64 * 16];
-		for (int k = 0; k < 16; k++) {
-			uint32_t c = 1u << k;
-			for (int j = 0; j < 64; j++) {
-				adv64[j * 16 + k] = (uint16_t)c;
+		// A^(-64): the register u that holds 1 << k 64 zero bits later, found by running every u forward (nothing assumed
+		// about the polynomial beyond "the step is invertible", which the search checks)
+		static uint16_t adv64inv[64 * 16];
+		{
+			static uint16_t back[65536];
+			static uint8_t hit[65536];
+			memset(hit, 0, sizeof(hit));
+			for (uint32_t u = 0; u < 65536; u++) {
+				uint32_t c = u;
 				for (int b = 0; b < 8; b++)
 					c = host_crc_byte(c, 0);
+				back[c] = (uint16_t)u;
+				hit[c] = 1;
+			}
+			for (uint32_t v = 0; v < 65536; v++)
+				if (!hit[v]) {
+					set_error("chain_upload: the CRC register's zero-byte step is not invertible");
+					return BTBBX_E_ARG;
+				}
+			for (int k = 0; k < 16; k++) {
+				uint32_t c = 1u << k;
+				for (int j = 0; j < 64; j++) {
+					adv64inv[j * 16 + k] = (uint16_t)c;
+					c = back[c];
+				}
 			}
 		}
-		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_adv64), adv64, sizeof(adv64)));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_adv64inv), adv64inv, sizeof(adv64inv)));
 	}
 	ChainTables c;
 	memset(&c, 0, sizeof(c));
@@ -1762,30 +1781,33 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 // each a sector of its own, one latency after the other: 1.4 - 3.5 ms per 1.29 M full-length packets against 0.13 - 0.15
 // for the single-slot types (profiles/r03_chain/decode_by_type.txt).  do_DM / do_DH therefore stop after their checks
 // when the payload has more than DHL_MIN_BITS bits (PState::def_nbits) and the wave works those packets off together:
-// G = 8 / 16 / 32 / 64 lanes per packet (the smallest that covers the stream words of every deferred packet of the
-// wave; the workgroup sort keeps packets of one G together), 64 / G packets per round.  Per round, lane `sub` of a group
-//   1. loads stream word `sub` of its packet (coalesced; the next round's words are requested before this round's
-//      are worked on), zeroes what lies at and behind the captured length (the reference's decoders read zeros there,
-//      bluetooth_packet.c:898-958) and puts it into LDS;
-//   2. DH (:962-1011): payload word `sub` is a funnel shift of two staged words.  DM (:898-958): blocks sub, sub + G, ..
-//      of the (15,10) code are decoded from LDS and their ten bits ORed into the packed payload in LDS (ds_or); one
-//      failing block anywhere in the packet and nothing is written (rv 0), as in the reference;
+// G = 8 / 16 / 32 / 64 lanes per packet -- one lane per 64-bit word of the longest deferred PAYLOAD of the wave (the
+// workgroup sort keeps packets of one G together) --, 64 / G packets per round.  Per round, lane `sub` of a group
+//   1. holds two stream words of its packet, requested one round ahead (a round's stores and loads all have a round's
+//      worth of work to complete in: gfx9 counts both in one in-order counter);
+//   2. DH (:962-1011): payload word `sub` is a funnel shift of those two words.  DM (:898-958): the words go to LDS
+//      (zeroed at and behind the captured length when a block reaches there: the reference reads zeros), blocks sub,
+//      sub + G, .. of the (15,10) code are decoded from LDS and their ten bits ORed into the packed payload in LDS
+//      (ds_or); one failing block anywhere in the packet and nothing is written (rv 0), as in the reference;
 //   3. unwhitens its word with the 64 whitening bits from (start + 64 sub) mod 127 and cuts it at payload_length;
-//   4. CRC (:671-690, :772-781): the register is GF(2)-linear, a seed is the same as its bits XORed onto the first
-//      sixteen message bits, and zero bits in front of a message do not move a zero register.  So the payload is cut
-//      into 64-bit blocks aligned to its END (block j = a funnel shift of the output words around word T - j), every
-//      lane runs its block from a zero register (two four-byte steps), carries the result over the 64 j bits behind it
-//      -- the fixed matrix A^(64 j), sixteen 16-bit columns per lane from g_adv64, loaded once per wave -- and the group
-//      XORs its registers: zero <=> the reference's compare of the computed with the received CRC succeeds;
+//   4. CRC (:671-690, :772-781): the register is GF(2)-linear; a seed is the same as its bits XORed onto the first
+//      sixteen message bits; zero bits appended to a message advance the register by an invertible map, so "register
+//      == 0" can be tested on the payload padded to whole words; and with A = "advance by one bit" the register after
+//      n words is A^(64 (n - 1)) applied to the XOR over the words of A^(-64 j) (register of word j alone) -- the outer
+//      factor is invertible too.  So every lane runs its own word from a zero register (two four-byte steps), applies
+//      the FIXED matrix A^(-64 sub) -- sixteen 16-bit columns per lane from g_adv64inv, loaded once per wave -- and the
+//      group XORs: zero <=> the reference's compare of the computed with the received CRC succeeds.  No lane needs
+//      another lane's word, whatever the payload length;
 //   5. stores its word (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
-// tests/_wave_model.py is the numpy model of exactly these steps (pinned against the oracle on the CPU).
-#define DHL_LIST   0u                        // 64 x 3 words: what the owner lanes know about their deferred packets
-#define DHL_STG    192u                      // 66 words: the round's packets as they lie in the stream
-#define DHL_PB     258u                      // 64 words: decoded FEC 2/3 bits, packed
-#define DHL_RV     322u                      // 32 words: verdict per owner lane
+// tests/_wave_model.py is the numpy model of these steps (pinned against the oracle on the CPU).
+#define DHL_LIST   0u                        // 64 x 2 words: what the owner lanes know about their deferred packets
+#define DHL_STG    128u                      // 130 words: the round's DM packets as they lie in the stream, 2 G words per group
+#define DHL_PB     258u                      // 64 words: decoded FEC 2/3 bits, packed, G words per group
+#define DHL_RV     322u                      // 32 words: verdict per deferred packet
 static_assert(DH_STAGE_WORDS >= DHL_RV + 32u, "the long-payload phase lives in the wave's input stage");
 typedef __attribute__((address_space(3))) uint64_t dhl_u64_t;
 typedef __attribute__((address_space(3))) uint32_t dhl_u32_t;
+typedef const __attribute__((address_space(1))) uint64_t dhl_g64_t;
 
 // XOR over the 2^logg lanes of a group (3 <= logg <= 6), every lane gets the result
 __device__ __forceinline__ uint32_t group_xor(uint32_t x, uint32_t logg)
@@ -1802,118 +1824,128 @@ __device__ __forceinline__ uint32_t group_xor(uint32_t x, uint32_t logg)
 	return x;
 }
 
-// the register after the matrix whose columns are the sixteen 16-bit halves of c[0..7]
+// the register after the matrix whose columns are the sixteen 16-bit halves of c[0..7]: per pair of register bits
+// two sign-extending bit-field extracts, one byte permute that joins their low / high halves, one and-xor
 __device__ __forceinline__ uint32_t apply_columns(const uint32_t (&c)[8], uint32_t reg)
 {
 	uint32_t x = 0;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		const uint32_t m0 = 0u - ((reg >> (2 * k)) & 1u), m1 = 0u - ((reg >> (2 * k + 1)) & 1u);
-		x ^= c[k] & ((m0 & 0xffffu) | (m1 & 0xffff0000u));
+		const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)reg, 2 * k, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)reg, 2 * k + 1, 1);
+		x ^= c[k] & __builtin_amdgcn_perm(m1, m0, 0x07060100u);
 	}
 	return (x ^ (x >> 16)) & 0xffffu;
 }
 
-// All 64 lanes; `deferred` lanes own a packet (s, nbits = s.def_nbits, nw = its stream words, pkt = its record).
+// All 64 lanes; `deferred` lanes own a packet (s with def_nbits / def_fec set; pkt8 = its record's index in outs).
 // Returns the payload verdict (0 / 2 / 10) to the owner lanes.  `area` = DH_STAGE_WORDS words of LDS of this wave.
 __device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bool deferred, const PState &s,
-					     uint32_t clkn, uint32_t pkt, btbbx_pkt_out *outs, uint32_t lane)
+					     uint32_t clkn, uint32_t pkt8, btbbx_pkt_out *outs, uint32_t lane)
 {
 	dhl_u32_t *const area32 = (dhl_u32_t *)area;
-	// stream words the packet's decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3
-	// blocks may lie behind the captured length (they read as zeros), never behind word 45
-	uint32_t nw = 0;
-	if (deferred) {
-		const uint32_t ext = s.def_fec ? 15u * ((s.def_nbits + 9u) / 10u) : s.def_nbits;
-		nw = (s.sh + 122u + ext + 63u) >> 6;
-	}
-	// lanes per packet
-	const uint32_t logg = __ballot(deferred && nw > 32) ? 6u : __ballot(deferred && nw > 16) ? 5u : __ballot(deferred && nw > 8) ? 4u : 3u;
+	// lanes per packet: one per payload word of the longest payload
+	const uint32_t own_words = deferred ? (s.def_nbits + 63u) >> 6 : 0u;
+	const uint32_t logg = __ballot(own_words > 32) ? 6u : __ballot(own_words > 16) ? 5u : __ballot(own_words > 8) ? 4u : 3u;
 	const uint32_t G = 1u << logg, R = 64u >> logg;
-	const uint32_t sub = lane & (G - 1), grp = lane >> logg;
+	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
 	const uint32_t n_def = (uint32_t)__popcll(dmask);
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
 	if (deferred) {
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
-		const uint32_t widx = wh_start(clkn, 18);
-		area[DHL_LIST + 3 * rank] = (uint64_t)(uintptr_t)s.w;
-		area[DHL_LIST + 3 * rank + 1] = (uint64_t)pkt | (uint64_t)s.sh << 32 | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 38
-			| (uint64_t)(uint32_t)s.length << 45 | (uint64_t)lane << 57;
-		area[DHL_LIST + 3 * rank + 2] = (uint64_t)s.def_nbits | (uint64_t)s.def_fec << 12 | (uint64_t)(whitened(s) ? 1u : 0u) << 13 | (uint64_t)widx << 14
-			| (uint64_t)crc_seed(s.uap) << 21;
+		// stream words the decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3 blocks may
+		// lie behind the captured length (they read as zeros), never behind word 45; nothing behind the stream's end is loaded
+		const uint32_t ext = s.def_fec ? 15u * ((s.def_nbits + 9u) / 10u) : s.def_nbits;
+		const uint32_t nw = (s.sh + 122u + ext + 63u) >> 6;
+		area[DHL_LIST + 2 * rank] = (uint64_t)(uintptr_t)s.w | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 48 | (uint64_t)s.sh << 55;
+		area[DHL_LIST + 2 * rank + 1] = (uint64_t)pkt8 | (uint64_t)(uint32_t)s.length << 8 | (uint64_t)s.def_nbits << 20 | (uint64_t)s.def_fec << 32
+			| (uint64_t)(whitened(s) ? 1u : 0u) << 33 | (uint64_t)wh_start(clkn, 18) << 34 | (uint64_t)(s.uap & 0xffu) << 41;
 	}
 	area[DHL_PB + lane] = 0;
 	if (lane < 2)
-		area[DHL_STG + 64 + lane] = 0;
-	// this lane's matrix: sixteen columns of A^(64 sub)
+		area[DHL_STG + 128 + lane] = 0;
+	// this lane's matrix: sixteen columns of A^(-64 sub)
 	uint32_t col[8];
 	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64) + 2 * sub;
+		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64inv) + 2 * sub;
 		const uint4 a = src[0], b = src[1];
 		col[0] = a.x; col[1] = a.y; col[2] = a.z; col[3] = a.w; col[4] = b.x; col[5] = b.y; col[6] = b.z; col[7] = b.w;
 	}
+	const uint32_t wh_lane = (64u * sub) % 127u;               // whitening phase of word `sub` relative to the payload's first bit
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t rounds = (n_def + R - 1) >> (6 - logg);
-	// the words of round r on their way: stream word `sub` of the group's packet, and -- the lane that will write a
-	// partial last word -- what the record holds there
-	auto request = [&](uint32_t r, uint64_t &wv, uint64_t &old) {
+	// the words of round r on their way: two stream words of the group's packet -- DH: the two that hold payload word
+	// `sub`, DM: words sub and sub + G of the packet -- and, for the lane that will write a partial last word, what the
+	// record holds there
+	auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
 		const uint32_t e = r * R + grp;
-		wv = 0;
-		old = 0;
+		w0 = 0;
+		w1 = 0;
 		if (e < n_def) {
-			const uint64_t a = area[DHL_LIST + 3 * e], b = area[DHL_LIST + 3 * e + 1], c = area[DHL_LIST + 3 * e + 2];
-			const uint32_t p_nw = (uint32_t)(b >> 38) & 127u, p_nbits = (uint32_t)c & 0xfffu;
-			if (sub < p_nw)
-				wv = ((const __attribute__((address_space(1))) uint64_t *)(uintptr_t)a)[sub];
-			if ((p_nbits & 63u) && sub == (p_nbits >> 6))
-				old = outs[(uint32_t)b].payload[sub];
+			const uint64_t a = area[DHL_LIST + 2 * e], b = area[DHL_LIST + 2 * e + 1];
+			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
+			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
+			const bool p_fec = (b >> 32) & 1u;
+			const uint32_t i0 = p_fec ? sub : sub + ((p_sh + 122u) >> 6), i1 = p_fec ? sub + G : i0 + 1u;
+			if (i0 < p_nw)
+				w0 = src[i0];
+			if (i1 < p_nw)
+				w1 = src[i1];
 		}
 	};
-	uint64_t nwv, nold;
-	request(0, nwv, nold);
-	// A round's word is stored at the start of the next round, behind that round's wait for its stream words: gfx9 counts
-	// loads and stores in one in-order counter, so whatever is waited for also waits for every store issued before it --
-	// this way each store and each load has a round's worth of work to complete in.
+	uint64_t nw0, nw1;
+	request(0, nw0, nw1);
+	// a round's word is stored at the start of the next round
 	uint64_t st_val = 0;
 	uint32_t st_pkt = 0;
 	bool st_do = false;
 	for (uint32_t r = 0; r < rounds; r++) {
 		const uint32_t e = r * R + grp;
 		const bool has = e < n_def;
-		uint64_t pb = 0, pc = 0;
+		uint64_t pa = 0, pb = 0;
 		if (has) {
-			pb = area[DHL_LIST + 3 * e + 1];
-			pc = area[DHL_LIST + 3 * e + 2];
+			pa = area[DHL_LIST + 2 * e];
+			pb = area[DHL_LIST + 2 * e + 1];
 		}
-		const uint32_t p_pkt = (uint32_t)pb, p_sh = (uint32_t)(pb >> 32) & 63u, p_len = (uint32_t)(pb >> 45) & 0xfffu, p_owner = (uint32_t)(pb >> 57) & 63u;
-		const uint32_t nbits = (uint32_t)pc & 0xfffu, p_widx = (uint32_t)(pc >> 14) & 127u, p_seed = (uint32_t)(pc >> 21) & 0xffffu;
-		const bool p_fec = (pc >> 12) & 1u, p_wht = (pc >> 13) & 1u;
-		// 1. the stream word, cut at the captured length, into LDS
-		{
-			const uint32_t valid_bits = p_sh + p_len;                   // stream bits of the packet's words that are symbols of the capture
-			const uint32_t here = valid_bits > 64u * sub ? valid_bits - 64u * sub : 0u;
-			uint64_t v = nwv;
-			if (here < 64)
-				v &= (1ULL << here) - 1;
-			area[DHL_STG + lane] = v;
-		}
-		const uint64_t oldw = nold;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		if (st_do)
-			outs[st_pkt].payload[sub] = st_val;
-		if (r + 1 < rounds)
-			request(r + 1, nwv, nold);
-		// 2. payload word `sub` of the packet
-		uint64_t word = 0;
-		bool fail = false;
-		const uint32_t T = nbits >> 6, rem = nbits & 63u, nwp = (nbits + 63u) >> 6;
-		const uint64_t any_fec = __ballot(has && p_fec);
+		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
+		const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
+		const uint32_t p_widx = (uint32_t)(pb >> 34) & 127u, p_uap = (uint32_t)(pb >> 41) & 0xffu;
+		const bool p_fec = has && ((pb >> 32) & 1u), p_wht = (pb >> 33) & 1u;
+		const uint32_t nblocks = (nbits + 9u) / 10u;
+		const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
+		const bool active = has && sub < nwp;
+		// 2a. DH: payload word `sub` is a funnel shift of the lane's two stream words
+		// (computed by every lane, wanted or not: the one wait for the words asked for a round ago then sits here, on every
+		// path, and the compiler needs no second one in front of the next request)
+		const uint32_t sft = (p_sh + 122u) & 63u;
+		const uint64_t funnel = sft ? (nw0 >> sft) | (nw1 << (64u - sft)) : nw0;
+		uint64_t word = has && !p_fec ? funnel : 0ULL;
+		const uint64_t any_fec = __ballot(p_fec);
 		if (any_fec) {
-			if (has && p_fec) {
-				const uint32_t nblocks = (nbits + 9u) / 10u;
-				for (uint32_t b = sub; b < nblocks; b += G) {
-					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 2u * (grp << logg) + (q >> 5);
+			// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
+			uint64_t v0 = nw0, v1 = nw1;
+			if (__ballot(p_fec && 122u + 15u * nblocks > p_len)) {
+				const uint32_t valid = p_sh + p_len;                        // stream bits of the packet's words that are symbols of the capture
+				const uint32_t h0 = valid > 64u * sub ? valid - 64u * sub : 0u, h1 = valid > 64u * (sub + G) ? valid - 64u * (sub + G) : 0u;
+				if (h0 < 64)
+					v0 &= (1ULL << h0) - 1;
+				if (h1 < 64)
+					v1 &= (1ULL << h1) - 1;
+			}
+			area[DHL_STG + 2 * gbase + sub] = v0;
+			area[DHL_STG + 2 * gbase + G + sub] = v1;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		// 2b. DM: the (15,10) blocks of the packet
+		bool fail = false;
+		if (any_fec) {
+			for (uint32_t b0 = 0; ; b0 += G) {
+				const uint32_t b = b0 + sub;
+				const bool on = p_fec && b < nblocks;
+				if (!__ballot(on))
+					break;
+				if (on) {
+					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
 					const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
 					uint32_t data = blk & 0x3ffu;
 					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
@@ -1922,7 +1954,10 @@ __device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bo
 						fail = true;
 					if (fix >= 0)
 						data ^= 1u << fix;
-					const uint32_t bit = 10u * b, d = 2u * DHL_PB + 2u * (grp << logg) + (bit >> 5), sft = bit & 31u;
+					const uint32_t bit = 10u * b, left = nbits - bit;
+					if (left < 10)
+						data &= (1u << left) - 1;                               // (nothing behind payload_length reaches the packed words)
+					const uint32_t d = 2u * DHL_PB + 2u * gbase + (bit >> 5), sft = bit & 31u;
 					__hip_atomic_fetch_or(area32 + d, data << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 					if (sft > 22)
 						__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1930,45 +1965,36 @@ __device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bo
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-		}
-		if (has && p_fec) {
-			word = area[DHL_PB + lane];
-		} else if (has) {
-			const uint32_t q = p_sh + 122u + 64u * sub, i = DHL_STG + (grp << logg) + (q >> 6), sft = q & 63u;
-			const uint64_t lo = area[i], hi = area[i + 1];
-			word = sft ? (lo >> sft) | (hi << (64u - sft)) : lo;
-		}
-		if (any_fec)
+			if (p_fec)
+				word = area[DHL_PB + lane];
 			area[DHL_PB + lane] = 0;                                // the packed bits are consumed: ready for the next round
+		}
+		// the stream words are used up: the previous round's word goes out, the next round's words are asked for, and the
+		// lane that writes a partial last word asks for what the record holds there (used at the end of the round) --
+		// all of it behind the last wait of this round for memory, in front of ~150 instructions that need none
+		if (st_do)
+			outs[st_pkt].payload[sub] = st_val;
+		if (r + 1 < rounds)
+			request(r + 1, nw0, nw1);
+		uint64_t oldw = 0;
+		if (active && sub == T)
+			oldw = outs[p_pkt].payload[sub];
 		const uint64_t fail_mask = __ballot(fail);
-		const bool group_fail = ((fail_mask >> (grp << logg)) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
+		const bool group_fail = ((fail_mask >> gbase) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
 		// 3. unwhitened, cut at the payload length
-		const bool active = has && sub < nwp;
 		uint64_t out = 0, keep_mask = ~0ULL;
 		if (active) {
-			const uint32_t idx = (p_widx + 64u * sub) % 127u;
+			uint32_t idx = p_widx + wh_lane;
+			idx = idx >= 127u ? idx - 127u : idx;
 			const uint64_t wbits = p_wht ? wh_bits(idx, 64) : 0ULL;
-			if (sub == T)                                             // (only when rem != 0)
-				keep_mask = (1ULL << rem) - 1;
+			if (sub == T)                                             // (a partial last word: nbits & 63 != 0)
+				keep_mask = (1ULL << (nbits & 63u)) - 1;
 			out = (word ^ wbits) & keep_mask;
 		}
-		// 4. CRC: end-aligned blocks through LDS (the staged stream words are used up)
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		area[DHL_STG + lane] = out ^ (sub == 0 ? (uint64_t)p_seed : 0ULL);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		uint32_t reg = 0;
-		if (has && sub < nwp) {
-			// block `sub` ends 64 sub bits in front of the payload's end: bits of words T - sub - 1 (from bit rem) and T - sub
-			const int ia = (int)T - (int)sub - 1, ib = (int)T - (int)sub;
-			const uint32_t base = DHL_STG + (grp << logg);
-			const uint64_t wa = ia >= 0 ? area[base + (uint32_t)ia] : 0ULL;
-			const uint64_t wb = (rem && ib >= 0) ? area[base + (uint32_t)ib] : 0ULL;
-			const uint64_t block = rem ? (wa >> rem) | (wb << (64u - rem)) : wa;
-			reg = crc_word(crc_word(0, (uint32_t)block), (uint32_t)(block >> 32));
-			reg = apply_columns(col, reg);
-		}
+		// 4. CRC: the word alone (the seed's bits on the first sixteen of the payload), carried back over the words in front of it
+		const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
+		uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+		reg = apply_columns(col, reg);
 		const uint32_t total = group_xor(reg, logg);
 		int rv = total == 0 ? 10 : 2;
 		if (p_fec && group_fail)
@@ -1978,13 +2004,13 @@ __device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bo
 		st_val = sub == T ? out | (oldw & ~keep_mask) : out;
 		st_pkt = p_pkt;
 		if (has && sub == 0)
-			area32[2u * DHL_RV + p_owner] = (uint32_t)rv;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+			area32[2u * DHL_RV + e] = (uint32_t)rv;
 	}
 	if (st_do)
 		outs[st_pkt].payload[sub] = st_val;
-	return deferred ? (int)area32[2u * DHL_RV + lane] : 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	return deferred ? (int)area32[2u * DHL_RV + rank] : 0;
 }
 
 #ifndef DH_WAVES_PER_EU
@@ -2106,7 +2132,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			// payloads that go to the wave phase (long_payloads): together, by the lanes a packet takes there (keys that
 			// are all but unused otherwise: class 0 has one length, HV packets that are not cut short another)
 			if (DH_LONG_PHASE && !small && want > 126 && (cls == 2 || cls == 3)) {
-				const uint32_t words = (s.sh + want + 63) >> 6;
+				const uint32_t pbits = cls == 2 ? (want - 122) / 15 * 10 : want - 122, words = (pbits + 63) >> 6;   // (about: the grouping only)
 				key = (cls == 2 ? 32u : 1u) + (words > 32 ? 3u : words > 16 ? 2u : words > 8 ? 1u : 0u);
 			}
 		}
@@ -2241,16 +2267,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		decode_view(s, pi, outs + pkt, mode,
 			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head, head_in DH_PASS);
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
-	{
-		// payloads the lanes left to the wave (DM3 / DH3 / DM5 / DH5 beyond 256 bits): a group of lanes per packet
-		const bool deferred = live && s.def_nbits != 0;
-		const uint64_t dmask = __ballot(deferred);
-		if (dmask) {
-			const int rv = long_payloads((dhl_u64_t *)(lds_u64_t *)(&stage[wave][0]), dmask, deferred, s, pi.clkn, pkt, outs, lane);
-			if (deferred)
-				head[0] = (head[0] & 0xffffffffULL) | (uint64_t)(uint32_t)rv << 32;      // payload_rv
-		}
-	}
 	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
 	for (int k = 0; k < 5; k++)
@@ -2269,6 +2285,21 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 	}
 	DH_MARK(7);                                         // decoded, results stored
+	{
+		// Payloads the lanes left to the wave (DM3 / DH3 / DM5 / DH5 beyond 256 bits): a group of lanes per packet, in the
+		// wave's input stage -- behind the store phase, so that the records' heads are out of the registers; the verdict
+		// goes into the record by itself (one dword; the wave's stores to one address arrive in order).
+		const bool deferred = live && s.def_nbits != 0;
+		const uint64_t dmask = __ballot(deferred);
+		if (dmask) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			const int rv = long_payloads((dhl_u64_t *)(lds_u64_t *)(&stage[wave][0]), dmask, deferred, s, pi.clkn, pkt - blockIdx.x * blockDim.x,
+						     outs + blockIdx.x * blockDim.x, lane);
+			if (deferred)
+				outs[pkt].payload_rv = rv;
+		}
+	}
 #ifdef DH_PROFILE
 	if (lane == 0)
 		for (int k = 0; k < 8; k++)

@@ -118,6 +118,7 @@ def dh_wave(sym, clk6, uap, ptype):
         return 2, payload
     ok = _wave_crc_is_zero(words, nbits, uap)
     assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
+    assert ok == wave_crc_is_zero_start_aligned([_int_of(w) for w in words], nbits, uap)
     return (10 if ok else 2), payload
 
 
@@ -195,6 +196,7 @@ def dm_wave(sym, clk6, uap, ptype):
     payload = np.concatenate(words)[:nbits] if words else np.zeros(0, np.uint8)
     ok = _wave_crc_is_zero(words, nbits, uap)
     assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
+    assert ok == wave_crc_is_zero_start_aligned([_int_of(w) for w in words], nbits, uap)
     return (10 if ok else 2), payload
 
 
@@ -218,4 +220,40 @@ def wave_crc_is_zero_u64(words, nbits, uap):
         else:
             block = get(T - 1 - lane)
         total ^= _apply(adv[lane], _crc_step_bits(0, _bits_of(block)))
+    return total == 0
+
+
+_ADV64INV = None
+
+
+def _adv64inv():
+    """Lane l's constant in the kernel as built (csrc/packet.hip long_payloads): A^(-64 l) as sixteen 16-bit columns, A = one
+    zero bit through the register.  Found like the library finds it: run every register value forward over 64 zero bits and
+    read the map backwards."""
+    global _ADV64INV
+    if _ADV64INV is None:
+        step = _advance_matrix(64)
+        back = {}
+        for u in range(1 << 16):
+            back[_apply(step, u)] = u
+        assert len(back) == 1 << 16                                   # the step is invertible
+        inv = [back[1 << j] for j in range(16)]
+        mats = [[1 << j for j in range(16)]]
+        for _ in range(1, LANES):
+            mats.append([_apply(inv, c) for c in mats[-1]])
+        _ADV64INV = mats
+    return _ADV64INV
+
+
+def wave_crc_is_zero_start_aligned(words, nbits, uap):
+    """The form the kernel runs: no lane needs another lane's word.  words[w] as in wave_crc_is_zero_u64 (zero behind nbits).
+    Appending zero bits advances the register by an invertible map, so `register == 0` may be tested on the payload padded
+    to whole words; the seed is its bits on the first sixteen message bits; and the register after n words is A^(64 (n - 1))
+    of the XOR over the words of A^(-64 w) (register of word w alone) -- again an invertible outer factor."""
+    inv = _adv64inv()
+    total = 0
+    for lane, word in enumerate(words):
+        if lane == 0:
+            word ^= _seed(uap)
+        total ^= _apply(inv[lane], _crc_step_bits(0, _bits_of(word)))
     return total == 0
