@@ -19,6 +19,8 @@
 // leaves UAP/type from the previous trial (:1186-1187).
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <type_traits>
 #include "common.h"
 #include "packet_obj.h"
 
@@ -398,9 +400,10 @@ struct PState {
 	bool spoiled = false;    // out is the caller's scratch copy (LDS) and holds a payload the reference would not have written
 	// decode_hits_kernel: a DM / DH payload of more than 256 bits is not walked by its lane; do_DM / do_DH return after
 	// their checks with the bit count here and the wave works it off afterwards, a group of lanes per packet (long_payloads)
-	bool defer_ok = false;
-	bool def_fec = false;
-	uint32_t def_nbits = 0;
+	// (decode_long_kernel); the sixteen bytes that kernel needs to know go straight into def_slot from here
+	uint4 *def_slot = nullptr;   // where (null: every payload is walked by its lane)
+	uint32_t def_pkt8 = 0;       // the record's index in its workgroup's 256
+	uint32_t def_nbits = 0;      // != 0: deferred
 	uint32_t written;        // payload bits written (prefix)
 	// which fields a trial assigned (replay_kernel merges 64 trials by "last writer wins")
 	uint32_t dirty;          // D_* bits
@@ -522,6 +525,23 @@ __device__ __forceinline__ bool fec23_ok(const PState &s, uint32_t pos, uint32_t
 			return false;
 	}
 	return true;
+}
+
+// The payload of s (nbits bits, FEC 2/3 or not) is left to decode_long_kernel: what that kernel needs, sixteen bytes.
+//   a: address of the stream word the packet starts in | stream words to load << 48 | bit the packet starts at << 55
+//   b: record index | captured length << 8 | payload bits << 20 | fec << 32 | whitened << 33 | whitening phase of the
+//      payload's first bit << 34 | UAP << 41
+__device__ __forceinline__ void defer_payload(PState &s, uint32_t clock, uint32_t nbits, bool fec)
+{
+	// stream words the decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3 blocks may
+	// lie behind the captured length (they read as zeros), never behind word 45; nothing behind the stream's end is loaded
+	const uint32_t ext = fec ? 15u * ((nbits + 9u) / 10u) : nbits;
+	const uint32_t nw = (s.sh + 122u + ext + 63u) >> 6;
+	const uint64_t a = (uint64_t)(uintptr_t)s.w | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 48 | (uint64_t)s.sh << 55;
+	const uint64_t b = (uint64_t)s.def_pkt8 | (uint64_t)(uint32_t)s.length << 8 | (uint64_t)nbits << 20 | (uint64_t)fec << 32
+		| (uint64_t)((s.flags & 1u) ? 1u : 0u) << 33 | (uint64_t)wh_start(clock, 18) << 34 | (uint64_t)(s.uap & 0xffu) << 41;
+	*s.def_slot = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+	s.def_nbits = nbits;
 }
 
 // fhs (:783-818)
@@ -676,10 +696,9 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 	if (nbits > size)
 		return 1;
 	uint32_t nblocks = (nbits + 9) / 10;
-	if (WRITE && s.defer_ok && !s.out.l && nbits > DHL_MIN_BITS) {
-		s.def_nbits = (uint32_t)nbits;
-		s.def_fec = true;
-		return 2;                                           // (replaced by long_payloads' verdict)
+	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
+		defer_payload(s, clock, (uint32_t)nbits, true);
+		return 2;                                           // (replaced by decode_long_kernel's verdict)
 	}
 	// The reference writes nothing when a block fails.  Into HBM that takes a pass over all blocks first; a scratch copy
 	// is written as the blocks decode and marked as not to be kept when one fails.
@@ -735,10 +754,9 @@ __device__ __forceinline__ int do_DH(PState &s, uint32_t clock)
 	int nbits = s.plen * 8;
 	if (nbits > size)
 		return 1;
-	if (WRITE && s.defer_ok && !s.out.l && nbits > DHL_MIN_BITS) {
-		s.def_nbits = (uint32_t)nbits;
-		s.def_fec = false;
-		return 2;                                           // (replaced by long_payloads' verdict)
+	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
+		defer_payload(s, clock, (uint32_t)nbits, false);
+		return 2;                                           // (replaced by decode_long_kernel's verdict)
 	}
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
@@ -1800,11 +1818,13 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 //      another lane's word, whatever the payload length;
 //   5. stores its word (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
 // tests/_wave_model.py is the numpy model of these steps (pinned against the oracle on the CPU).
+#ifndef DHL_UNIFORM
+#define DHL_UNIFORM 1                        // a second copy of the round loop for one packet per round, its facts in scalar registers
+#endif
 #define DHL_LIST   0u                        // 64 x 2 words: what the owner lanes know about their deferred packets
 #define DHL_STG    128u                      // 130 words: the round's DM packets as they lie in the stream, 2 G words per group
 #define DHL_PB     258u                      // 64 words: decoded FEC 2/3 bits, packed, G words per group
-#define DHL_RV     322u                      // 32 words: verdict per deferred packet
-static_assert(DH_STAGE_WORDS >= DHL_RV + 32u, "the long-payload phase lives in the wave's input stage");
+#define DHL_WORDS  322u
 typedef __attribute__((address_space(3))) uint64_t dhl_u64_t;
 typedef __attribute__((address_space(3))) uint32_t dhl_u32_t;
 typedef const __attribute__((address_space(1))) uint64_t dhl_g64_t;
@@ -1837,28 +1857,13 @@ __device__ __forceinline__ uint32_t apply_columns(const uint32_t (&c)[8], uint32
 	return (x ^ (x >> 16)) & 0xffffu;
 }
 
-// All 64 lanes; `deferred` lanes own a packet (s with def_nbits / def_fec set; pkt8 = its record's index in outs).
-// Returns the payload verdict (0 / 2 / 10) to the owner lanes.  `area` = DH_STAGE_WORDS words of LDS of this wave.
-__device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bool deferred, const PState &s,
-					     uint32_t clkn, uint32_t pkt8, btbbx_pkt_out *outs, uint32_t lane)
+// All 64 lanes of a wave of decode_long_kernel; the wave's n_def list entries (DHL_LIST) are in LDS.  `area` = DHL_WORDS
+// words of LDS of this wave, `outs` = the records of the workgroup of decode_hits_kernel that deferred the packets.
+__device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
 {
 	dhl_u32_t *const area32 = (dhl_u32_t *)area;
-	// lanes per packet: one per payload word of the longest payload
-	const uint32_t own_words = deferred ? (s.def_nbits + 63u) >> 6 : 0u;
-	const uint32_t logg = __ballot(own_words > 32) ? 6u : __ballot(own_words > 16) ? 5u : __ballot(own_words > 8) ? 4u : 3u;
 	const uint32_t G = 1u << logg, R = 64u >> logg;
 	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
-	const uint32_t n_def = (uint32_t)__popcll(dmask);
-	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
-	if (deferred) {
-		// stream words the decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3 blocks may
-		// lie behind the captured length (they read as zeros), never behind word 45; nothing behind the stream's end is loaded
-		const uint32_t ext = s.def_fec ? 15u * ((s.def_nbits + 9u) / 10u) : s.def_nbits;
-		const uint32_t nw = (s.sh + 122u + ext + 63u) >> 6;
-		area[DHL_LIST + 2 * rank] = (uint64_t)(uintptr_t)s.w | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 48 | (uint64_t)s.sh << 55;
-		area[DHL_LIST + 2 * rank + 1] = (uint64_t)pkt8 | (uint64_t)(uint32_t)s.length << 8 | (uint64_t)s.def_nbits << 20 | (uint64_t)s.def_fec << 32
-			| (uint64_t)(whitened(s) ? 1u : 0u) << 33 | (uint64_t)wh_start(clkn, 18) << 34 | (uint64_t)(s.uap & 0xffu) << 41;
-	}
 	area[DHL_PB + lane] = 0;
 	if (lane < 2)
 		area[DHL_STG + 128 + lane] = 0;
@@ -1873,144 +1878,187 @@ __device__ __forceinline__ int long_payloads(dhl_u64_t *area, uint64_t dmask, bo
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t rounds = (n_def + R - 1) >> (6 - logg);
-	// the words of round r on their way: two stream words of the group's packet -- DH: the two that hold payload word
-	// `sub`, DM: words sub and sub + G of the packet -- and, for the lane that will write a partial last word, what the
-	// record holds there
-	auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
-		const uint32_t e = r * R + grp;
-		w0 = 0;
-		w1 = 0;
-		if (e < n_def) {
-			const uint64_t a = area[DHL_LIST + 2 * e], b = area[DHL_LIST + 2 * e + 1];
-			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
-			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
-			const bool p_fec = (b >> 32) & 1u;
-			const uint32_t i0 = p_fec ? sub : sub + ((p_sh + 122u) >> 6), i1 = p_fec ? sub + G : i0 + 1u;
-			if (i0 < p_nw)
-				w0 = src[i0];
-			if (i1 < p_nw)
-				w1 = src[i1];
-		}
-	};
-	uint64_t nw0, nw1;
-	request(0, nw0, nw1);
-	// a round's word is stored at the start of the next round
-	uint64_t st_val = 0;
-	uint32_t st_pkt = 0;
-	bool st_do = false;
-	for (uint32_t r = 0; r < rounds; r++) {
-		const uint32_t e = r * R + grp;
-		const bool has = e < n_def;
-		uint64_t pa = 0, pb = 0;
-		if (has) {
-			pa = area[DHL_LIST + 2 * e];
-			pb = area[DHL_LIST + 2 * e + 1];
-		}
-		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
-		const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
-		const uint32_t p_widx = (uint32_t)(pb >> 34) & 127u, p_uap = (uint32_t)(pb >> 41) & 0xffu;
-		const bool p_fec = has && ((pb >> 32) & 1u), p_wht = (pb >> 33) & 1u;
-		const uint32_t nblocks = (nbits + 9u) / 10u;
-		const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
-		const bool active = has && sub < nwp;
-		// 2a. DH: payload word `sub` is a funnel shift of the lane's two stream words
-		// (computed by every lane, wanted or not: the one wait for the words asked for a round ago then sits here, on every
-		// path, and the compiler needs no second one in front of the next request)
-		const uint32_t sft = (p_sh + 122u) & 63u;
-		const uint64_t funnel = sft ? (nw0 >> sft) | (nw1 << (64u - sft)) : nw0;
-		uint64_t word = has && !p_fec ? funnel : 0ULL;
-		const uint64_t any_fec = __ballot(p_fec);
-		if (any_fec) {
-			// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
-			uint64_t v0 = nw0, v1 = nw1;
-			if (__ballot(p_fec && 122u + 15u * nblocks > p_len)) {
-				const uint32_t valid = p_sh + p_len;                        // stream bits of the packet's words that are symbols of the capture
-				const uint32_t h0 = valid > 64u * sub ? valid - 64u * sub : 0u, h1 = valid > 64u * (sub + G) ? valid - 64u * (sub + G) : 0u;
-				if (h0 < 64)
-					v0 &= (1ULL << h0) - 1;
-				if (h1 < 64)
-					v1 &= (1ULL << h1) - 1;
+	// One packet per round (G = 64: DH5, the longest DH3): everything the round knows about its packet is the same in all
+	// lanes -- read once, kept in scalar registers, unpacked by the scalar unit (`uni`); the loop exists twice for that.
+	auto run = [&](auto uniform_t) {
+		constexpr bool UNI = decltype(uniform_t)::value;
+		auto uni = [&](uint64_t v) -> uint64_t {
+			if (!UNI)
+				return v;
+			return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v)
+				| (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+		};
+		// the words of round r on their way: two stream words of the group's packet -- DH: the two that hold payload word
+		// `sub`, DM: words sub and sub + G of the packet -- and, for the lane that will write a partial last word, what the
+		// record holds there
+		auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
+			const uint32_t e = r * R + grp;
+			w0 = 0;
+			w1 = 0;
+			if (e < n_def) {
+				const uint64_t a = uni(area[DHL_LIST + 2 * e]), b = uni(area[DHL_LIST + 2 * e + 1]);
+				dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
+				const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
+				const bool p_fec = (b >> 32) & 1u;
+				const uint32_t i0 = p_fec ? sub : sub + ((p_sh + 122u) >> 6), i1 = p_fec ? sub + G : i0 + 1u;
+				if (i0 < p_nw)
+					w0 = src[i0];
+				if (i1 < p_nw)
+					w1 = src[i1];
 			}
-			area[DHL_STG + 2 * gbase + sub] = v0;
-			area[DHL_STG + 2 * gbase + G + sub] = v1;
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-		}
-		// 2b. DM: the (15,10) blocks of the packet
-		bool fail = false;
-		if (any_fec) {
-			for (uint32_t b0 = 0; ; b0 += G) {
-				const uint32_t b = b0 + sub;
-				const bool on = p_fec && b < nblocks;
-				if (!__ballot(on))
-					break;
-				if (on) {
-					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
-					const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
-					uint32_t data = blk & 0x3ffu;
-					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
-					const int fix = g_lds.fix23[diff & 31u];
-					if (fix == -2)
-						fail = true;
-					if (fix >= 0)
-						data ^= 1u << fix;
-					const uint32_t bit = 10u * b, left = nbits - bit;
-					if (left < 10)
-						data &= (1u << left) - 1;                               // (nothing behind payload_length reaches the packed words)
-					const uint32_t d = 2u * DHL_PB + 2u * gbase + (bit >> 5), sft = bit & 31u;
-					__hip_atomic_fetch_or(area32 + d, data << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					if (sft > 22)
-						__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		};
+		uint64_t nw0, nw1;
+		request(0, nw0, nw1);
+		// a round's word is stored at the start of the next round
+		uint64_t st_val = 0;
+		uint32_t st_pkt = 0;
+		bool st_do = false;
+		for (uint32_t r = 0; r < rounds; r++) {
+			const uint32_t e = r * R + grp;
+			const bool has = e < n_def;
+			uint64_t pa = 0, pb = 0;
+			if (has) {
+				pa = uni(area[DHL_LIST + 2 * e]);
+				pb = uni(area[DHL_LIST + 2 * e + 1]);
+			}
+			const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
+			const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
+			const uint32_t p_widx = (uint32_t)(pb >> 34) & 127u, p_uap = (uint32_t)(pb >> 41) & 0xffu;
+			const bool p_fec = has && ((pb >> 32) & 1u), p_wht = (pb >> 33) & 1u;
+			const uint32_t nblocks = (nbits + 9u) / 10u;
+			const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
+			const bool active = has && sub < nwp;
+			// 2a. DH: payload word `sub` is a funnel shift of the lane's two stream words
+			// (computed by every lane, wanted or not: the one wait for the words asked for a round ago then sits here, on every
+			// path, and the compiler needs no second one in front of the next request)
+			const uint32_t sft = (p_sh + 122u) & 63u;
+			const uint64_t funnel = sft ? (nw0 >> sft) | (nw1 << (64u - sft)) : nw0;
+			uint64_t word = has && !p_fec ? funnel : 0ULL;
+			const uint64_t any_fec = __ballot(p_fec);
+			if (any_fec) {
+				// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
+				uint64_t v0 = nw0, v1 = nw1;
+				if (__ballot(p_fec && 122u + 15u * nblocks > p_len)) {
+					const uint32_t valid = p_sh + p_len;                        // stream bits of the packet's words that are symbols of the capture
+					const uint32_t h0 = valid > 64u * sub ? valid - 64u * sub : 0u, h1 = valid > 64u * (sub + G) ? valid - 64u * (sub + G) : 0u;
+					if (h0 < 64)
+						v0 &= (1ULL << h0) - 1;
+					if (h1 < 64)
+						v1 &= (1ULL << h1) - 1;
 				}
+				area[DHL_STG + 2 * gbase + sub] = v0;
+				area[DHL_STG + 2 * gbase + G + sub] = v1;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			if (p_fec)
-				word = area[DHL_PB + lane];
-			area[DHL_PB + lane] = 0;                                // the packed bits are consumed: ready for the next round
+			// 2b. DM: the (15,10) blocks of the packet
+			bool fail = false;
+			if (any_fec) {
+				for (uint32_t b0 = 0; ; b0 += G) {
+					const uint32_t b = b0 + sub;
+					const bool on = p_fec && b < nblocks;
+					if (!__ballot(on))
+						break;
+					if (on) {
+						const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
+						const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
+						uint32_t data = blk & 0x3ffu;
+						const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
+						const int fix = g_lds.fix23[diff & 31u];
+						if (fix == -2)
+							fail = true;
+						if (fix >= 0)
+							data ^= 1u << fix;
+						const uint32_t bit = 10u * b, left = nbits - bit;
+						if (left < 10)
+							data &= (1u << left) - 1;                               // (nothing behind payload_length reaches the packed words)
+						const uint32_t d = 2u * DHL_PB + 2u * gbase + (bit >> 5), sft = bit & 31u;
+						__hip_atomic_fetch_or(area32 + d, data << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+						if (sft > 22)
+							__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				if (p_fec)
+					word = area[DHL_PB + lane];
+				area[DHL_PB + lane] = 0;                                // the packed bits are consumed: ready for the next round
+			}
+			// the stream words are used up: the previous round's word goes out, the next round's words are asked for, and the
+			// lane that writes a partial last word asks for what the record holds there (used at the end of the round) --
+			// all of it behind the last wait of this round for memory, in front of ~150 instructions that need none
+			if (st_do)
+				outs[st_pkt].payload[sub] = st_val;
+			if (r + 1 < rounds)
+				request(r + 1, nw0, nw1);
+			uint64_t oldw = 0;
+			if (active && sub == T)
+				oldw = outs[p_pkt].payload[sub];
+			const uint64_t fail_mask = __ballot(fail);
+			const bool group_fail = ((fail_mask >> gbase) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
+			// 3. unwhitened, cut at the payload length
+			uint64_t out = 0, keep_mask = ~0ULL;
+			if (active) {
+				uint32_t idx = p_widx + wh_lane;
+				idx = idx >= 127u ? idx - 127u : idx;
+				const uint64_t wbits = p_wht ? wh_bits(idx, 64) : 0ULL;
+				if (sub == T)                                             // (a partial last word: nbits & 63 != 0)
+					keep_mask = (1ULL << (nbits & 63u)) - 1;
+				out = (word ^ wbits) & keep_mask;
+			}
+			// 4. CRC: the word alone (the seed's bits on the first sixteen of the payload), carried back over the words in front of it
+			const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
+			uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+			reg = apply_columns(col, reg);
+			const uint32_t total = group_xor(reg, logg);
+			int rv = total == 0 ? 10 : 2;
+			if (p_fec && group_fail)
+				rv = 0;
+			// 5. out (nothing when a block failed)
+			st_do = active && rv != 0;
+			st_val = sub == T ? out | (oldw & ~keep_mask) : out;
+			st_pkt = p_pkt;
+			if (has && sub == 0)
+				outs[p_pkt].payload_rv = rv;                            // (decode_hits_kernel left a placeholder)
 		}
-		// the stream words are used up: the previous round's word goes out, the next round's words are asked for, and the
-		// lane that writes a partial last word asks for what the record holds there (used at the end of the round) --
-		// all of it behind the last wait of this round for memory, in front of ~150 instructions that need none
 		if (st_do)
 			outs[st_pkt].payload[sub] = st_val;
-		if (r + 1 < rounds)
-			request(r + 1, nw0, nw1);
-		uint64_t oldw = 0;
-		if (active && sub == T)
-			oldw = outs[p_pkt].payload[sub];
-		const uint64_t fail_mask = __ballot(fail);
-		const bool group_fail = ((fail_mask >> gbase) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
-		// 3. unwhitened, cut at the payload length
-		uint64_t out = 0, keep_mask = ~0ULL;
-		if (active) {
-			uint32_t idx = p_widx + wh_lane;
-			idx = idx >= 127u ? idx - 127u : idx;
-			const uint64_t wbits = p_wht ? wh_bits(idx, 64) : 0ULL;
-			if (sub == T)                                             // (a partial last word: nbits & 63 != 0)
-				keep_mask = (1ULL << (nbits & 63u)) - 1;
-			out = (word ^ wbits) & keep_mask;
-		}
-		// 4. CRC: the word alone (the seed's bits on the first sixteen of the payload), carried back over the words in front of it
-		const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
-		uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
-		reg = apply_columns(col, reg);
-		const uint32_t total = group_xor(reg, logg);
-		int rv = total == 0 ? 10 : 2;
-		if (p_fec && group_fail)
-			rv = 0;
-		// 5. out (nothing when a block failed)
-		st_do = active && rv != 0;
-		st_val = sub == T ? out | (oldw & ~keep_mask) : out;
-		st_pkt = p_pkt;
-		if (has && sub == 0)
-			area32[2u * DHL_RV + e] = (uint32_t)rv;
+	};
+#if DHL_UNIFORM
+	if (logg == 6)
+		run(std::true_type{});
+	else
+#endif
+		run(std::false_type{});
+}
+
+// One workgroup per workgroup of decode_hits_kernel, wave w takes what wave w of that workgroup left: hdr[4 b + w] = which
+// of its 64 list slots list[(4 b + w) * 64 ..] are filled (defer_payload).  Workgroups with nothing to do leave after two
+// scalar loads; the hardware's dispatcher balances the rest.  Lanes per packet = one per payload word of the wave's longest
+// payload (the sort of decode_hits_kernel keeps like with like).
+__global__ __launch_bounds__(256) void decode_long_kernel(const uint4 *list, const uint64_t *hdr, btbbx_pkt_out *outs)
+{
+	__shared__ uint64_t larea[4][DHL_WORDS];
+	const uint64_t m0 = hdr[blockIdx.x * 4], m1 = hdr[blockIdx.x * 4 + 1], m2 = hdr[blockIdx.x * 4 + 2], m3 = hdr[blockIdx.x * 4 + 3];
+	if (!(m0 | m1 | m2 | m3))
+		return;
+	chain_lds_init();
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint64_t dmask = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
+	if (!dmask)
+		return;
+	dhl_u64_t *const area = (dhl_u64_t *)&larea[wave][0];
+	const bool mine = (dmask >> lane) & 1;
+	uint32_t own_words = 0;
+	if (mine) {
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
+		const uint4 e = list[(size_t)(blockIdx.x * 4 + wave) * 64 + lane];
+		area[DHL_LIST + 2 * rank] = (uint64_t)e.x | (uint64_t)e.y << 32;
+		area[DHL_LIST + 2 * rank + 1] = (uint64_t)e.z | (uint64_t)e.w << 32;
+		own_words = (((e.z >> 20) & 0xfffu) + 63u) >> 6;
 	}
-	if (st_do)
-		outs[st_pkt].payload[sub] = st_val;
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	return deferred ? (int)area32[2u * DHL_RV + rank] : 0;
+	const uint32_t logg = __ballot(own_words > 32) ? 6u : __ballot(own_words > 16) ? 5u : __ballot(own_words > 8) ? 4u : 3u;
+	long_payloads(area, (uint32_t)__popcll(dmask), logg, outs + (size_t)blockIdx.x * 256, lane);
 }
 
 #ifndef DH_WAVES_PER_EU
@@ -2023,7 +2071,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH_WAVES_PE
 void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
 							  const uint32_t *d_count, uint32_t max_length, btbbx_pkt_out *outs,
-							  uint32_t *lengths, uint32_t mode, btbbx_pkt_in one_in, uint32_t clk_div)
+							  uint32_t *lengths, uint32_t mode, btbbx_pkt_in one_in, uint32_t clk_div,
+							  uint4 *long_list, uint32_t *long_hdr)
 {
 	__shared__ uint64_t stage[4][DH_STAGE_WORDS];
 	__shared__ uint64_t ostage[4][64 * DH_OUT_WORDS];
@@ -2033,8 +2082,11 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
 		n_packets = min(n_packets, *d_count);
 	bool live = pkt < n_packets;
-	if (blockIdx.x * blockDim.x >= n_packets)
+	if (blockIdx.x * blockDim.x >= n_packets) {
+		if (long_hdr && lane == 0)
+			reinterpret_cast<uint64_t *>(long_hdr)[blockIdx.x * 4 + wave] = 0;      // (decode_long_kernel is launched for the capacity too)
 		return;
+	}
 #ifdef DH_PROFILE
 	uint32_t dh_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t dh_t;
@@ -2262,11 +2314,20 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	DH_MARK(2);                                         // packets staged
 
 	uint64_t head[5] = {0, 0, 0, 0, 0};
-	s.defer_ok = DH_LONG_PHASE;
+	if (long_list) {
+		s.def_slot = long_list + ((size_t)(blockIdx.x * 4 + wave) * 64 + lane);
+		s.def_pkt8 = pkt - blockIdx.x * blockDim.x;
+	}
 	if (live)
 		decode_view(s, pi, outs + pkt, mode,
 			    small ? OutRef::lds((uint32_t)(uintptr_t)(lds_u64_t *)(&ostage[wave][lane * DH_OUT_WORDS])) : OutRef(), head, head_in DH_PASS);
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
+	if (long_hdr) {
+		// which of the wave's 64 list slots hold a payload that was left to decode_long_kernel (do_DM / do_DH, defer_payload)
+		const uint64_t dmask = __ballot(live && s.def_nbits != 0);
+		if (lane == 0)
+			reinterpret_cast<uint64_t *>(long_hdr)[blockIdx.x * 4 + wave] = dmask;
+	}
 	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
 	for (int k = 0; k < 5; k++)
@@ -2285,21 +2346,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 	}
 	DH_MARK(7);                                         // decoded, results stored
-	{
-		// Payloads the lanes left to the wave (DM3 / DH3 / DM5 / DH5 beyond 256 bits): a group of lanes per packet, in the
-		// wave's input stage -- behind the store phase, so that the records' heads are out of the registers; the verdict
-		// goes into the record by itself (one dword; the wave's stores to one address arrive in order).
-		const bool deferred = live && s.def_nbits != 0;
-		const uint64_t dmask = __ballot(deferred);
-		if (dmask) {
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			const int rv = long_payloads((dhl_u64_t *)(lds_u64_t *)(&stage[wave][0]), dmask, deferred, s, pi.clkn, pkt - blockIdx.x * blockDim.x,
-						     outs + blockIdx.x * blockDim.x, lane);
-			if (deferred)
-				outs[pkt].payload_rv = rv;
-		}
-	}
 #ifdef DH_PROFILE
 	if (lane == 0)
 		for (int k = 0; k < 8; k++)
@@ -2739,6 +2785,51 @@ extern "C" int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in
 	return launch_decode(d_packets, d_in, n_packets, d_out, DEC_HEADER | DEC_PAYLOAD, nullptr, (hipStream_t)hip_stream);
 }
 
+// decode_hits_kernel, then decode_long_kernel over the lists it left (DM / DH payloads beyond 256 bits).  The lists live in
+// a block from the device's stream-ordered pool -- asked for and given back on the caller's stream, so concurrent callers
+// on other streams share nothing and nothing is synchronised; the pool keeps what it has (release threshold raised once).
+static int launch_decode_hits(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, const btbbx_hit *d_hits,
+			      const btbbx_pkt_in *d_in, uint32_t n_packets, const uint32_t *d_count, uint32_t max_length,
+			      btbbx_pkt_out *d_out, uint32_t *d_lengths, const btbbx_pkt_in &one_in, uint32_t clk_div, hipStream_t stream)
+{
+	const uint32_t groups = (uint32_t)(((uint64_t)n_packets + 255) / 256);
+	uint4 *list = nullptr;
+	uint32_t *hdr = nullptr;
+	void *block = nullptr;
+#if DH_LONG_PHASE
+	{
+		static std::atomic<uint64_t> pool_ready{0};
+		int dev = 0;
+		HIP_TRY(hipGetDevice(&dev));
+		if (dev < 64 && !((pool_ready.load() >> dev) & 1)) {
+			hipMemPool_t pool;
+			uint64_t keep = UINT64_MAX;
+			HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+			HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+			pool_ready.fetch_or(1ULL << dev);
+		}
+		const size_t list_bytes = (size_t)groups * 4 * 64 * sizeof(uint4);
+		HIP_TRY(hipMallocAsync(&block, list_bytes + (size_t)groups * 32, stream));
+		list = (uint4 *)block;
+		hdr = (uint32_t *)((char *)block + list_bytes);
+	}
+#endif
+	hipLaunchKernelGGL(decode_hits_kernel, dim3(groups), dim3(256), 0, stream, d_words, n_words, pitch_words, d_hits, d_in, n_packets,
+			   d_count, max_length, d_out, d_lengths, DEC_HEADER | DEC_PAYLOAD, one_in, clk_div, list, hdr);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && block) {
+		hipLaunchKernelGGL(decode_long_kernel, dim3(groups), dim3(256), 0, stream, (const uint4 *)list, (const uint64_t *)hdr, d_out);
+		e = hipGetLastError();
+	}
+	if (block) {
+		const hipError_t f = hipFreeAsync(block, stream);
+		if (e == hipSuccess)
+			e = f;
+	}
+	HIP_TRY(e);
+	return BTBBX_OK;
+}
+
 extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 					const btbbx_hit *d_hits, const btbbx_pkt_in *d_in, uint32_t n_packets,
 					uint32_t max_length, btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
@@ -2752,11 +2843,8 @@ extern "C" int btbbx_decode_hits_device(const uint64_t *d_words, uint64_t n_word
 		set_error("btbbx_decode_hits_device: null pointer");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)n_packets + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-			   d_words, n_words, pitch_words, d_hits, d_in, n_packets, (const uint32_t *)nullptr, max_length, d_out,
-			   d_lengths, DEC_HEADER | DEC_PAYLOAD, btbbx_pkt_in{}, 1u);
-	HIP_TRY(hipGetLastError());
-	return BTBBX_OK;
+	return launch_decode_hits(d_words, n_words, pitch_words, d_hits, d_in, n_packets, nullptr, max_length, d_out, d_lengths, btbbx_pkt_in{}, 1u,
+				  (hipStream_t)hip_stream);
 }
 
 // The same with the number of hits still on the device (the counter btbbx_scan_device filled): decodes
@@ -2776,10 +2864,10 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 		set_error("btbbx_decode_hits_counted_device: null pointer");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)cap + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-			   d_words, n_words, pitch_words, d_hits, d_in, cap, d_count, max_length, d_out, d_lengths,
-			   DEC_HEADER | DEC_PAYLOAD, btbbx_pkt_in{}, 1u);
-	HIP_TRY(hipGetLastError());
+	rc = launch_decode_hits(d_words, n_words, pitch_words, d_hits, d_in, cap, d_count, max_length, d_out, d_lengths, btbbx_pkt_in{}, 1u,
+				(hipStream_t)hip_stream);
+	if (rc)
+		return rc;
 #ifdef DH_PROFILE
 	{
 		unsigned long long prof[8], total = 0;
@@ -2816,9 +2904,6 @@ extern "C" int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_
 		set_error("btbbx_decode_hits_piconet_device: null pointer or clk_div = 0");
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(decode_hits_kernel, dim3((uint32_t)(((uint64_t)cap + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
-			   d_words, n_words, pitch_words, d_hits, (const btbbx_pkt_in *)nullptr, cap, d_count, max_length, d_out,
-			   d_lengths, DEC_HEADER | DEC_PAYLOAD, *entry, clk_div);
-	HIP_TRY(hipGetLastError());
-	return BTBBX_OK;
+	return launch_decode_hits(d_words, n_words, pitch_words, d_hits, nullptr, cap, d_count, max_length, d_out, d_lengths, *entry, clk_div,
+				  (hipStream_t)hip_stream);
 }
