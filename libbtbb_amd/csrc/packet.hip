@@ -1001,7 +1001,7 @@ __device__ __forceinline__ int do_header_present(const PState &s)
 // payload header, a length, a handful of table reads and a compare.  EV4 (which scans for the first byte
 // count whose CRC is zero) still walks bytes, but bytes that are already decoded.
 #ifndef TL_WAVE
-#define TL_WAVE 1                       // trials_wave_kernel (a wave owns its packets, no workgroup barrier); 0: trials_linear_kernel
+#define TL_WAVE 0                       // 1: trials_wave_kernel (a wave owns its packets, no workgroup barrier) -- measured slower, see there
 #endif
 #ifndef TL_THREADS
 #define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
@@ -1489,6 +1489,13 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 // for itself (LDS operations of one wave complete in order: a fence for the compiler is all a phase boundary needs).  The
 // sixteen waves of the workgroup share the read-only tables and drift apart: one wave's table reads fill another's
 // dependent steps.  Arithmetic, tables and per-packet LDS layout are trials_linear_kernel's.
+// [measured, profiles/r04_trials] bit-exact (all 77 GPU tests), and it does what it was built for -- SQ_WAIT_ANY falls from
+// 72 % to 43 % of the wave-cycles, VALU-active from 9.6 % to 22 % -- but it is SLOWER: 1.33 against 0.94 ms per 2^20 packets
+// (bench mix), 537 against 656 M packets/s on random packets of every type.  The counters say why: 780 VALU wave-instructions
+// per packet against 421.  A sort over the 256 trials of four packets leaves four types in every pass of 64 (the workgroup-
+// wide sort over 4096 leaves one), so the DM/DH, FHS and EV4 code runs in every pass with a quarter of the lanes; the
+// one-lane-per-packet steps (header, HV1, type bases, chunk starts) are issued by every wave instead of by one in sixteen;
+// and 80 chunk tasks on 64 lanes are two passes where 1280 on 1024 threads are 1.25.  Not the default (-DTL_WAVE=1 builds it).
 #define TW_PPW 4u                           // packets per wave and step
 #define TW_TRIALS (TW_PPW * 64u)
 __global__ __launch_bounds__(TL_THREADS) void trials_wave_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
