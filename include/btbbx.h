@@ -185,7 +185,9 @@ int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uin
 				 uint64_t search_bits, void *d_scratch, size_t scratch_bytes, void *hip_stream);
 /* btbbx_scan_device with the list coming back in (stream, offset) order: the scan kernels count every record they write in
  * the bucket the ordering will put it in, so the list is not read again for a histogram.  Arguments as btbbx_scan_device plus
- * the ordering scratch (btbbx_order_hits_scratch_bytes(cap)); cap >= 2; nothing is synchronised. */
+ * the ordering scratch (btbbx_order_hits_scratch_bytes(cap)); cap >= 2; nothing is synchronised.  *d_count must be 0 on
+ * entry (the list is built from this call's matches only: records an earlier scan appended are not carried over -- chain
+ * scans with btbbx_scan_device and order the whole list once with btbbx_order_hits_device). */
 int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
 			      uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
 			      uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream);

@@ -106,6 +106,7 @@ struct Ctx {
 
 Ctx &ctx();                              // context of the current device (never null; maybe !ready)
 int ctx_require();                       // BTBBX_OK or error (sets last error)
+void ctx_scan_snapshot(ScanTables *tables, int *table_errors);   // the current device's scan tables as one consistent set (a re-init may run beside the caller)
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 

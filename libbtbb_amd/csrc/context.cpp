@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 #include "common.h"
 
@@ -19,6 +20,16 @@
 #define NO_DEVICE_SLOT BTBBX_MAX_DEVICES
 static Ctx g_ctx[BTBBX_MAX_DEVICES + 1];
 static std::mutex g_init_lock;            // table builds / re-builds and shutdown
+static std::shared_mutex g_tables_lock;   // the table description of a context while it is swapped (upload_tables) / copied by a launcher
+
+// what a scan launch needs of the current device's tables, as ONE consistent set
+void ctx_scan_snapshot(ScanTables *tables, int *table_errors)
+{
+	std::shared_lock<std::shared_mutex> g(g_tables_lock);
+	const Ctx &c = ctx();
+	*tables = c.scan;
+	*table_errors = c.table_errors;
+}
 static int g_table_errors = 0;            // process-wide: the first non-zero btbb_init value
 static thread_local char g_err[512] = "";
 
@@ -363,6 +374,16 @@ extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64
 	return members;
 }
 
+// size of the second-level bitmap by the error count the tables are built for (2^bits bits; 26 = 8 MiB, rounds 1-3)
+#ifndef BITMAP2_BITS_3
+#define BITMAP2_BITS_3 26
+#endif
+#ifndef BITMAP2_BITS_4
+#define BITMAP2_BITS_4 26
+#endif
+#ifndef BITMAP2_BITS_5
+#define BITMAP2_BITS_5 26
+#endif
 static int upload_tables(int max_ac_errors)
 {
 	const HostTables &t = host_tables();
@@ -387,8 +408,9 @@ static int upload_tables(int max_ac_errors)
 		// With 32 567 (3 errors) .. 5.0 M (5) patterns the 2^19-bit LDS bitmap passes 6 % .. 100 %
 		// of the survivors; a 2^26-bit bitmap over a hash of the low 32 syndrome bits (8 MiB, L2 /
 		// Infinity Cache resident) prunes them before the pattern table is probed.
-		mb.shift2 = 32 - 26;
-		mb.bitmap2.assign(1u << (26 - 5), 0);
+		const int bits2 = max_ac_errors == 3 ? BITMAP2_BITS_3 : max_ac_errors == 4 ? BITMAP2_BITS_4 : BITMAP2_BITS_5;
+		mb.shift2 = 32 - bits2;
+		mb.bitmap2.assign(1u << (bits2 - 5), 0);
 		mb.bitmap2[0] |= 1u;            // hash of syndrome 0
 	}
 	int pos[5];
@@ -447,6 +469,9 @@ static int upload_tables(int max_ac_errors)
 	// The set just replaced is not freed here: a launcher on another thread may have copied `c.scan` (the old
 	// pointers) a moment ago and not launched yet.  It is parked in the context and freed by the NEXT re-build,
 	// i.e. after one more hipDeviceSynchronize() -- by then every launch that could have seen it has finished.
+	// ... and it copies the whole table description under the shared side of g_tables_lock (ctx_scan_snapshot): either the
+	// old set or the new one, never a mix of tables of one with the error count of the other.
+	std::unique_lock<std::shared_mutex> swap_guard(g_tables_lock);
 	if (c.d_retired_tab) (void)hipFree(c.d_retired_tab);
 	if (c.d_retired_hslots) (void)hipFree(c.d_retired_hslots);
 	if (c.d_retired_bitmap2) (void)hipFree(c.d_retired_bitmap2);

@@ -1167,6 +1167,9 @@ __device__ __forceinline__ uint32_t bitop3_tt(uint32_t a, uint32_t b, uint32_t c
 // (window bit 52 + k of offset p is bit p + 20 + k of dh:dm), a carry-save adder tree to a 4-bit
 // count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
 // 79 / 4096 = 1.9 % of the offsets of a random stream.
+#ifndef KL_SATURATE
+#define KL_SATURATE 1
+#endif
 template <int CLS>
 __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
@@ -1193,6 +1196,13 @@ __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);
 	const uint32_t t1 = FA_SUM(c3, k0, k1), f1 = FA_CARRY(c3, k0, k1);
 	const uint32_t twos = t0 ^ t1, f2 = t0 & t1;
+#if KL_SATURATE
+	if (limit <= 3) {                                   // (see top16_filter)
+		const uint32_t ge4 = BITOP3(f0, f1, f2, 0xfe);
+		const uint32_t low = limit == 0 ? (twos | ones) : limit == 1 ? twos : limit == 2 ? (twos & ones) : 0u;
+		return ~(ge4 | low);
+	}
+#endif
 	const uint32_t fours = FA_SUM(f0, f1, f2), eights = FA_CARRY(f0, f1, f2);
 #undef FA_SUM
 #undef FA_CARRY
@@ -1242,6 +1252,16 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 	const uint32_t t1 = FA_SUM(c3, c4, k0), f1 = FA_CARRY(c3, c4, k0);
 	const uint32_t t2 = FA_SUM(k1, k2, t0), f2 = FA_CARRY(k1, k2, t0);
 	const uint32_t twos = t1 ^ t2, f3 = t1 & t2;
+#if KL_SATURATE
+	// limit <= 3: "count >= 4" is all that matters of the upper weights, and it is the OR of the four carries out of the
+	// twos column -- six adder instructions and the compare become three (the compiler cannot find this: it is not the
+	// same function as the sum it replaces)
+	if (limit <= 3) {
+		const uint32_t ge4 = BITOP3(f0, f1, f2, 0xfe);
+		const uint32_t low = limit == 0 ? (twos | ones) : limit == 1 ? twos : limit == 2 ? (twos & ones) : 0u;
+		return ~BITOP3(ge4, f3, low, 0xfe);
+	}
+#endif
 	// weight 4: f0..f3
 	const uint32_t g0 = FA_SUM(f0, f1, f2), h0 = FA_CARRY(f0, f1, f2);
 	const uint32_t fours = g0 ^ f3, h1 = g0 & f3;
@@ -1611,15 +1631,16 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 	a.bucket_shift = bucket_shift;
 	a.xcd_tiles = 0;
 	a.ring_margin = 4;
-	a.t = c.scan;
+	int table_errors = 0;
+	ctx_scan_snapshot(&a.t, &table_errors);
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
 		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
 		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one); everything else
 		// runs the sliding-check kernel
 		int run_variant = SCAN_SLIDE ? 1 : 0;
-		if (c.scan.bitmap2 && c.table_errors >= 4)
-			run_variant = c.table_errors == 4 ? (SLIDE_FOR_4 ? 1 : 9) : 8;
+		if (a.t.bitmap2 && table_errors >= 4)
+			run_variant = table_errors == 4 ? (SLIDE_FOR_4 ? 1 : 9) : 8;
 		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : SCAN_THREADS;      // one word per thread
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
@@ -1649,7 +1670,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		case 1: {
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
-			if (c.table_errors >= 4) {
+			if (table_errors >= 4) {
 				// 4 errors: 58 % of the survivors pass the 2^19-bit set -- one tile per trip (two chains), the ring drained after
 				// practically every pass, every candidate through the 2^26-bit second-level bitmap in L2 (verify_lap_any) at
 				// full lanes instead of one probe per surviving lane inside the lock-step loop (scan_lap_any_kernel<9>)
@@ -1657,7 +1678,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<1, SLIDE_WGS, true>),
 							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 				hipLaunchKernelGGL((scan_slide_kernel<1, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
-			} else if (c.table_errors >= 3) {
+			} else if (table_errors >= 3) {
 				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>),
 							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
@@ -1859,14 +1880,21 @@ static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t
 	uint32_t dev_cap = guess > 0xffffffffULL ? 0xffffffffu : (uint32_t)guess;
 	uint32_t count = 0;
 	for (int pass = 0; pass < 2; pass++) {
-		char *block = (char *)scope_hits(16 + (size_t)dev_cap * sizeof(btbbx_hit));
+		// counter, records and the ordering's scratch in ONE block of the call's own lease: the list comes back from the
+		// scan in (stream, offset) order on the call's private stream -- nothing shared with other callers, no lock, no
+		// allocation in steady state (round 3 ordered through btbbx_sort_hits_device's per-device scratch and its mutex)
+		const size_t rec_bytes = ((size_t)dev_cap * sizeof(btbbx_hit) + 255) & ~(size_t)255;
+		const size_t order_bytes = dev_cap >= 2 ? btbbx_order_hits_scratch_bytes(dev_cap) : 0;
+		char *block = (char *)scope_hits(256 + rec_bytes + order_bytes);
 		if (!block)
 			return BTBBX_E_NOMEM;
 		d.count = (uint32_t *)block;
-		d.hits = (btbbx_hit *)(block + 16);
+		d.hits = (btbbx_hit *)(block + 256);
 		HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(uint32_t), q));
-		int rc = btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap,
-					   d.count, q);
+		int rc = dev_cap >= 2
+			? btbbx_scan_ordered_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap, d.count,
+						    block + 256 + rec_bytes, order_bytes, q)
+			: btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap, d.count, q);
 		if (rc)
 			return rc;
 		HIP_TRY(hipMemcpyAsync(&count, d.count, sizeof(count), hipMemcpyDeviceToHost, q));
@@ -1879,9 +1907,6 @@ static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t
 	}
 	const uint32_t have = count < dev_cap ? count : dev_cap;
 	if (have) {
-		int rc = btbbx_sort_hits_device(d.hits, have, q);
-		if (rc)
-			return rc;
 		const uint64_t n = have < cap ? have : cap;
 		HIP_TRY(hipMemcpyAsync(hits, d.hits, (size_t)n * sizeof(btbbx_hit), hipMemcpyDeviceToHost, q));
 		HIP_TRY(hipStreamSynchronize(q));

@@ -20,6 +20,7 @@
 // share nothing; btbbx_sort_hits_device keeps its old signature on top of a per-device scratch block.
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include "common.h"
 
@@ -154,9 +155,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 	return base + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums, OrderParams *p)
+// (bounds_streams != 0: the caller knows the list's bounds, and thread 0 of the grid writes the parameters
+// order_bounds_kernel would have -- one launch less on the stream)
+__global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums, OrderParams *p,
+							       const uint32_t *d_count, uint32_t n_imm, uint32_t cap, uint32_t nb_log2,
+							       uint32_t bounds_streams, unsigned long long max_offset)
 {
 	__shared__ uint32_t lds_wave[16];
+	if (bounds_streams && blockIdx.x == 0 && threadIdx.x == 0) {
+		const unsigned long long mul = max_offset + 1;
+		p->mul = mul;
+		p->n = d_count ? min(*d_count, cap) : n_imm;
+		p->shift = order_shift(bounds_streams, mul, nb_log2);
+	}
 	const uint32_t base = blockIdx.x * 1024 * ORDER_SCAN_ITEMS + threadIdx.x * ORDER_SCAN_ITEMS;
 	uint32_t v = 0;
 	bool big = false;
@@ -210,8 +221,11 @@ __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, u
 		cnt[nb] = run;
 }
 
+// `final` (may be null): where a record that is alone in its bucket goes instead of `grouped` -- its bucket start IS its
+// rank, so when the list was parked somewhere else by the scan (btbbx_scan_ordered_device) the scatter is also the copy
+// into place and only the records that share a bucket are looked at again (order_rank_buckets_kernel)
 __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, const OrderParams *p, const uint32_t *start,
-							    uint32_t *cursor, btbbx_hit *grouped)
+							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final)
 {
 	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
@@ -220,7 +234,26 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hit
 		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
 		const uint32_t s0 = start[b], k = start[b + 1] - s0;      // a bucket of one (more than half of the records) needs no cursor
 		const uint32_t pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
-		reinterpret_cast<HitRec *>(grouped)[pos] = *reinterpret_cast<const HitRec *>(&h);
+		HitRec *dst = reinterpret_cast<HitRec *>(k == 1 && final ? final : grouped);
+		dst[pos] = *reinterpret_cast<const HitRec *>(&h);
+	}
+}
+
+// The ranking for a list whose singletons are in place already: one thread per BUCKET, and only buckets of 2 .. ORDER_SMALL
+// members have work (a pass over the bucket starts -- 4 bytes per bucket, coalesced -- instead of one over every record)
+__global__ __launch_bounds__(256) void order_rank_buckets_kernel(const btbbx_hit *grouped, const uint32_t *start, uint32_t nb, btbbx_hit *out)
+{
+	for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
+		const uint32_t s = start[b], k = start[b + 1] - s;
+		if (k < 2 || k > ORDER_SMALL)
+			continue;                                   // in place already / order_crowded_kernel's
+		for (uint32_t i = 0; i < k; i++) {
+			const btbbx_hit h = grouped[s + i];
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < k; j++)
+				rank += order_before(grouped[s + j], s + j, h, s + i) ? 1u : 0u;
+			reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
+		}
 	}
 }
 
@@ -371,7 +404,7 @@ static uint32_t order_nb_log2(uint32_t cap)
 	return l;
 }
 
-struct OrderLayout { size_t params, start, cursor, sums, grouped, total; uint32_t nb_log2; };
+struct OrderLayout { size_t params, start, cursor, sums, grouped, parked, total; uint32_t nb_log2; };
 static OrderLayout order_layout(uint32_t cap)
 {
 	OrderLayout L;
@@ -383,7 +416,8 @@ static OrderLayout order_layout(uint32_t cap)
 	L.cursor = L.start + up((nb + 1) * 4);
 	L.sums = L.cursor + up(nb * 4);
 	L.grouped = L.sums + up(1024 * 4);
-	L.total = L.grouped + up((size_t)cap * sizeof(btbbx_hit));
+	L.parked = L.grouped + up((size_t)cap * sizeof(btbbx_hit));      // where btbbx_scan_ordered_device's scan leaves its list
+	L.total = L.parked + up((size_t)cap * sizeof(btbbx_hit));
 	return L;
 }
 
@@ -392,6 +426,8 @@ extern "C" size_t btbbx_order_hits_scratch_bytes(uint32_t cap)
 	return order_layout(cap ? cap : 1).total;
 }
 
+// counted_by_scan: the list lies in the scratch's `parked` region (the scan wrote it there and counted its buckets);
+// d_hits only receives the ordered list
 static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_imm, uint32_t cap, void *d_scratch,
 			size_t scratch_bytes, hipStream_t stream, uint32_t n_streams = 0, uint64_t max_offset = 0,
 			bool counted_by_scan = false)
@@ -413,21 +449,42 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	if (!counted_by_scan)
 		HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)cap + 255) / 256, 2048);
-	if (n_streams)
-		hipLaunchKernelGGL(order_bounds_kernel, dim3(1), dim3(1), 0, stream, d_count, n_imm, cap, L.nb_log2, n_streams,
-				   (unsigned long long)max_offset, p);
-	else
-		hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
-	if (!counted_by_scan)
-		hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
-	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
-	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p);
-	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
-	hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped);
-	hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
+	// the crowded-bucket pass wants 132 KiB of dynamic LDS: asked for once per device, before anything is queued (a part
+	// that cannot give it makes the call fail here, with nothing half done)
 	const uint32_t crowded_lds = 4u * ((1u << (ORDER_BIG_BITS - 5)) + 1024u);
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(order_crowded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-				    crowded_lds));
+	{
+		static std::atomic<uint64_t> attr_set{0};
+		int dev = 0;
+		HIP_TRY(hipGetDevice(&dev));
+		if (dev >= 64 || !((attr_set.load() >> dev) & 1)) {
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(order_crowded_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+						    crowded_lds));
+			if (dev < 64)
+				attr_set.fetch_or(1ULL << dev);
+		}
+	}
+	const bool bounds = n_streams != 0;
+	if (!bounds)
+		hipLaunchKernelGGL(order_extent_kernel, dim3(std::min(blocks, 512u)), dim3(256), 0, stream, d_hits, d_count, n_imm, cap, L.nb_log2, p);
+	if (!counted_by_scan) {
+		if (bounds)     // (the histogram needs the parameters before the scan of its counts can write them)
+			hipLaunchKernelGGL(order_bounds_kernel, dim3(1), dim3(1), 0, stream, d_count, n_imm, cap, L.nb_log2, n_streams,
+					   (unsigned long long)max_offset, p);
+		hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
+	}
+	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
+	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
+			   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	if (counted_by_scan) {
+		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the shared buckets by bucket
+		const btbbx_hit *parked = (const btbbx_hit *)(base + L.parked);
+		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits);
+		hipLaunchKernelGGL(order_rank_buckets_kernel, dim3(std::min((nb + 255) / 256, 2048u)), dim3(256), 0, stream, grouped, start, nb, d_hits);
+	} else {
+		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped, (btbbx_hit *)nullptr);
+		hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
+	}
 	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits);
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
@@ -483,8 +540,9 @@ extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_wor
 	char *base = (char *)d_scratch;
 	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
 	const uint32_t shift = order_shift(n_streams, search_bits, L.nb_log2);
-	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, d_hits, cap, d_count, nullptr,
-			     stream, (uint32_t *)(base + L.start), search_bits, shift);
+	// the scan leaves its records in the scratch (and counts each in its bucket); the ordering puts them into d_hits
+	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, (btbbx_hit *)(base + L.parked), cap, d_count,
+			     nullptr, stream, (uint32_t *)(base + L.start), search_bits, shift);
 	if (rc)
 		return rc;
 	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, stream, n_streams, search_bits - 1, true);
