@@ -39,6 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_MIN_PER_WORD = 121        # fewest vector instructions per 64 offsets of an exact LAP_ANY filter of this shape
 SEED = 20260926
 STRIDE = 4096
 
@@ -106,6 +107,31 @@ def physical_cpus():
             seen.add(sib)
             firsts.append(cpu)
     return allowed, firsts
+
+
+def pin_to_gpu_numa(device_index):
+    """One process per GPU: keep this rank's host threads (launches, the event loop of torch.distributed) on the NUMA node
+    the GPU hangs off -- /sys/bus/pci/devices/<bus id>/numa_node, the node's cpulist cut with what the process may use.
+    Returns what was done, for the JSON line; never fails the run."""
+    info = {"numa_node": None, "cpus": None}
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bus = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            info["cpus"] = len(allowed)
+    except Exception as e:                      # no sysfs entry, old torch, a container without the node files ...
+        info["error"] = str(e)[:80]
+    return info
 
 
 def cpu_quota():
@@ -247,8 +273,9 @@ class Timer:
         return a.elapsed_time(b) / reps
 
 
-def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
-    """BASELINE configs 3 and 5, driver-timed: see the module docstring."""
+def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
+    """BASELINE configs 3 and 5, driver-timed: see the module docstring.  only: run just the named line (and what it needs
+    as input) -- for the PMC passes of tools/collect_evidence.sh, whose per-kernel means must not mix two workloads."""
     import _libs
     from libbtbb_amd import synth
     tm = Timer(cur)
@@ -419,9 +446,15 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
 
     t4 = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_FHS]
     t7 = [synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_DH3, synth.TYPE_DM5, synth.TYPE_DH5, synth.TYPE_FHS]
-    out["known_lap_79ch_chain_full_payloads"], d3, n3 = known_lap_chain("known_lap_79ch_chain_full_payloads", t7, True, SEED + 11)
-    del d3
+    want = lambda name: only is None or only == name                  # noqa: E731
+    if want("known_lap_79ch_chain_full_payloads"):
+        out["known_lap_79ch_chain_full_payloads"], d3, n3 = known_lap_chain("known_lap_79ch_chain_full_payloads", t7, True, SEED + 11)
+        del d3
+        if only is not None:
+            return out
     out["known_lap_79ch_chain"], d3, n3 = known_lap_chain("known_lap_79ch_chain", t4, False, SEED)
+    if only == "known_lap_79ch_chain":
+        return out
     # the packets of that capture as rows, for the config 5 stream below (the list was left unordered by the scan timing)
     bt.check(lib.btbbx_order_scan_hits_device(hits.data_ptr(), cnt.data_ptr(), cap, nch, nbits, order_scratch.data_ptr(), order_bytes, hs))
     bt.check(lib.btbbx_gather_packets_device(d3.data_ptr(), wpc, wpc, hits.data_ptr(), n3, 3125, pk.data_ptr(), ln.data_ptr(), hs))
@@ -444,8 +477,10 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
 
     def uaptab():
         bt.check(lib.btbbx_uap_table_device(pk5.data_ptr(), in5.data_ptr(), npk, tab.data_ptr(), hs))
-    t_tr = tm.ms(trials, 3)
-    t_u = tm.ms(uaptab, 5)
+    if only == "clk6_bruteforce_all_types":
+        out.pop("known_lap_79ch_chain", None)
+    t_tr = tm.ms(trials, 3) if want("clk6_bruteforce") else 1.0
+    t_u = tm.ms(uaptab, 5) if want("clk6_bruteforce") else 1.0
     alg5 = npk * (391 + 256)
     entry = {
         "config": "BASELINE configs[4]: UAP / CLK1-6 brute force, 64 whitening seeds x (HEC -> UAP, CRC check) "
@@ -484,7 +519,12 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
                       "(bluetooth_piconet.c:675-690) on one thread" % m,
         }
         entry["parity"] = bool(np.array_equal(gpu_tab, table))
-    out["clk6_bruteforce"] = entry
+    if want("clk6_bruteforce"):
+        if only is not None:
+            out.pop("known_lap_79ch_chain", None)
+        out["clk6_bruteforce"] = entry
+        if only is not None:
+            return out
 
     # ---- config 5 on the reference's WORST-CASE input: packets of 3125 random symbols whose header
     # region is a clean FEC-1/3 encoding of 18 random bits, so that for every candidate clock the type field is uniform
@@ -518,7 +558,8 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu):
         "trials_per_s": round(npk * 64 / (t_all * 1e-3)),
         "roofline": {"bound": "hbm", "achieved": round(alg5 / (t_all * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg5 / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": alg5,
-                     "kernel": "trials_linear_kernel", "kernel_ms": round(t_all, 4), "traffic": None},
+                     "kernel": "trials_linear_kernel", "kernel_ms": round(t_all, 4),
+                     "traffic": traffic_of("clk6_bruteforce_all_types")[0], "traffic_source": traffic_of("clk6_bruteforce_all_types")[1]},
     }
     if ref is not None:
         m = 128
@@ -658,6 +699,8 @@ def main():
     ap.add_argument("--cpu-symbols", type=int, default=0, help="size of the CPU-baseline sample (0 = 2^33 symbols when the host has >= 64 CPUs and the RAM for it, else 2^30)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 block")
+    ap.add_argument("--only-secondary", default=None, metavar="NAME", help="run one line of the secondary block only (with the input it "
+                    "needs): known_lap_79ch_chain_full_payloads, known_lap_79ch_chain, clk6_bruteforce, clk6_bruteforce_all_types")
     ap.add_argument("--layout", default="single", choices=["single", "channels79"],
                     help="single: one stream of --gib GiB per GPU (weak scaling, BASELINE configs[1], the default line); "
                          "channels79: BASELINE configs[3] as written -- 79 channel streams, --gib GiB IN TOTAL (default 64), every "
@@ -680,6 +723,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa = pin_to_gpu_numa(local_rank) if world > 1 else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -769,6 +813,15 @@ def main():
                     busy_s = v["insts_per_launch"] * v["cycles_per_inst"] / (v["simds"] * v["clock_ghz"] * 1e9)
                     valu = {"insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
                             "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kern_ms * 1e-3), 4)}
+                    # ... and how far the instruction stream itself is from the fewest vector instructions ANY exact filter of
+                    # this shape needs per 64-bit stream word (7 barker planes + their adder tree for both halves
+                    # 30, the sliding check stream 27, eight survivors x (find, funnel shift, set address, bit test, clear) 64):
+                    # kernel time x bound / measured = what this kernel would take at its own measured issue rate
+                    per_word = v["insts_per_launch"] / (nwords / 64.0)
+                    valu["bound"] = {"min_valu_per_word": VALU_MIN_PER_WORD, "measured_valu_per_word": round(per_word, 1),
+                                     "frac": round(VALU_MIN_PER_WORD / per_word, 4),
+                                     "bound_ms": round(kern_ms * VALU_MIN_PER_WORD / per_word, 4),
+                                     "salu_per_valu": round((v.get("salu_insts_per_launch") or 0) / v["insts_per_launch"], 3)}
                 traffic_source = "profiles/traffic.json (%s), same sources as this build (csrc_sha16 %s); not re-measured in this run" % (
                     tj.get("source", "rocprofv3 --pmc"), fp)
             else:
@@ -785,7 +838,8 @@ def main():
                                    "bitstream per GPU, max_ac_errors=2, sync word every %d symbols"
                                    % (args.gib, STRIDE),
                        "symbols_per_gpu": nbits, "hits_per_gpu": nhits,
-                       "parallelism": "time-sharded x%d (btbbx_shard_plan: slices + 63-symbol halo), no collectives" % world},
+                       "parallelism": "time-sharded x%d (btbbx_shard_plan: slices + 63-symbol halo), no collectives" % world,
+                       "rank0_host_pinning": numa},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_slide_kernel", "kernel_ms": round(kern_ms, 4),
@@ -810,7 +864,7 @@ def main():
         if world == 1 and not args.no_secondary:
             del stream, hits_t
             torch.cuda.empty_cache()
-            result["secondary"] = secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu)
+            result["secondary"] = secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu, args.only_secondary)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

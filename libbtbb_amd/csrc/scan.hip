@@ -1891,7 +1891,7 @@ static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t
 		d.count = (uint32_t *)block;
 		d.hits = (btbbx_hit *)(block + 256);
 		HIP_TRY(hipMemsetAsync(d.count, 0, sizeof(uint32_t), q));
-		int rc = dev_cap >= 2
+		int rc = dev_cap >= 2 && search_bits
 			? btbbx_scan_ordered_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap, d.count,
 						    block + 256 + rec_bytes, order_bytes, q)
 			: btbbx_scan_device(d_words, n_words, n_words, 1, search_bits, lap, max_ac_errors, d.hits, dev_cap, d.count, q);

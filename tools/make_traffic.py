@@ -42,23 +42,24 @@ json.dump({
 }, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / alg))
 
-sec_path = os.path.join(d, "pmc_secondary.json")
-if os.path.exists(sec_path):
-    sec = json.load(open(sec_path))
-    out = {"csrc_sha16": fp, "source": "%s/pmc_secondary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-           "`python bench.py --steps 2 --warmup 1 --no-cpu`; (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
-    chain = [k for k in sec if k.startswith(("void scan_known_lap_kernel", "scan_known_lap_kernel", "order_", "decode_hits_kernel"))
-             or "order_" in k or "decode_hits_kernel" in k or "scan_known_lap_kernel" in k]
-    tot = sum(hbm(sec[k]) for k in chain if "FETCH_SIZE" in sec[k] and "WRITE_SIZE" in sec[k])
-    alg3 = bench["secondary"]["known_lap_79ch_chain"]["roofline"]["algorithmic_bytes_per_step"]
-    out["known_lap_79ch_chain"] = {"bytes_per_step": int(tot), "kernels": " + ".join(sorted(chain)) + " (the torch element-wise kernel that "
-                                   "fills btbbx_pkt_in is not counted)", "algorithmic_bytes_per_step": alg3,
-                                   "ratio_to_algorithmic": round(tot / alg3, 3)}
-    tl = [k for k in sec if "trials_linear_kernel" in k]
-    if tl:
-        t5 = hbm(sec[tl[0]])
-        alg5 = bench["secondary"]["clk6_bruteforce"]["roofline"]["algorithmic_bytes_per_step"]
-        out["clk6_bruteforce"] = {"bytes_per_step": int(t5), "kernels": "trials_linear_kernel", "algorithmic_bytes_per_step": alg5,
-                                  "ratio_to_algorithmic": round(t5 / alg5, 3)}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_secondary.json"), "w"), indent=1)
-    print("traffic_secondary.json:", {k: v["ratio_to_algorithmic"] for k, v in out.items() if isinstance(v, dict)})
+out = {"csrc_sha16": fp, "source": "%s/pmc_sec_<line>.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+       "`python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary <line>` (one line of the block at a time: a kernel's mean "
+       "per launch then belongs to one workload); (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
+CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel", "decode_long_kernel")
+for line, keys in (("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
+                   ("clk6_bruteforce", ("trials_linear_kernel", "trials_wave_kernel")),
+                   ("clk6_bruteforce_all_types", ("trials_linear_kernel", "trials_wave_kernel"))):
+    path = os.path.join(d, "pmc_sec_%s.json" % line)
+    if not os.path.exists(path) or line not in bench.get("secondary", {}):
+        continue
+    sec = json.load(open(path))
+    used = sorted(k for k in sec if any(x in k for x in keys) and "FETCH_SIZE" in sec[k] and "WRITE_SIZE" in sec[k])
+    if not used:
+        continue
+    tot = sum(hbm(sec[k]) for k in used)
+    alg = bench["secondary"][line]["roofline"]["algorithmic_bytes_per_step"]
+    out[line] = {"bytes_per_step": int(tot), "kernels": " + ".join(used), "algorithmic_bytes_per_step": alg,
+                 "ratio_to_algorithmic": round(tot / alg, 3),
+                 "per_kernel_bytes": {k: int(hbm(sec[k])) for k in used}}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_secondary.json"), "w"), indent=1)
+print("traffic_secondary.json:", {k: v["ratio_to_algorithmic"] for k, v in out.items() if isinstance(v, dict)})
