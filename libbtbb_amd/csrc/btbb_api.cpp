@@ -119,6 +119,90 @@ uint8_t btbb_packet_get_ac_errors(const btbb_packet *pkt) { return pkt->ac_error
 /* :188-199 -- once per search, host side (24 XORs); the kernels get the result */
 uint64_t btbb_gen_syncword(const int LAP) { return host_gen_syncword((uint32_t)LAP); }
 
+/* A caller that walks a buffer with btbb_find_ac -- search, take the match, search again one symbol further: the loop of
+ * gr-bluetooth's and of every all-matches caller -- pays a full host <-> device round trip per call for a
+ * window the GPU has just looked at.  Per thread, the library remembers the LAST window it scanned for ALL its matches
+ * together with a copy of its symbols; a later call whose window lies inside it, with the same search parameters and --
+ * compared byte for byte -- the same symbols, is answered from that list.  Exactly what a fresh scan would return: the
+ * list holds every match of the window in order, and a window whose bytes have changed is scanned again.  A window is
+ * scanned for all its matches only when the previous call ended at the same address (the caller is walking a buffer);
+ * single calls take the first-match kernel as before.  Buffers beyond 1 Mi symbols are not remembered. */
+#define AC_CACHE_MAX_SYMBOLS (1u << 20)
+#define AC_CACHE_HITS 4096
+struct AcWindow {
+	const char *base = nullptr, *last_end = nullptr;
+	uint64_t n_sym = 0;                  // symbols of the remembered window (search length + 63)
+	uint32_t lap = 0;
+	int max_err = 0, table_errors = -1;
+	uint64_t found = 0;                  // matches the window has (hits holds the smallest of them)
+	uint64_t n_hits = 0;
+	char *copy = nullptr;
+	size_t copy_bytes = 0;
+	btbbx_hit *hits = nullptr;
+	~AcWindow() { free(copy); free(hits); }
+};
+static thread_local AcWindow tl_ac;
+
+/* 1 / 0 = answered (found / no match in the window), -1 = the remembered window cannot answer */
+static int ac_window_lookup(const char *stream, uint64_t search_length, uint32_t lap, int max_err, btbbx_hit *first)
+{
+	AcWindow &w = tl_ac;
+	if (!w.base || lap != w.lap || max_err != w.max_err || btbbx_table_errors() != w.table_errors)
+		return -1;
+	if (stream < w.base || stream + search_length + 63 > w.base + w.n_sym)
+		return -1;
+	const uint64_t delta = (uint64_t)(stream - w.base);
+	if (memcmp(stream, w.copy + delta, search_length + 63) != 0)
+		return -1;
+	uint64_t lo = 0, hi = w.n_hits;              // first remembered match at or behind `delta`
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) / 2;
+		if (w.hits[mid].offset < delta)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	if (lo == w.n_hits)
+		return w.found > w.n_hits ? -1 : 0;      // behind the last one remembered: only known when the list is complete
+	if (w.hits[lo].offset >= delta + search_length)
+		return 0;
+	*first = w.hits[lo];
+	first->offset -= delta;
+	return 1;
+}
+
+/* scan [stream, stream + search_length + 63) for all its matches and remember it; 1 / 0 / negative error */
+static int ac_window_scan(const char *stream, uint64_t search_length, uint32_t lap, int max_err, btbbx_hit *first)
+{
+	AcWindow &w = tl_ac;
+	const uint64_t n_sym = search_length + 63;
+	if (n_sym > w.copy_bytes) {
+		free(w.copy);
+		w.copy = (char *)malloc(n_sym);
+		w.copy_bytes = w.copy ? n_sym : 0;
+	}
+	if (!w.hits)
+		w.hits = (btbbx_hit *)malloc(sizeof(btbbx_hit) * AC_CACHE_HITS);
+	w.base = nullptr;
+	if (!w.copy || !w.hits)
+		return BTBBX_E_NOMEM;
+	memcpy(w.copy, stream, n_sym);
+	const int64_t n = btbbx_scan_symbols(w.copy, n_sym, search_length, lap, max_err, w.hits, AC_CACHE_HITS);
+	if (n < 0)
+		return (int)n;
+	w.base = stream;
+	w.n_sym = n_sym;
+	w.lap = lap;
+	w.max_err = max_err;
+	w.table_errors = btbbx_table_errors();
+	w.found = (uint64_t)n;
+	w.n_hits = (uint64_t)n < AC_CACHE_HITS ? (uint64_t)n : AC_CACHE_HITS;
+	if (!n)
+		return 0;
+	*first = w.hits[0];
+	return 1;
+}
+
 /* :444-464 -- first match through the GPU scan */
 int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_errors, btbb_packet **pkt_ptr)
 {
@@ -127,8 +211,17 @@ int btbb_find_ac(char *stream, int search_length, uint32_t lap, int max_ac_error
 	if (!gpu_ready("btbb_find_ac"))
 		return -1;
 	btbbx_hit first;
-	const int rc = btbbx_find_first_symbols(stream, (uint64_t)search_length + 63, (uint64_t)search_length,
-						lap == LAP_ANY ? BTBBX_LAP_ANY : lap, max_ac_errors, &first);
+	const uint32_t xlap = lap == LAP_ANY ? BTBBX_LAP_ANY : lap;
+	const char *end = stream + (size_t)search_length + 63;
+	static const bool remember = []() { const char *e = getenv("BTBB_FIND_AC_WINDOW"); return !(e && e[0] == '0'); }();   // (0: measurements)
+	int rc = remember ? ac_window_lookup(stream, (uint64_t)search_length, xlap, max_ac_errors, &first) : -1;
+	if (rc < 0) {
+		if (remember && tl_ac.last_end == end && (uint64_t)search_length + 63 <= AC_CACHE_MAX_SYMBOLS)
+			rc = ac_window_scan(stream, (uint64_t)search_length, xlap, max_ac_errors, &first);     // the caller walks this buffer
+		else
+			rc = btbbx_find_first_symbols(stream, (uint64_t)search_length + 63, (uint64_t)search_length, xlap, max_ac_errors, &first);
+	}
+	tl_ac.last_end = end;
 	if (rc < 0) {
 		fprintf(stderr, "btbb_find_ac: GPU scan failed: %s\n", btbbx_last_error());
 		return -1;

@@ -268,6 +268,73 @@ def test_find_ac_drop_in():
     assert lib.btbb_find_ac(_libs.ptr(z), 4000, bt.LAP_ANY, 2, C.byref(pkt)) < 0 and not pkt.value
 
 
+def test_find_ac_walk_is_answered_from_the_remembered_window_and_only_while_it_is_true():
+    """A caller that walks a buffer with btbb_find_ac is answered, from its second call on, from the list of ALL matches of
+    the window scanned then (btbb_api.cpp, AcWindow) -- as long as the bytes are the bytes that were scanned.  Every call
+    of several walks is held against the oracle: a plain walk, a walk whose buffer is changed between two calls (an access
+    code destroyed behind the cursor, one created in front of it), alternating search parameters, windows that end
+    elsewhere, a buffer with more matches than the list holds, and one with none."""
+    lib = bt.lib()
+    orc = _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(141))
+
+    def call(sym, off, n, lap, max_err, pkt):
+        lo, eo = C.c_uint32(0), C.c_uint8(0)
+        want = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + off), n, lap, max_err, C.byref(lo), C.byref(eo))
+        got = lib.btbb_find_ac(C.c_void_p(sym.ctypes.data + off), n, lap, max_err, C.byref(pkt))
+        assert (got if got >= 0 else -1) == want, (off, n, hex(lap), max_err, got, want)
+        if want >= 0:
+            assert lib.btbb_packet_get_lap(pkt) == lo.value and lib.btbb_packet_get_ac_errors(pkt) == eo.value
+        return want
+
+    def walk(sym, lap, max_err, pkt, mutate=None):
+        off, found = 0, 0
+        while True:
+            n = len(sym) - 63 - off
+            if n <= 0:
+                break
+            r = call(sym, off, n, lap, max_err, pkt)
+            if r < 0:
+                break
+            found += 1
+            off += r + 1
+            if mutate is not None and found == mutate[0]:
+                mutate[1](off)
+        return found
+
+    _, sym, _ = stream(141, 1 << 9, stride=1024)               # 32 Ki symbols, an access code every 1024
+    sym = np.ascontiguousarray(sym)
+    pkt = C.c_void_p(None)
+    n_all = walk(sym, bt.LAP_ANY, 2, pkt)
+    assert n_all > 20
+    # the same buffer again (remembered), then with one access code in front of the cursor broken and a new one planted
+    assert walk(sym, bt.LAP_ANY, 2, pkt) == n_all
+    planted = synth.access_code(0x2A5B17)[4:68]
+
+    def change(off):
+        nxt = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + off), len(sym) - 63 - off, bt.LAP_ANY, 2, C.byref(C.c_uint32(0)), C.byref(C.c_uint8(0)))
+        assert nxt >= 0
+        sym[off + nxt + 10:off + nxt + 20] ^= 1                 # the next match is gone
+        sym[off + nxt + 200:off + nxt + 264] = planted          # and a new one stands 200 symbols behind where it was
+    m = walk(sym, bt.LAP_ANY, 2, pkt, mutate=(5, change))
+    assert m in (n_all, n_all + 1)
+    # parameters alternate call by call on one buffer; windows with other ends
+    for k in range(12):
+        off = int(rng.integers(0, len(sym) - 3000))
+        call(sym, off, len(sym) - 63 - off, bt.LAP_ANY if k % 2 else 0x2A5B17, 1 + k % 2, pkt)
+        call(sym, off, int(rng.integers(1, 2500)), bt.LAP_ANY, 2, pkt)
+    # more matches than the list holds: back-to-back sync words (4 500 of them), walked to the end
+    dense = np.concatenate([synth.access_code(int(l))[4:68] for l in rng.integers(0, 1 << 24, 4500)]).astype(np.uint8)
+    dense = np.ascontiguousarray(np.concatenate([dense, np.zeros(70, np.uint8)]))
+    assert walk(dense, bt.LAP_ANY, 0, pkt) >= 4500
+    # and none at all
+    z = np.zeros(9000, np.uint8)
+    for off in (0, 10, 20):
+        assert call(z, off, len(z) - 63 - off, bt.LAP_ANY, 2, pkt) < 0
+    if pkt.value:
+        lib.btbb_packet_unref(pkt)
+
+
 def test_large_stream_properties():
     """512 MiB of packed stream generated in HBM: every injected sync word with <= 2 bit errors
     is reported with its LAP and error count, nothing is reported twice, the count equals

@@ -1,4 +1,4 @@
-import sys, time, ctypes as C
+import os, sys, time, ctypes as C
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
 import libbtbb_amd as bt
@@ -12,6 +12,25 @@ for n in (4096, 65536):
     t0 = time.perf_counter()
     for _ in range(200): r = lib.btbb_find_ac(small.ctypes.data, n, bt.LAP_ANY, 2, C.byref(pkt))
     print(n, "symbols: find_ac us", round((time.perf_counter() - t0) / 200 * 1e6, 1), "offset", r)
+# a caller walking a buffer (search, take the match, search again one symbol further): microseconds per call
+for n, stride in ((65536, 4096), (8192, 1024)):
+    w2, _ = synth.make_stream(9, n // 64 + 2, stride=stride)
+    buf = np.ascontiguousarray(synth.unpack_bits(w2)[: n + 63]); pkt = C.c_void_p(None)
+    def walk():
+        off, calls = 0, 0
+        while True:
+            left = len(buf) - 63 - off
+            if left <= 0:
+                break
+            r = lib.btbb_find_ac(buf.ctypes.data + off, left, bt.LAP_ANY, 2, C.byref(pkt))
+            calls += 1
+            if r < 0:
+                break
+            off += r + 1
+        return calls
+    walk()
+    t0 = time.perf_counter(); calls = sum(walk() for _ in range(20)); dt = time.perf_counter() - t0
+    print(n, "symbols walked:", calls // 20, "calls per walk,", round(dt / calls * 1e6, 1), "us per call (BTBB_FIND_AC_WINDOW=%s)" % os.environ.get("BTBB_FIND_AC_WINDOW", "1"))
 # drop-in decode and UAP discovery round trips
 from libbtbb_amd import synth as _s
 rng = np.random.default_rng(1)
