@@ -309,7 +309,7 @@ def test_find_ac_walk_is_answered_from_the_remembered_window_and_only_while_it_i
     assert n_all > 20
     # the same buffer again (remembered), then with one access code in front of the cursor broken and a new one planted
     assert walk(sym, bt.LAP_ANY, 2, pkt) == n_all
-    planted = synth.access_code(0x2A5B17)[4:68]
+    planted = synth.access_code(0x2A5B17)[:64]
 
     def change(off):
         nxt = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + off), len(sym) - 63 - off, bt.LAP_ANY, 2, C.byref(C.c_uint32(0)), C.byref(C.c_uint8(0)))
@@ -324,7 +324,7 @@ def test_find_ac_walk_is_answered_from_the_remembered_window_and_only_while_it_i
         call(sym, off, len(sym) - 63 - off, bt.LAP_ANY if k % 2 else 0x2A5B17, 1 + k % 2, pkt)
         call(sym, off, int(rng.integers(1, 2500)), bt.LAP_ANY, 2, pkt)
     # more matches than the list holds: back-to-back sync words (4 500 of them), walked to the end
-    dense = np.concatenate([synth.access_code(int(l))[4:68] for l in rng.integers(0, 1 << 24, 4500)]).astype(np.uint8)
+    dense = np.concatenate([synth.access_code(int(l))[:64] for l in rng.integers(0, 1 << 24, 4500)]).astype(np.uint8)
     dense = np.ascontiguousarray(np.concatenate([dense, np.zeros(70, np.uint8)]))
     assert walk(dense, bt.LAP_ANY, 0, pkt) >= 4500
     # and none at all
