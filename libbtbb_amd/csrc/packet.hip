@@ -1010,9 +1010,6 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 #ifndef TL_LDSNOW
 #define TL_LDSNOW 1                     // trials_linear_kernel reads a_fail through lds_now (0: the volatile generic read of rounds 2-3)
 #endif
-#ifndef TL_WAVE
-#define TL_WAVE 0                       // 1: trials_wave_kernel (a wave owns its packets, no workgroup barrier) -- measured slower, see there
-#endif
 #ifndef TL_THREADS
 #define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
 #endif
@@ -1489,868 +1486,19 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	TL_PROF_END;
 }
 
-// The same work without a workgroup barrier on the path (round 4).  trials_linear_kernel moves 64 packets through six
-// barrier-separated phases with all sixteen waves of the CU in step: 61 % of its wave-cycles wait (profiles/r03_v4/
-// pmc_secondary.json), because every wave sits out every other wave's LDS latencies at the same barrier.  Here a WAVE owns
-// four packets from their first word to their last result -- the sixteen-lanes-per-packet FEC pass, the 256 trials sorted
-// by type inside the wave (counters and order in the wave's own LDS), the chunk registers, the trials -- and only waits
-// for itself (LDS operations of one wave complete in order: a fence for the compiler is all a phase boundary needs).  The
-// sixteen waves of the workgroup share the read-only tables and drift apart: one wave's table reads fill another's
-// dependent steps.  Arithmetic, tables and per-packet LDS layout are trials_linear_kernel's.
-// [measured, profiles/r04_trials] bit-exact (all 77 GPU tests), and it does what it was built for -- SQ_WAIT_ANY falls from
-// 72 % to 43 % of the wave-cycles, VALU-active from 9.6 % to 22 % -- but it is SLOWER: 1.33 against 0.94 ms per 2^20 packets
-// (bench mix), 537 against 656 M packets/s on random packets of every type.  The counters say why: 780 VALU wave-instructions
-// per packet against 421.  A sort over the 256 trials of four packets leaves four types in every pass of 64 (the workgroup-
-// wide sort over 4096 leaves one), so the DM/DH, FHS and EV4 code runs in every pass with a quarter of the lanes; the
-// one-lane-per-packet steps (header, HV1, type bases, chunk starts) are issued by every wave instead of by one in sixteen;
-// and 80 chunk tasks on 64 lanes are two passes where 1280 on 1024 threads are 1.25.  Not the default (-DTL_WAVE=1 builds it).
-#define TW_PPW 4u                           // packets per wave and step
-#define TW_TRIALS (TW_PPW * 64u)
-__global__ __launch_bounds__(TL_THREADS) void trials_wave_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
-							       uint32_t n_packets, btbbx_trial *trials)
-{
-	static_assert(TL_THREADS == 1024 && TL_PACKETS == 64, "sixteen waves of four packets");
-	__shared__ uint64_t pk[TL_PACKETS][BTBBX_PKT_WORDS + 1];
-	__shared__ __attribute__((aligned(8))) btbbx_pkt_in pin[TL_PACKETS];
-	__shared__ uint32_t hdr_ut[TL_PACKETS];
-	__shared__ uint16_t clk_ut[64];
-	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];
-	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
-	__shared__ __attribute__((aligned(16))) uint16_t advw[7 * 2 * 256];
-	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
-	__shared__ uint32_t t_info[TL_TRIALS];
-	__shared__ int16_t t_rv[TL_TRIALS];
-	__shared__ uint32_t type_count[16][16], type_base[16][16];       // [wave][type]
-	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];
-	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];
-	__shared__ uint32_t a_bytes[TL_PACKETS][TL_A_BYTES / 4], b_bytes[TL_PACKETS][TL_B_BYTES / 4];
-	__shared__ uint32_t a_fail[TL_PACKETS], b_fail[TL_PACKETS];
-	__shared__ uint16_t p4a[TL_PACKETS][TL_A_BYTES / 4], p4b[TL_PACKETS][TL_B_BYTES / 4], p4c[TL_PACKETS][LIN_MAXLEN / 4];
-	__shared__ int8_t hv_rv[TL_PACKETS];
-	__shared__ uint16_t chunk_reg[TL_PACKETS][20];
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for (uint32_t i = tid; i < LIN_MAXLEN * 2; i += TL_THREADS)
-		reinterpret_cast<uint4 *>(lin)[i] = reinterpret_cast<const uint4 *>(g_lin)[i];
-	for (uint32_t i = tid; i < 7 * 2 * 256 / 8; i += TL_THREADS)
-		reinterpret_cast<uint4 *>(advw)[i] = reinterpret_cast<const uint4 *>(g_advw)[i];
-	chain_lds_init();                                       // ends with a barrier
-	if (tid >= 64 && tid < 128) {
-		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
-		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
-		const uint32_t v = (uint32_t)wh_bits(wh_start(tid - 64, 18), 7);
-		uint32_t x = 0;
-		for (int j = 0; j < 7; j++)
-			if ((v >> j) & 1)
-				x ^= lin[20 * 16 + 8 + j];
-		pw20[tid - 64] = (uint16_t)x;
-	}
-	__syncthreads();                                        // the last barrier: from here on every wave is on its own
-	auto wsync = [] {
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-	};
-	const uint32_t P0 = wave * TW_PPW, T0 = wave * TW_TRIALS;
-	const uint32_t n_groups = (n_packets + TW_PPW - 1) / TW_PPW, g_stride = gridDim.x * 16;
-	// a group is 4 x 51 packet words + 4 x 2 words of btbbx_pkt_in = 212 words, four per lane (the last round 20 lanes);
-	// the next group's words fly while this one is worked on
-	constexpr uint32_t PK_ELEMS = TW_PPW * (BTBBX_PKT_WORDS + 1), IN_ELEMS = TW_PPW * 2, PER_LANE = (PK_ELEMS + IN_ELEMS + 63) / 64;
-	uint64_t pre[PER_LANE];
-	auto have_of = [&](uint32_t g) { return g < n_groups ? (n_packets - g * TW_PPW < TW_PPW ? n_packets - g * TW_PPW : TW_PPW) : 0u; };
-	// (the element -> (packet, word) arithmetic of the two lambdas is done where it is used: hoisted out of the group loop
-	// it is thirty registers that live in scratch, and a reload from scratch counts on the same counter as the prefetch)
-	auto fetch = [&](uint32_t g) {
-		const uint32_t f = g * TW_PPW, have = have_of(g);
-		uint32_t ln = lane;
-		asm volatile("" : "+v"(ln));
-#pragma unroll
-		for (uint32_t k = 0; k < PER_LANE; k++) {
-			const uint32_t i = ln + 64 * k;
-			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1), e = i - PK_ELEMS;
-			const uint64_t *src = packets;
-			if (i < PK_ELEMS) {
-				if (p < have && w < BTBBX_PKT_WORDS)
-					src = packets + (uint64_t)(f + p) * BTBBX_PKT_WORDS + w;
-			} else if (e < 2 * have) {
-				src = reinterpret_cast<const uint64_t *>(in) + (uint64_t)f * 2 + e;
-			}
-			pre[k] = *src;
-		}
-	};
-	auto stage_in = [&](uint32_t g) {
-		const uint32_t have = have_of(g);
-		uint32_t ln = lane;
-		asm volatile("" : "+v"(ln));
-#pragma unroll
-		for (uint32_t k = 0; k < PER_LANE; k++) {
-			const uint32_t i = ln + 64 * k;
-			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
-			if (i < PK_ELEMS)
-				pk[P0 + p][w] = (p < have && w < BTBBX_PKT_WORDS) ? pre[k] : 0;
-			else if (i < PK_ELEMS + IN_ELEMS)
-				reinterpret_cast<uint64_t *>(pin + P0)[i - PK_ELEMS] = pre[k];
-		}
-		if (lane < 16)
-			type_count[wave][lane] = 0;
-		if (lane < TW_PPW) {
-			a_fail[P0 + lane] = TL_A_BLOCKS;
-			b_fail[P0 + lane] = TL_B_BLOCKS;
-		}
-	};
-	const uint32_t g0 = blockIdx.x * 16 + wave;
-	fetch(g0);
-	stage_in(g0);
-	fetch(g0 + g_stride);
-	for (uint32_t g = g0; g < n_groups; g += g_stride) {
-		const uint32_t first = g * TW_PPW, mine = have_of(g);
-		wsync();                                            // this group is in LDS
-		// 1. try_clock's linear part, once per packet (see trials_linear_kernel)
-		if (lane < mine) {
-			uint32_t dis;
-			const uint32_t hdr = header_fec13(pk[P0 + lane], dis);
-			hdr_ut[P0 + lane] = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
-		}
-		auto a_words = [&](uint32_t p) {
-			const uint32_t blocks = lds_now(&a_fail[p]) < TL_A_BLOCKS ? lds_now(&a_fail[p]) : TL_A_BLOCKS, n = (blocks * 10 + 31) / 32 + 1;
-			return n < TL_A_BYTES / 4 ? n : (uint32_t)(TL_A_BYTES / 4);
-		};
-		// 2a. FEC 2/3 of both layouts: sixteen lanes per packet, no further round once a block of the packet has failed
-		{
-			const uint32_t q = lane >> 4, sub = lane & 15, p = P0 + q;
-			if (q < mine) {
-				uint32_t d;
-				if (sub < TL_B_BLOCKS) {
-					if (!fec23_block(pk_bits32(pk[p], 202 + 15 * sub, 15), d))
-						atomicMin(&b_fail[p], sub);
-					b10[p][sub] = (uint16_t)d;
-				}
-#pragma unroll 1
-				for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
-					const uint32_t k = k0 + sub;
-					if (k < TL_A_BLOCKS) {
-						if (!fec23_block(pk_bits32(pk[p], 122 + 15 * k, 15), d))
-							atomicMin(&a_fail[p], k);
-						a10[p][k] = (uint16_t)d;
-					}
-					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-					if (lds_now(&a_fail[p]) < k0 + 16)
-						break;
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				auto word_from = [&](const uint16_t *src, uint32_t nblk, uint32_t word) {
-					const uint32_t bit = 32 * word, k0 = bit / 10, sh = bit % 10;
-					uint64_t acc = 0;
-					for (uint32_t j = 0; j < 5; j++)
-						acc |= (uint64_t)(k0 + j < nblk ? src[k0 + j] : 0) << (10 * j);
-					return (uint32_t)(acc >> sh);
-				};
-				if (sub < TL_B_BYTES / 4)
-					b_bytes[p][sub] = word_from(b10[p], TL_B_BLOCKS, sub);
-				const uint32_t need = a_words(p);
-				for (uint32_t word = sub; word < need; word += 16)
-					a_bytes[p][word] = word_from(a10[p], TL_A_BLOCKS, word);
-			}
-		}
-		// HV1 verdict (:1131-1150): one lane of each packet's sixteen
-		if ((lane & 15) == 15 && (lane >> 4) < mine) {
-			const uint32_t p = P0 + (lane >> 4);
-			int rv = 1;
-			if ((int)pin[p].length - 122 >= 240) {
-				uint32_t total = 0;
-				for (int i = 0; i < 4; i++) {
-					uint32_t dis;
-					(void)fec13(pk_bits(pk[p], 122 + 60 * i, 60), 20, dis);
-					total += dis;
-				}
-				rv = total < 20 ? 2 : 0;
-			}
-			hv_rv[p] = (int8_t)rv;
-		}
-		wsync();
-		// 2b. the 64 trials of packet k: try_clock's result, counted by type (the wave's own counters)
-#pragma unroll 1
-		for (uint32_t k = 0; k < mine; k++) {
-			const uint32_t p = P0 + k, i = T0 + 64 * k + lane;
-			const uint32_t h = hdr_ut[p];
-			uint32_t uap = pin[p].uap, type = pin[p].type, ret = 0;     // FEC 1/3 failure: nothing changes
-			if (h & 0x10000u) {
-				const uint32_t v = (h ^ ((pin[p].flags & F_WHITENED) ? clk_ut[lane] : 0u)) & 0xffff;
-				uap = ret = v & 0xff;
-				type = v >> 8;
-			}
-			t_info[i] = ret | (type << 8) | (uap << 16);
-			t_slot[i] = (uint16_t)atomicAdd(&type_count[wave][type & 15], 1u);
-		}
-		// 2c. chunk registers (see trials_linear_kernel): 20 chunk tasks per packet
-		auto chunk_of = [&](uint32_t t, uint32_t &p, uint32_t &r, uint32_t &layout, uint32_t &j, uint32_t &nwords) {
-			if (t < mine * 12) {
-				p = P0 + t / 12;
-				j = t % 12;
-				if (j < 11) { layout = 0; r = j; nwords = j < 10 ? 8 : LIN_MAXLEN / 4 - 80; }
-				else { layout = 2; r = 19; j = 0; nwords = TL_B_BYTES / 4; }
-			} else {
-				const uint32_t u = t - mine * 12;
-				p = P0 + u / 8;
-				j = u % 8;
-				layout = 1;
-				r = 11 + j;
-				const uint32_t need = a_words(p);
-				nwords = need > 8 * j ? (need - 8 * j < 8 ? need - 8 * j : 8) : 0;
-			}
-		};
-		auto data_word = [&](uint32_t p, uint32_t layout, uint32_t i) {
-			return layout == 0 ? pk_bits32(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
-		};
-		auto chunk_words = [&](uint32_t p, uint32_t layout, uint32_t j, uint32_t nwords, uint32_t (&w8)[8]) {
-			if (layout == 0) {
-				const uint32_t *d = reinterpret_cast<const uint32_t *>(pk[p]) + 3 + 8 * j;
-				uint32_t raw[9];
-#pragma unroll
-				for (uint32_t i = 0; i < 9; i++)
-					raw[i] = i <= nwords ? d[i] : 0;
-#pragma unroll
-				for (uint32_t i = 0; i < 8; i++)
-					w8[i] = __builtin_amdgcn_alignbit(raw[i + 1], raw[i], 26);
-			} else {
-#pragma unroll
-				for (uint32_t i = 0; i < 8; i++)
-					w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
-			}
-		};
-		for (uint32_t t = lane; t < mine * 20; t += 64) {
-			uint32_t p, r, layout, j, nwords, crc = 0;
-			chunk_of(t, p, r, layout, j, nwords);
-			if (!nwords)
-				continue;
-			uint32_t w8[8];
-			chunk_words(p, layout, j, nwords, w8);
-			uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
-#pragma unroll
-			for (uint32_t i = 0; i < 8; i++)
-				if (i < nwords) {
-					dst[8 * j + i] = (uint16_t)crc;
-					crc = crc_word(crc, w8[i]);
-				}
-			chunk_reg[p][r] = (uint16_t)crc;
-		}
-		wsync();
-		// 3. where each type's trials start in the wave's order (lanes 0 .. 15: an exclusive scan), and the chunk starts
-		{
-			uint32_t c = lane < 16 ? type_count[wave][lane] : 0u, incl = c;
-#pragma unroll
-			for (int d = 1; d < 16; d <<= 1) {
-				const uint32_t u = __shfl_up(incl, d);
-				if (lane >= (uint32_t)d)
-					incl += u;
-			}
-			if (lane < 16)
-				type_base[wave][lane] = incl - c;
-		}
-		if (lane >= 16 && lane < 16 + 3 * mine) {
-			const uint32_t p = P0 + (lane - 16) / 3, layout = (lane - 16) % 3;
-			const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
-			const uint32_t n = layout == 0 ? 11 : layout == 1 ? (a_words(p) + 7) / 8 : 1;
-			uint32_t start = 0;
-			for (uint32_t j = 0; j < n; j++) {
-				const uint32_t c = chunk_reg[p][r0 + j];
-				chunk_reg[p][r0 + j] = (uint16_t)start;
-				start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
-			}
-		}
-		wsync();
-#pragma unroll 1
-		for (uint32_t k = 0; k < mine; k++) {
-			const uint32_t i = T0 + 64 * k + lane;
-			order[T0 + type_base[wave][(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)(i - T0);
-		}
-		wsync();
-		// 4. crc_check (:708-769) in type order
-#pragma unroll 1
-		for (uint32_t k = 0; k < mine; k++) {
-			const uint32_t i = T0 + order[T0 + 64 * k + lane], p = P0 + ((i - T0) >> 6), clock = i & 63;
-			const uint32_t info = t_info[i], type = (info >> 8) & 0xff, uap = (info >> 16) & 0xff;
-			const bool wht = pin[p].flags & F_WHITENED;
-			const int size = (int)pin[p].length - 122;
-			const uint32_t seed = crc_seed(uap);
-			const uint32_t sel = (seed >> 8) | (wht ? (uint32_t)wh_bits(wh_start(clock, 18), 7) << 8 : 0u);
-			auto seed_row20 = [&](uint32_t sd) {
-				const uint4 r0 = reinterpret_cast<const uint4 *>(lin)[40];
-				const uint32_t r[4] = {r0.x, r0.y, r0.z, r0.w};
-				uint32_t x = 0;
-#pragma unroll
-				for (int bit = 0; bit < 8; bit++)
-					x ^= (0u - ((sd >> (8 + bit)) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
-				return x & 0xffff;
-			};
-			auto lin_terms = [&](uint32_t L) {
-				uint32_t x = 0;
-#pragma unroll 1
-				for (int half = 0; half < 2; half++) {
-					const uint4 q = reinterpret_cast<const uint4 *>(lin)[2 * L + half];
-					const uint32_t r[4] = {q.x, q.y, q.z, q.w};
-					const uint32_t sl = sel >> (8 * half);
-#pragma unroll
-					for (int bit = 0; bit < 8; bit++)
-						x ^= (0u - ((sl >> bit) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
-				}
-				return x & 0xffff;
-			};
-			auto data_reg = [&](int layout, uint32_t L) {
-				const uint32_t q = L >> 2, r = L & 3;
-				uint32_t crc, w;
-				if (layout == 0) { crc = p4c[p][q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
-				else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
-				else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
-				const uint32_t start = chunk_reg[p][(layout == 0 ? 0u : layout == 1 ? 11u : 19u) + (q >> 3)], iw = q & 7;
-				crc ^= iw ? (uint32_t)(advw[((iw - 1) * 2) * 256 + (start & 0xff)] ^ advw[((iw - 1) * 2 + 1) * 256 + (start >> 8)]) : start;
-				for (uint32_t j = 0; j < r; j++)
-					crc = crc_byte(crc, (w >> (8 * j)) & 0xff);
-				return crc;
-			};
-			auto crc_is_zero = [&](int layout, uint32_t L) {
-				return (data_reg(layout, L) ^ lin_terms(L)) == 0;
-			};
-			int rv = 1;
-			switch (type) {
-			case 2: {                                               // fhs (:783-818)
-				if (size < 240) { rv = 1; break; }
-				if (a_fail[p] < 16) { rv = 0; break; }
-				const uint32_t x = data_reg(1, 20) ^ seed_row20(seed);
-				rv = 0;
-				if (!wht) {
-					if (x == 0) rv = 1000;
-				} else {
-					uint32_t hit = x == pw20[clock];
-					const uint32_t xx = x | (x << 16);
-#pragma unroll 1
-					for (int v = 0; v < 4; v++) {
-						const uint4 q = reinterpret_cast<const uint4 *>(&pw20[32])[v];
-						const uint32_t d0 = q.x ^ xx, d1 = q.y ^ xx, d2 = q.z ^ xx, d3 = q.w ^ xx;
-						hit |= ((d0 & 0xffff) == 0) | ((d0 >> 16) == 0) | ((d1 & 0xffff) == 0) | ((d1 >> 16) == 0)
-						     | ((d2 & 0xffff) == 0) | ((d2 >> 16) == 0) | ((d3 & 0xffff) == 0) | ((d3 >> 16) == 0);
-					}
-					if (hit) rv = 1000;
-				}
-				break;
-			}
-			case 3: case 8: case 10: case 14:                       // DM (:898-958)
-			case 4: case 11: case 15: {                             // DH (:962-1011)
-				const bool fec = type == 3 || type == 8 || type == 10 || type == 14;
-				const int layout = !fec ? 0 : (type == 8 ? 2 : 1);
-				const int psize = type == 8 ? size - 80 : size;
-				const int hb = (type == 3 || type == 8 || type == 4) ? 1 : 2;
-				const int hbits = 8 * hb;
-				const uint32_t fail = layout == 2 ? b_fail[p] : a_fail[p];
-				rv = 0;
-				if (psize < hbits) break;
-				uint32_t raw;
-				if (fec) {
-					if (psize < (hb == 2 ? 30 : 15)) break;
-					if (fail < (uint32_t)hb) break;
-					raw = (layout == 2 ? b_bytes[p][0] : a_bytes[p][0]) & ((1u << hbits) - 1);
-				} else {
-					raw = pk_bits32(pk[p], 122, hbits);
-				}
-				const uint32_t ph = raw ^ (wht ? (uint32_t)wh_bits(wh_start(clock, 18), hbits) : 0u);
-				int plen = hb == 2 ? (int)((ph >> 3) & 0x3ff) + 4 : (int)((ph >> 3) & 0x1f) + 3;
-				int cap;
-				switch (type) {
-				case 3:  cap = 20;  break;
-				case 4:  cap = 30;  break;
-				case 8:  cap = 12;  break;
-				case 10: cap = 125; break;
-				case 11: cap = 187; break;
-				case 14: cap = 228; break;
-				default: cap = 343; break;
-				}
-				if (plen > cap) plen = cap;
-				const int nbits = plen * 8;
-				if (nbits > psize) { rv = 1; break; }
-				if (fec && fail < (uint32_t)(nbits + 9) / 10) break;
-				rv = crc_is_zero(layout, (uint32_t)plen) ? 10 : 2;
-				break;
-			}
-			case 12: {                                              // EV4 (:1044-1097)
-				uint32_t B = size >= 15 ? (uint32_t)size / 15 : 0;
-				if (B > 98) B = 98;
-				if (B > a_fail[p]) B = a_fail[p];
-				const uint32_t lmax = B ? 5 * (B - 1) / 4 : 0;
-				uint32_t crc = seed, idx = wh_start(clock, 18);
-				rv = B == 98 ? 2 : 1;
-				for (uint32_t L0 = 0; L0 < lmax; L0 += 4) {
-					const uint32_t w = a_bytes[p][L0 >> 2] ^ (wht ? (uint32_t)wh_bits(idx, 32) : 0u);
-					idx = idx + 32 >= 127 ? idx + 32 - 127 : idx + 32;
-					const uint32_t x0 = (crc ^ w) & 0xff, x1 = ((crc ^ w) >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
-					const uint32_t c1 = (crc >> 8) ^ g_lds.crc[x0];
-					const uint32_t c2 = g_lds.crc_z[0][x0] ^ g_lds.crc[x1];
-					const uint32_t c3 = g_lds.crc_z[1][x0] ^ g_lds.crc_z[0][x1] ^ g_lds.crc[b2];
-					const uint32_t c4 = g_lds.crc_z[2][x0] ^ g_lds.crc_z[1][x1] ^ g_lds.crc_z[0][b2] ^ g_lds.crc[b3];
-					const bool z1 = c1 == 0 && L0 + 1 >= 2 && L0 + 1 <= lmax, z2 = c2 == 0 && L0 + 2 <= lmax;
-					const bool z3 = c3 == 0 && L0 + 3 <= lmax, z4 = c4 == 0 && L0 + 4 <= lmax;
-					if (z1 || z2 || z3 || z4) { rv = 10; break; }
-					crc = c4;
-				}
-				break;
-			}
-			case 5: rv = hv_rv[p]; break;                           // HV1
-			default: rv = 1; break;
-			}
-			if (rv == 0 && type != 2 && type != 3 && type != 5)
-				rv = 1;
-			t_rv[i] = (int16_t)rv;
-		}
-		wsync();
-		// the results into registers, the next group into LDS and the one after that requested -- and only then the
-		// stores (one in-order counter for loads and stores, see trials_linear_kernel)
-		uint32_t res[TW_PPW];
-#pragma unroll
-		for (uint32_t k = 0; k < TW_PPW; k++) {
-			const uint32_t i = T0 + 64 * k + lane;
-			res[k] = (t_info[i] & 0xffff) | ((uint32_t)(uint16_t)t_rv[i] << 16);
-		}
-		wsync();
-		stage_in(g + g_stride);
-		fetch(g + 2 * g_stride);
-		static_assert(sizeof(btbbx_trial) == 4, "one dword per trial");
-#pragma unroll
-		for (uint32_t k = 0; k < TW_PPW; k++)
-			if (k < mine)
-				reinterpret_cast<uint32_t *>(trials)[(uint64_t)(first + k) * 64 + lane] = res[k];
-	}
-}
-
-// Third form (round 4): what belongs to ONE packet -- header, FEC 2/3, decoded bytes, chunk registers and their starts, the
-// packet's 64 try_clock results -- is done by the wave that owns the packet with no workgroup barrier in between
-// (trials_wave_kernel's phase), but the trials are sorted by type over the whole BATCH of 64 packets as in
-// trials_linear_kernel, so that a pass of 64 trials is of one type: three barriers per batch instead of six, the
-// instruction count of the workgroup-wide sort.
-__global__ __launch_bounds__(TL_THREADS) void trials_hybrid_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
-							       uint32_t n_packets, btbbx_trial *trials)
-{
-	static_assert(TL_THREADS == 1024 && TL_PACKETS == 64, "sixteen waves of four packets");
-	__shared__ uint64_t pk[TL_PACKETS][BTBBX_PKT_WORDS + 1];
-	__shared__ __attribute__((aligned(8))) btbbx_pkt_in pin[TL_PACKETS];
-	__shared__ uint32_t hdr_ut[TL_PACKETS];
-	__shared__ uint16_t clk_ut[64];
-	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];
-	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
-	__shared__ __attribute__((aligned(16))) uint16_t advw[7 * 2 * 256];
-	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
-	__shared__ uint32_t t_info[TL_TRIALS];
-	__shared__ int16_t t_rv[TL_TRIALS];
-	__shared__ uint32_t type_count[16];                              // workgroup-wide: the sort is over all 4096 trials of the batch
-	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];
-	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];
-	__shared__ uint32_t a_bytes[TL_PACKETS][TL_A_BYTES / 4], b_bytes[TL_PACKETS][TL_B_BYTES / 4];
-	__shared__ uint32_t a_fail[TL_PACKETS], b_fail[TL_PACKETS];
-	__shared__ uint16_t p4a[TL_PACKETS][TL_A_BYTES / 4], p4b[TL_PACKETS][TL_B_BYTES / 4], p4c[TL_PACKETS][LIN_MAXLEN / 4];
-	__shared__ int8_t hv_rv[TL_PACKETS];
-	__shared__ uint16_t chunk_reg[TL_PACKETS][20];
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for (uint32_t i = tid; i < LIN_MAXLEN * 2; i += TL_THREADS)
-		reinterpret_cast<uint4 *>(lin)[i] = reinterpret_cast<const uint4 *>(g_lin)[i];
-	for (uint32_t i = tid; i < 7 * 2 * 256 / 8; i += TL_THREADS)
-		reinterpret_cast<uint4 *>(advw)[i] = reinterpret_cast<const uint4 *>(g_advw)[i];
-	chain_lds_init();                                       // ends with a barrier
-	if (tid >= 64 && tid < 128) {
-		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
-		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
-		const uint32_t v = (uint32_t)wh_bits(wh_start(tid - 64, 18), 7);
-		uint32_t x = 0;
-		for (int j = 0; j < 7; j++)
-			if ((v >> j) & 1)
-				x ^= lin[20 * 16 + 8 + j];
-		pw20[tid - 64] = (uint16_t)x;
-	}
-	__syncthreads();                                        // the last barrier: from here on every wave is on its own
-	auto wsync = [] {
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-	};
-	const uint32_t P0 = wave * TW_PPW, T0 = wave * TW_TRIALS;
-	const uint32_t n_batches = (n_packets + TL_PACKETS - 1) / TL_PACKETS;
-	// a wave's share of a batch is 4 x 51 packet words + 4 x 2 words of btbbx_pkt_in = 212 words, four per lane; the next
-	// batch's words fly while this one is worked on
-	constexpr uint32_t PK_ELEMS = TW_PPW * (BTBBX_PKT_WORDS + 1), IN_ELEMS = TW_PPW * 2, PER_LANE = (PK_ELEMS + IN_ELEMS + 63) / 64;
-	uint64_t pre[PER_LANE];
-	// packets of batch b this wave owns: 4 w .. 4 w + 3 of its (up to) 64
-	auto have_of = [&](uint32_t b) {
-		if (b >= n_batches)
-			return 0u;
-		const uint32_t in_batch = n_packets - b * TL_PACKETS < TL_PACKETS ? n_packets - b * TL_PACKETS : TL_PACKETS;
-		return in_batch > P0 ? (in_batch - P0 < TW_PPW ? in_batch - P0 : TW_PPW) : 0u;
-	};
-	// (the element -> (packet, word) arithmetic of the two lambdas is done where it is used: hoisted out of the batch loop
-	// it is thirty registers that live in scratch, and a reload from scratch counts on the same counter as the prefetch)
-	auto fetch = [&](uint32_t g) {
-		const uint32_t f = g * TL_PACKETS + P0, have = have_of(g);
-		uint32_t ln = lane;
-		asm volatile("" : "+v"(ln));
-#pragma unroll
-		for (uint32_t k = 0; k < PER_LANE; k++) {
-			const uint32_t i = ln + 64 * k;
-			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1), e = i - PK_ELEMS;
-			const uint64_t *src = packets;
-			if (i < PK_ELEMS) {
-				if (p < have && w < BTBBX_PKT_WORDS)
-					src = packets + (uint64_t)(f + p) * BTBBX_PKT_WORDS + w;
-			} else if (e < 2 * have) {
-				src = reinterpret_cast<const uint64_t *>(in) + (uint64_t)f * 2 + e;
-			}
-			pre[k] = *src;
-		}
-	};
-	auto stage_in = [&](uint32_t g) {
-		const uint32_t have = have_of(g);
-		uint32_t ln = lane;
-		asm volatile("" : "+v"(ln));
-#pragma unroll
-		for (uint32_t k = 0; k < PER_LANE; k++) {
-			const uint32_t i = ln + 64 * k;
-			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
-			if (i < PK_ELEMS)
-				pk[P0 + p][w] = (p < have && w < BTBBX_PKT_WORDS) ? pre[k] : 0;
-			else if (i < PK_ELEMS + IN_ELEMS)
-				reinterpret_cast<uint64_t *>(pin + P0)[i - PK_ELEMS] = pre[k];
-		}
-		if (lane < TW_PPW) {
-			a_fail[P0 + lane] = TL_A_BLOCKS;
-			b_fail[P0 + lane] = TL_B_BLOCKS;
-		}
-	};
-	if (tid < 16)
-		type_count[tid] = 0;
-	const uint32_t g0 = blockIdx.x, g_stride = gridDim.x;
-	fetch(g0);
-	stage_in(g0);
-	fetch(g0 + g_stride);
-	__syncthreads();
-	for (uint32_t g = g0; g < n_batches; g += g_stride) {
-		const uint32_t first = g * TL_PACKETS + P0, mine = have_of(g);
-		const uint32_t in_batch = n_packets - g * TL_PACKETS < TL_PACKETS ? n_packets - g * TL_PACKETS : TL_PACKETS;
-		// ---- A: everything that belongs to ONE packet, by the wave that owns it (no workgroup barrier inside) ----
-		wsync();                                            // this group is in LDS
-		// 1. try_clock's linear part, once per packet (see trials_linear_kernel)
-		if (lane < mine) {
-			uint32_t dis;
-			const uint32_t hdr = header_fec13(pk[P0 + lane], dis);
-			hdr_ut[P0 + lane] = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
-		}
-		auto a_words = [&](uint32_t p) {
-			const uint32_t blocks = lds_now(&a_fail[p]) < TL_A_BLOCKS ? lds_now(&a_fail[p]) : TL_A_BLOCKS, n = (blocks * 10 + 31) / 32 + 1;
-			return n < TL_A_BYTES / 4 ? n : (uint32_t)(TL_A_BYTES / 4);
-		};
-		// 2a. FEC 2/3 of both layouts: sixteen lanes per packet, no further round once a block of the packet has failed
-		{
-			const uint32_t q = lane >> 4, sub = lane & 15, p = P0 + q;
-			if (q < mine) {
-				uint32_t d;
-				if (sub < TL_B_BLOCKS) {
-					if (!fec23_block(pk_bits32(pk[p], 202 + 15 * sub, 15), d))
-						atomicMin(&b_fail[p], sub);
-					b10[p][sub] = (uint16_t)d;
-				}
-#pragma unroll 1
-				for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
-					const uint32_t k = k0 + sub;
-					if (k < TL_A_BLOCKS) {
-						if (!fec23_block(pk_bits32(pk[p], 122 + 15 * k, 15), d))
-							atomicMin(&a_fail[p], k);
-						a10[p][k] = (uint16_t)d;
-					}
-					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-					if (lds_now(&a_fail[p]) < k0 + 16)
-						break;
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				auto word_from = [&](const uint16_t *src, uint32_t nblk, uint32_t word) {
-					const uint32_t bit = 32 * word, k0 = bit / 10, sh = bit % 10;
-					uint64_t acc = 0;
-					for (uint32_t j = 0; j < 5; j++)
-						acc |= (uint64_t)(k0 + j < nblk ? src[k0 + j] : 0) << (10 * j);
-					return (uint32_t)(acc >> sh);
-				};
-				if (sub < TL_B_BYTES / 4)
-					b_bytes[p][sub] = word_from(b10[p], TL_B_BLOCKS, sub);
-				const uint32_t need = a_words(p);
-				for (uint32_t word = sub; word < need; word += 16)
-					a_bytes[p][word] = word_from(a10[p], TL_A_BLOCKS, word);
-			}
-		}
-		// HV1 verdict (:1131-1150): one lane of each packet's sixteen
-		if ((lane & 15) == 15 && (lane >> 4) < mine) {
-			const uint32_t p = P0 + (lane >> 4);
-			int rv = 1;
-			if ((int)pin[p].length - 122 >= 240) {
-				uint32_t total = 0;
-				for (int i = 0; i < 4; i++) {
-					uint32_t dis;
-					(void)fec13(pk_bits(pk[p], 122 + 60 * i, 60), 20, dis);
-					total += dis;
-				}
-				rv = total < 20 ? 2 : 0;
-			}
-			hv_rv[p] = (int8_t)rv;
-		}
-		wsync();
-		// 2b. the 64 trials of packet k: try_clock's result, counted by type (the wave's own counters)
-#pragma unroll 1
-		for (uint32_t k = 0; k < mine; k++) {
-			const uint32_t p = P0 + k, i = T0 + 64 * k + lane;
-			const uint32_t h = hdr_ut[p];
-			uint32_t uap = pin[p].uap, type = pin[p].type, ret = 0;     // FEC 1/3 failure: nothing changes
-			if (h & 0x10000u) {
-				const uint32_t v = (h ^ ((pin[p].flags & F_WHITENED) ? clk_ut[lane] : 0u)) & 0xffff;
-				uap = ret = v & 0xff;
-				type = v >> 8;
-			}
-			t_info[i] = ret | (type << 8) | (uap << 16);
-			t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
-		}
-		// 2c. chunk registers (see trials_linear_kernel): 20 chunk tasks per packet
-		auto chunk_of = [&](uint32_t t, uint32_t &p, uint32_t &r, uint32_t &layout, uint32_t &j, uint32_t &nwords) {
-			if (t < mine * 12) {
-				p = P0 + t / 12;
-				j = t % 12;
-				if (j < 11) { layout = 0; r = j; nwords = j < 10 ? 8 : LIN_MAXLEN / 4 - 80; }
-				else { layout = 2; r = 19; j = 0; nwords = TL_B_BYTES / 4; }
-			} else {
-				const uint32_t u = t - mine * 12;
-				p = P0 + u / 8;
-				j = u % 8;
-				layout = 1;
-				r = 11 + j;
-				const uint32_t need = a_words(p);
-				nwords = need > 8 * j ? (need - 8 * j < 8 ? need - 8 * j : 8) : 0;
-			}
-		};
-		auto data_word = [&](uint32_t p, uint32_t layout, uint32_t i) {
-			return layout == 0 ? pk_bits32(pk[p], 122 + 32 * i, 32) : layout == 1 ? a_bytes[p][i] : b_bytes[p][i];
-		};
-		auto chunk_words = [&](uint32_t p, uint32_t layout, uint32_t j, uint32_t nwords, uint32_t (&w8)[8]) {
-			if (layout == 0) {
-				const uint32_t *d = reinterpret_cast<const uint32_t *>(pk[p]) + 3 + 8 * j;
-				uint32_t raw[9];
-#pragma unroll
-				for (uint32_t i = 0; i < 9; i++)
-					raw[i] = i <= nwords ? d[i] : 0;
-#pragma unroll
-				for (uint32_t i = 0; i < 8; i++)
-					w8[i] = __builtin_amdgcn_alignbit(raw[i + 1], raw[i], 26);
-			} else {
-#pragma unroll
-				for (uint32_t i = 0; i < 8; i++)
-					w8[i] = i < nwords ? data_word(p, layout, 8 * j + i) : 0;
-			}
-		};
-		for (uint32_t t = lane; t < mine * 20; t += 64) {
-			uint32_t p, r, layout, j, nwords, crc = 0;
-			chunk_of(t, p, r, layout, j, nwords);
-			if (!nwords)
-				continue;
-			uint32_t w8[8];
-			chunk_words(p, layout, j, nwords, w8);
-			uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
-#pragma unroll
-			for (uint32_t i = 0; i < 8; i++)
-				if (i < nwords) {
-					dst[8 * j + i] = (uint16_t)crc;
-					crc = crc_word(crc, w8[i]);
-				}
-			chunk_reg[p][r] = (uint16_t)crc;
-		}
-		wsync();
-		// the chunk starts of the wave's packets (lanes 16 ..: dependent steps per layout)
-		if (lane >= 16 && lane < 16 + 3 * mine) {
-			const uint32_t p = P0 + (lane - 16) / 3, layout = (lane - 16) % 3;
-			const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
-			const uint32_t n = layout == 0 ? 11 : layout == 1 ? (a_words(p) + 7) / 8 : 1;
-			uint32_t start = 0;
-			for (uint32_t j = 0; j < n; j++) {
-				const uint32_t c = chunk_reg[p][r0 + j];
-				chunk_reg[p][r0 + j] = (uint16_t)start;
-				start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
-			}
-		}
-		__syncthreads();                                    // ---- B: every trial of the batch is counted under its type ----
-		// where each type's trials start in the batch's order: every wave works the sixteen sums out for itself (lanes
-		// 0 .. 15, an exclusive scan in registers), then puts its own 256 trials into the workgroup's order
-		{
-			uint32_t c = lane < 16 ? type_count[lane] : 0u, incl = c;
-#pragma unroll
-			for (int d = 1; d < 16; d <<= 1) {
-				const uint32_t u = __shfl_up(incl, d);
-				if (lane >= (uint32_t)d)
-					incl += u;
-			}
-			const uint32_t base_of_lane = incl - c;             // lane t < 16: start of type t
-#pragma unroll 1
-			for (uint32_t k = 0; k < mine; k++) {
-				const uint32_t i = T0 + 64 * k + lane;
-				const uint32_t tb = (uint32_t)__shfl((int)base_of_lane, (int)((t_info[i] >> 8) & 15));
-				order[tb + t_slot[i]] = (uint16_t)i;
-			}
-		}
-		__syncthreads();                                    // ---- C: the order is complete ----
-		if (tid < 16)
-			type_count[tid] = 0;                            // (read by everyone in front of this barrier, counted into again behind the next)
-		// 4. crc_check (:708-769) in type order
-		const uint32_t total = in_batch * 64;
-#pragma unroll 1
-		for (uint32_t kk = tid; kk < total; kk += TL_THREADS) {
-			const uint32_t i = order[kk], p = i >> 6, clock = i & 63;
-			const uint32_t info = t_info[i], type = (info >> 8) & 0xff, uap = (info >> 16) & 0xff;
-			const bool wht = pin[p].flags & F_WHITENED;
-			const int size = (int)pin[p].length - 122;
-			const uint32_t seed = crc_seed(uap);
-			const uint32_t sel = (seed >> 8) | (wht ? (uint32_t)wh_bits(wh_start(clock, 18), 7) << 8 : 0u);
-			auto seed_row20 = [&](uint32_t sd) {
-				const uint4 r0 = reinterpret_cast<const uint4 *>(lin)[40];
-				const uint32_t r[4] = {r0.x, r0.y, r0.z, r0.w};
-				uint32_t x = 0;
-#pragma unroll
-				for (int bit = 0; bit < 8; bit++)
-					x ^= (0u - ((sd >> (8 + bit)) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
-				return x & 0xffff;
-			};
-			auto lin_terms = [&](uint32_t L) {
-				uint32_t x = 0;
-#pragma unroll 1
-				for (int half = 0; half < 2; half++) {
-					const uint4 q = reinterpret_cast<const uint4 *>(lin)[2 * L + half];
-					const uint32_t r[4] = {q.x, q.y, q.z, q.w};
-					const uint32_t sl = sel >> (8 * half);
-#pragma unroll
-					for (int bit = 0; bit < 8; bit++)
-						x ^= (0u - ((sl >> bit) & 1)) & (r[bit >> 1] >> (16 * (bit & 1)));
-				}
-				return x & 0xffff;
-			};
-			auto data_reg = [&](int layout, uint32_t L) {
-				const uint32_t q = L >> 2, r = L & 3;
-				uint32_t crc, w;
-				if (layout == 0) { crc = p4c[p][q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
-				else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
-				else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
-				const uint32_t start = chunk_reg[p][(layout == 0 ? 0u : layout == 1 ? 11u : 19u) + (q >> 3)], iw = q & 7;
-				crc ^= iw ? (uint32_t)(advw[((iw - 1) * 2) * 256 + (start & 0xff)] ^ advw[((iw - 1) * 2 + 1) * 256 + (start >> 8)]) : start;
-				for (uint32_t j = 0; j < r; j++)
-					crc = crc_byte(crc, (w >> (8 * j)) & 0xff);
-				return crc;
-			};
-			auto crc_is_zero = [&](int layout, uint32_t L) {
-				return (data_reg(layout, L) ^ lin_terms(L)) == 0;
-			};
-			int rv = 1;
-			switch (type) {
-			case 2: {                                               // fhs (:783-818)
-				if (size < 240) { rv = 1; break; }
-				if (a_fail[p] < 16) { rv = 0; break; }
-				const uint32_t x = data_reg(1, 20) ^ seed_row20(seed);
-				rv = 0;
-				if (!wht) {
-					if (x == 0) rv = 1000;
-				} else {
-					uint32_t hit = x == pw20[clock];
-					const uint32_t xx = x | (x << 16);
-#pragma unroll 1
-					for (int v = 0; v < 4; v++) {
-						const uint4 q = reinterpret_cast<const uint4 *>(&pw20[32])[v];
-						const uint32_t d0 = q.x ^ xx, d1 = q.y ^ xx, d2 = q.z ^ xx, d3 = q.w ^ xx;
-						hit |= ((d0 & 0xffff) == 0) | ((d0 >> 16) == 0) | ((d1 & 0xffff) == 0) | ((d1 >> 16) == 0)
-						     | ((d2 & 0xffff) == 0) | ((d2 >> 16) == 0) | ((d3 & 0xffff) == 0) | ((d3 >> 16) == 0);
-					}
-					if (hit) rv = 1000;
-				}
-				break;
-			}
-			case 3: case 8: case 10: case 14:                       // DM (:898-958)
-			case 4: case 11: case 15: {                             // DH (:962-1011)
-				const bool fec = type == 3 || type == 8 || type == 10 || type == 14;
-				const int layout = !fec ? 0 : (type == 8 ? 2 : 1);
-				const int psize = type == 8 ? size - 80 : size;
-				const int hb = (type == 3 || type == 8 || type == 4) ? 1 : 2;
-				const int hbits = 8 * hb;
-				const uint32_t fail = layout == 2 ? b_fail[p] : a_fail[p];
-				rv = 0;
-				if (psize < hbits) break;
-				uint32_t raw;
-				if (fec) {
-					if (psize < (hb == 2 ? 30 : 15)) break;
-					if (fail < (uint32_t)hb) break;
-					raw = (layout == 2 ? b_bytes[p][0] : a_bytes[p][0]) & ((1u << hbits) - 1);
-				} else {
-					raw = pk_bits32(pk[p], 122, hbits);
-				}
-				const uint32_t ph = raw ^ (wht ? (uint32_t)wh_bits(wh_start(clock, 18), hbits) : 0u);
-				int plen = hb == 2 ? (int)((ph >> 3) & 0x3ff) + 4 : (int)((ph >> 3) & 0x1f) + 3;
-				int cap;
-				switch (type) {
-				case 3:  cap = 20;  break;
-				case 4:  cap = 30;  break;
-				case 8:  cap = 12;  break;
-				case 10: cap = 125; break;
-				case 11: cap = 187; break;
-				case 14: cap = 228; break;
-				default: cap = 343; break;
-				}
-				if (plen > cap) plen = cap;
-				const int nbits = plen * 8;
-				if (nbits > psize) { rv = 1; break; }
-				if (fec && fail < (uint32_t)(nbits + 9) / 10) break;
-				rv = crc_is_zero(layout, (uint32_t)plen) ? 10 : 2;
-				break;
-			}
-			case 12: {                                              // EV4 (:1044-1097)
-				uint32_t B = size >= 15 ? (uint32_t)size / 15 : 0;
-				if (B > 98) B = 98;
-				if (B > a_fail[p]) B = a_fail[p];
-				const uint32_t lmax = B ? 5 * (B - 1) / 4 : 0;
-				uint32_t crc = seed, idx = wh_start(clock, 18);
-				rv = B == 98 ? 2 : 1;
-				for (uint32_t L0 = 0; L0 < lmax; L0 += 4) {
-					const uint32_t w = a_bytes[p][L0 >> 2] ^ (wht ? (uint32_t)wh_bits(idx, 32) : 0u);
-					idx = idx + 32 >= 127 ? idx + 32 - 127 : idx + 32;
-					const uint32_t x0 = (crc ^ w) & 0xff, x1 = ((crc ^ w) >> 8) & 0xff, b2 = (w >> 16) & 0xff, b3 = w >> 24;
-					const uint32_t c1 = (crc >> 8) ^ g_lds.crc[x0];
-					const uint32_t c2 = g_lds.crc_z[0][x0] ^ g_lds.crc[x1];
-					const uint32_t c3 = g_lds.crc_z[1][x0] ^ g_lds.crc_z[0][x1] ^ g_lds.crc[b2];
-					const uint32_t c4 = g_lds.crc_z[2][x0] ^ g_lds.crc_z[1][x1] ^ g_lds.crc_z[0][b2] ^ g_lds.crc[b3];
-					const bool z1 = c1 == 0 && L0 + 1 >= 2 && L0 + 1 <= lmax, z2 = c2 == 0 && L0 + 2 <= lmax;
-					const bool z3 = c3 == 0 && L0 + 3 <= lmax, z4 = c4 == 0 && L0 + 4 <= lmax;
-					if (z1 || z2 || z3 || z4) { rv = 10; break; }
-					crc = c4;
-				}
-				break;
-			}
-			case 5: rv = hv_rv[p]; break;                           // HV1
-			default: rv = 1; break;
-			}
-			if (rv == 0 && type != 2 && type != 3 && type != 5)
-				rv = 1;
-			t_rv[i] = (int16_t)rv;
-		}
-		__syncthreads();                                    // ---- D: every trial has its result ----
-		// the results of the wave's own packets into registers, its share of the next batch into LDS and the one after that
-		// requested -- and only then the stores (one in-order counter for loads and stores, see trials_linear_kernel).
-		// Nothing another wave reads is touched from here to the next barrier B: phase A of the next batch needs no barrier.
-		uint32_t res[TW_PPW];
-#pragma unroll
-		for (uint32_t k = 0; k < TW_PPW; k++) {
-			const uint32_t i = T0 + 64 * k + lane;
-			res[k] = (t_info[i] & 0xffff) | ((uint32_t)(uint16_t)t_rv[i] << 16);
-		}
-		wsync();
-		stage_in(g + g_stride);
-		fetch(g + 2 * g_stride);
-		static_assert(sizeof(btbbx_trial) == 4, "one dword per trial");
-#pragma unroll
-		for (uint32_t k = 0; k < TW_PPW; k++)
-			if (k < mine)
-				reinterpret_cast<uint32_t *>(trials)[(uint64_t)(first + k) * 64 + lane] = res[k];
-		wsync();                                            // the next batch's share is in LDS
-	}
-}
-
+// Two other shapes of this kernel were built and measured in round 4 and are NOT in the source (kept as text in
+// profiles/r04_trials/, both bit-exact on every GPU test):
+//   * trials_wave_kernel: a WAVE owns four packets from first word to last result, no workgroup barrier at all.  It does
+//     what it was built for -- SQ_WAIT_ANY 72 % -> 43 % of the wave-cycles, VALU-active 9.6 % -> 22 % -- and is slower,
+//     1.33 against 0.94 ms per 2^20 packets: 780 VALU wave-instructions per packet against 421 (pmc_*.json there).  A
+//     sort over the 256 trials of four packets leaves four types in every pass of 64 (the workgroup-wide sort over 4096
+//     leaves one), so the DM/DH, FHS and EV4 code runs in every pass with a quarter of the lanes; the one-lane-per-
+//     packet steps are issued by every wave instead of one in sixteen; 80 chunk tasks on 64 lanes are two passes.
+//   * trials_hybrid_kernel: the packet-local phases wave-local as above, the type sort workgroup-wide as here, three
+//     barriers per batch instead of six: 1.10 ms (the redundant one-lane steps and the second chunk pass cost more than
+//     the three barriers saved).
+// What stayed: the a_fail reads below no longer go through a generic pointer (lds_now: a volatile generic read is a
+// FLAT load, which waits for every prefetched word in flight): 0.957 -> 0.944 ms.
 // Small batches (a handful of packets from a live receiver): one workgroup per (packet, clock),
 // lane 0 runs the trial.  64 x n waves spread over the CUs, none of them serialising different packet
 // types, so the call takes as long as the longest single trial -- the lane-per-clock kernel above is
@@ -3602,16 +2750,8 @@ extern "C" int btbbx_trials_device(const uint64_t *d_packets, const btbbx_pkt_in
 	} else {                     // per-packet FEC / CRC prefix work once, O(1) per DM / DH / FHS trial
 		const uint32_t batches = (n_packets + TL_PACKETS - 1) / TL_PACKETS;
 		const uint32_t resident = (uint32_t)ctx().num_cus * TL_WGS_PER_CU;
-#if TL_WAVE == 2
-		hipLaunchKernelGGL(trials_hybrid_kernel, dim3(batches < resident ? batches : resident), dim3(TL_THREADS), 0,
-				   (hipStream_t)hip_stream, d_packets, d_in, n_packets, d_trials);
-#elif TL_WAVE
-		hipLaunchKernelGGL(trials_wave_kernel, dim3(batches < resident ? batches : resident), dim3(TL_THREADS), 0,
-				   (hipStream_t)hip_stream, d_packets, d_in, n_packets, d_trials);
-#else
 		hipLaunchKernelGGL(trials_linear_kernel, dim3(batches < resident ? batches : resident), dim3(TL_THREADS), 0,
 				   (hipStream_t)hip_stream, d_packets, d_in, n_packets, d_trials);
-#endif
 	}
 #ifdef TL_PROFILE
 	if (n_packets > 256) {
