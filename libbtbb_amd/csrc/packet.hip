@@ -1007,6 +1007,12 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 	return *(volatile __attribute__((address_space(3))) const uint32_t *)p;
 }
 
+#ifndef TL_OPAQUE
+#define TL_OPAQUE 1                     // trials_linear_kernel: no hoisted index arithmetic, FEC loop not unrolled (spills, see fetch)
+#endif
+#ifndef TL_MERGE34
+#define TL_MERGE34 1                    // trials_linear_kernel: type bases per wave in registers, one barrier less per batch
+#endif
 #ifndef TL_LDSNOW
 #define TL_LDSNOW 1                     // trials_linear_kernel reads a_fail through lds_now (0: the volatile generic read of rounds 2-3)
 #endif
@@ -1060,6 +1066,9 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
 	__shared__ uint32_t type_count[16], type_base[16];
+#if TL_MERGE34
+	__shared__ uint32_t type_base_w[TL_THREADS / 64][16];
+#endif
 	// per packet
 	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
 	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];       // ... DV data at 202
@@ -1095,11 +1104,18 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	static_assert(sizeof(btbbx_pkt_in) == 16, "two words per btbbx_pkt_in");
 	uint64_t pre[PER_THREAD];
 	// every load unconditional, from a clamped address (validity is applied when the words go to LDS)
+	// (round 4: the element -> (packet, word) arithmetic of the two lambdas is done where it is used -- `tv` is opaque to the
+	// compiler --: hoisted out of the batch loop it is a dozen registers that live in scratch, and a reload from scratch counts
+	// on the same in-order counter as the prefetched words)
 	auto fetch = [&](uint32_t b) {
 		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
+		uint32_t tv = tid;
+#if TL_OPAQUE
+		asm volatile("" : "+v"(tv));
+#endif
 #pragma unroll
 		for (uint32_t k = 0; k < PER_THREAD; k++) {
-			const uint32_t i = tid + TL_THREADS * k;
+			const uint32_t i = tv + TL_THREADS * k;
 			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1), e = i - PK_ELEMS;
 			const uint64_t *src = packets;
 			if (i < PK_ELEMS) {
@@ -1114,9 +1130,13 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	// the prefetched words of batch b go to LDS (and the per-batch counters are reset)
 	auto stage_in = [&](uint32_t b) {
 		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
+		uint32_t tv = tid;
+#if TL_OPAQUE
+		asm volatile("" : "+v"(tv));
+#endif
 #pragma unroll
 		for (uint32_t k = 0; k < PER_THREAD; k++) {
-			const uint32_t i = tid + TL_THREADS * k;
+			const uint32_t i = tv + TL_THREADS * k;
 			const uint32_t p = i / (BTBBX_PKT_WORDS + 1), w = i % (BTBBX_PKT_WORDS + 1);
 			if (i < PK_ELEMS)
 				pk[p][w] = (p < have && w < BTBBX_PKT_WORDS) ? pre[k] : 0;
@@ -1173,6 +1193,9 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 					atomicMin(&b_fail[p], sub);
 				b10[p][sub] = (uint16_t)d;
 			}
+#if TL_OPAQUE
+#pragma unroll 1
+#endif
 			for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
 				const uint32_t k = k0 + sub;
 				if (k < TL_A_BLOCKS) {
@@ -1295,6 +1318,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(8);
+#if !TL_MERGE34
 	if (tid == 0) {
 		uint32_t run = 0;
 		for (uint32_t t = 0; t < 16; t++) {
@@ -1302,6 +1326,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			run += type_count[t];
 		}
 	}
+#endif
 	if (tid >= 64 && tid < 64 + 3 * mine) {
 		const uint32_t p = (tid - 64) / 3, layout = (tid - 64) % 3;
 		const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
@@ -1313,11 +1338,31 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
 		}
 	}
+#if TL_MERGE34
+	// (round 4) no barrier here: the chunk starts above are wanted by the trials, not by the order pass, and where a type's
+	// trials start is worked out by every wave for itself from the sixteen counters (lanes 0 .. 15, a scan in registers)
+	// instead of by thread 0 in sixteen dependent LDS steps behind a barrier of their own
+	{
+		uint32_t c = lane < 16 ? type_count[lane] : 0u, incl = c;
+#pragma unroll
+		for (int d = 1; d < 16; d <<= 1) {
+			const uint32_t u = __shfl_up(incl, d);
+			if (lane >= (uint32_t)d)
+				incl += u;
+		}
+		if (lane < 16)
+			type_base_w[tid >> 6][lane] = incl - c;             // the wave's own copy (LDS operations of a wave complete in order)
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		for (uint32_t i = tid; i < total; i += TL_THREADS)
+			order[type_base_w[tid >> 6][(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
+	}
+#else
 	__syncthreads();
 	TL_PROF(9);
 	TL_PROF(3);
 	for (uint32_t i = tid; i < total; i += TL_THREADS)
 		order[type_base[(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
+#endif
 	__syncthreads();
 	TL_PROF(4);
 	TL_SETPRIO(3);

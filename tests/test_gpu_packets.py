@@ -323,6 +323,63 @@ def test_decode_with_the_count_in_hbm():
         assert np.array_equal(len_c[:k], len_f[:k]) and not len_c[k:].any(), count
 
 
+def test_piconet_decode_entry_equals_the_per_packet_form():
+    """btbbx_decode_hits_piconet_device (one entry state for all packets, clock = entry.clkn + offset / clk_div worked out in the
+    kernel) against btbbx_decode_hits_counted_device with the same clocks written into a btbbx_pkt_in per packet: byte-identical
+    records -- with a divisor above the stream length (every packet at the entry's clock: the packets were built for it and decode),
+    with 625 and 4096 (clocks from the offsets), with and without the count in HBM."""
+    lib = bt.lib()
+    rng = np.random.default_rng(_libs.seed(97))
+    n_streams, n_words = 4, 1 << 14
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    lap, uap, clk6 = 0x5A17C3, 0x6B, 0x19
+    rows, pos = [], [100 + int(rng.integers(0, 64)) for _ in range(n_streams)]
+    types = (synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_DM3, synth.TYPE_DH3, synth.TYPE_DM5, synth.TYPE_DH5, synth.TYPE_FHS, synth.TYPE_HV3)
+    for i in range(900):
+        st, t = i % n_streams, types[(i // n_streams) % len(types)]
+        nb = 30 if t == synth.TYPE_HV3 else int(rng.integers(0, LONG_MAXBODY.get(t, 0) + 1))
+        p = synth.build_packet(lap, uap, clk6, t, lt_addr=1 + i % 7, flags=i % 8, body=rng.integers(0, 256, nb, dtype=np.uint8).tobytes(),
+                               fhs_bits=synth.fhs_payload(lap, uap, 0x1234, i, rng))[:bt.MAX_SYMBOLS]
+        if pos[st] + len(p) + 300 > n_words * 64:
+            continue
+        sym[st, pos[st]:pos[st] + len(p)] = p
+        rows.append((st, pos[st]))
+        pos[st] += len(p) + int(rng.integers(1, 150))
+    n = len(rows)
+    assert n > 400
+    hits = np.zeros(n, bt.HIT_DTYPE)
+    hits["stream"], hits["offset"] = [r[0] for r in rows], [r[1] for r in rows]
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    flags = (1 << 0) | (1 << 2) | (1 << 4)
+    entry = np.zeros(1, bt.PKTIN_DTYPE)
+    d_w = bt.DeviceBuffer(words.nbytes).upload(words)
+    d_h = bt.DeviceBuffer(hits.nbytes).upload(hits)
+    good = 0
+    for clk_div, base, count in ((1 << 30, clk6, None), (625, 5, n), (4096, 0x123456, n - 7)):
+        entry["clkn"], entry["flags"], entry["uap"] = base, flags, uap
+        pin = np.zeros(n, bt.PKTIN_DTYPE)
+        pin["clkn"] = (base + hits["offset"] // clk_div).astype(np.uint32)
+        pin["flags"], pin["uap"] = flags, uap
+        want, len_w = bt.run_decode_hits(words, hits, pin, count=count)
+        d_out = bt.DeviceBuffer(n * bt.PKTOUT_DTYPE.itemsize).zero()
+        d_len = bt.DeviceBuffer(n * 4).zero()
+        d_cnt = bt.DeviceBuffer(8).upload(np.array([count or 0, 0], dtype=np.uint32))
+        bt.check(lib.btbbx_decode_hits_piconet_device(d_w.ptr, n_words, n_words, d_h.ptr, d_cnt.ptr if count is not None else None, n,
+                                                      entry.ctypes.data_as(C.c_void_p), clk_div, bt.MAX_SYMBOLS, d_out.ptr, d_len.ptr, None))
+        bt.check(lib.btbbx_sync(None))
+        got = d_out.download(bt.PKTOUT_DTYPE, n)
+        assert got.tobytes() == want.tobytes(), (clk_div, [i for i in range(n) if got[i].tobytes() != want[i].tobytes()][:5])
+        assert np.array_equal(d_len.download(np.uint32, n), len_w)
+        good = max(good, int((got["payload_rv"] == 10).sum() + (got["payload_rv"] == 1000).sum()))
+        for b in (d_out, d_len, d_cnt):
+            b.free()
+    assert good > 300                                             # the packets built for the entry's clock decode with it
+    assert lib.btbbx_decode_hits_piconet_device(d_w.ptr, n_words, n_words, d_h.ptr, None, n, entry.ctypes.data_as(C.c_void_p), 0,
+                                                bt.MAX_SYMBOLS, d_w.ptr, None, None) < 0          # clk_div = 0 is refused
+    d_w.free()
+    d_h.free()
+
+
 def test_decode_from_the_streams_equals_gather_then_decode():
     """btbbx_decode_hits_device reads the packets where they lie: same btbbx_pkt_out, byte for byte, as cutting
     them out first -- for every bit alignment, for captures cut short by the end of the stream (the decoders
