@@ -1065,9 +1065,11 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
 	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
-	__shared__ uint32_t type_count[16], type_base[16];
+	__shared__ uint32_t type_count[16];
 #if TL_MERGE34
 	__shared__ uint32_t type_base_w[TL_THREADS / 64][16];
+#else
+	__shared__ uint32_t type_base[16];
 #endif
 	// per packet
 	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
@@ -1543,7 +1545,11 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 //     barriers per batch instead of six: 1.10 ms (the redundant one-lane steps and the second chunk pass cost more than
 //     the three barriers saved).
 // What stayed: the a_fail reads below no longer go through a generic pointer (lds_now: a volatile generic read is a
-// FLAT load, which waits for every prefetched word in flight): 0.957 -> 0.944 ms.
+// FLAT load, which waits for every prefetched word in flight): 0.957 -> 0.944 ms; the index arithmetic of fetch / stage_in is
+// kept out of the batch loop's preheader and the FEC loop rolled (13 spilled registers -> none); every wave works the type
+// bases out for itself, which takes thread 0's sixteen dependent LDS steps and their barrier off the path.  The last two
+// are within the noise (0.927-0.938 ms; 670 -> 689 M packets/s on random packets of every type, profiles/r04_trials/
+// trials_ab2.txt): the kernel waits on the dependent LDS steps of its phases, not on these.
 // Small batches (a handful of packets from a live receiver): one workgroup per (packet, clock),
 // lane 0 runs the trial.  64 x n waves spread over the CUs, none of them serialising different packet
 // types, so the call takes as long as the longest single trial -- the lane-per-clock kernel above is
