@@ -33,7 +33,8 @@ struct OrderParams {
 	uint32_t shift;                            // bucket = lin >> shift
 	uint32_t ticket;                           // last workgroup of the extent pass works the parameters out
 	uint32_t crowded;                          // some bucket has more than ORDER_SMALL members (set by the scan of the counts)
-	uint32_t pad[2];
+	uint32_t n_work;                           // records that share their bucket (order_scatter_kernel's worklist)
+	uint32_t pad;
 };
 
 #define ORDER_SMALL 48u                        // bucket-mates up to here are ranked by a plain loop
@@ -223,37 +224,57 @@ __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, u
 
 // `final` (may be null): where a record that is alone in its bucket goes instead of `grouped` -- its bucket start IS its
 // rank, so when the list was parked somewhere else by the scan (btbbx_scan_ordered_device) the scatter is also the copy
-// into place and only the records that share a bucket are looked at again (order_rank_buckets_kernel)
-__global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, const OrderParams *p, const uint32_t *start,
-							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final)
+// into place and only the records that share a bucket are looked at again (order_rank_list_kernel)
+// `work` (with `final`): the positions in `grouped` of the records that share a bucket, appended with one counter atomic
+// per wave -- order_rank_list_kernel then ranks exactly those, one thread per record
+__global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, OrderParams *p, const uint32_t *start,
+							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final, uint32_t *work)
 {
 	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
-	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-		const btbbx_hit h = hits[i];
-		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
-		const uint32_t s0 = start[b], k = start[b + 1] - s0;      // a bucket of one (more than half of the records) needs no cursor
-		const uint32_t pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
-		HitRec *dst = reinterpret_cast<HitRec *>(k == 1 && final ? final : grouped);
-		dst[pos] = *reinterpret_cast<const HitRec *>(&h);
+	const uint32_t rounds = (n + gridDim.x * 256 - 1) / (gridDim.x * 256);       // every lane of a wave runs the same number of rounds (ballots)
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t i = r * gridDim.x * 256 + blockIdx.x * 256 + threadIdx.x;
+		bool shared = false;
+		uint32_t pos = 0;
+		if (i < n) {
+			const btbbx_hit h = hits[i];
+			const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+			const uint32_t s0 = start[b], k = start[b + 1] - s0;  // a bucket of one (more than half of the records) needs no cursor
+			pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
+			HitRec *dst = reinterpret_cast<HitRec *>(k == 1 && final ? final : grouped);
+			dst[pos] = *reinterpret_cast<const HitRec *>(&h);
+			shared = k > 1 && k <= ORDER_SMALL;
+		}
+		if (work) {
+			const uint64_t m = __ballot(shared);
+			if (m) {
+				uint32_t base = 0;
+				if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m))
+					base = atomicAdd(&p->n_work, (uint32_t)__popcll(m));
+				base = (uint32_t)__shfl((int)base, __builtin_ctzll(m));
+				if (shared)
+					work[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pos;
+			}
+		}
 	}
 }
 
-// The ranking for a list whose singletons are in place already: one thread per BUCKET, and only buckets of 2 .. ORDER_SMALL
-// members have work (a pass over the bucket starts -- 4 bytes per bucket, coalesced -- instead of one over every record)
-__global__ __launch_bounds__(256) void order_rank_buckets_kernel(const btbbx_hit *grouped, const uint32_t *start, uint32_t nb, btbbx_hit *out)
+// one thread per record of the worklist: rank among its bucket-mates (they sit in L1 / L2), into place
+__global__ __launch_bounds__(256) void order_rank_list_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
+							      const uint32_t *work, btbbx_hit *out)
 {
-	for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nb; b += gridDim.x * 256) {
+	const uint32_t n_work = p->n_work, shift = p->shift;
+	const unsigned long long mul = p->mul;
+	for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < n_work; w += gridDim.x * 256) {
+		const uint32_t i = work[w];
+		const btbbx_hit h = grouped[i];
+		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
 		const uint32_t s = start[b], k = start[b + 1] - s;
-		if (k < 2 || k > ORDER_SMALL)
-			continue;                                   // in place already / order_crowded_kernel's
-		for (uint32_t i = 0; i < k; i++) {
-			const btbbx_hit h = grouped[s + i];
-			uint32_t rank = 0;
-			for (uint32_t j = 0; j < k; j++)
-				rank += order_before(grouped[s + j], s + j, h, s + i) ? 1u : 0u;
-			reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
-		}
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < k; j++)
+			rank += order_before(grouped[s + j], s + j, h, i) ? 1u : 0u;
+		reinterpret_cast<HitRec *>(out)[s + rank] = *reinterpret_cast<const HitRec *>(&h);
 	}
 }
 
@@ -404,7 +425,7 @@ static uint32_t order_nb_log2(uint32_t cap)
 	return l;
 }
 
-struct OrderLayout { size_t params, start, cursor, sums, grouped, parked, total; uint32_t nb_log2; };
+struct OrderLayout { size_t params, start, cursor, sums, grouped, parked, work, total; uint32_t nb_log2; };
 static OrderLayout order_layout(uint32_t cap)
 {
 	OrderLayout L;
@@ -417,7 +438,8 @@ static OrderLayout order_layout(uint32_t cap)
 	L.sums = L.cursor + up(nb * 4);
 	L.grouped = L.sums + up(1024 * 4);
 	L.parked = L.grouped + up((size_t)cap * sizeof(btbbx_hit));      // where btbbx_scan_ordered_device's scan leaves its list
-	L.total = L.parked + up((size_t)cap * sizeof(btbbx_hit));
+	L.work = L.parked + up((size_t)cap * sizeof(btbbx_hit));        // positions of the records that share a bucket
+	L.total = L.work + up((size_t)cap * 4);
 	return L;
 }
 
@@ -477,12 +499,14 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 			   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
 	if (counted_by_scan) {
-		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the shared buckets by bucket
+		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records of the worklist
 		const btbbx_hit *parked = (const btbbx_hit *)(base + L.parked);
-		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits);
-		hipLaunchKernelGGL(order_rank_buckets_kernel, dim3(std::min((nb + 255) / 256, 2048u)), dim3(256), 0, stream, grouped, start, nb, d_hits);
+		uint32_t *work = (uint32_t *)(base + L.work);
+		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits, work);
+		hipLaunchKernelGGL(order_rank_list_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, work, d_hits);
 	} else {
-		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped, (btbbx_hit *)nullptr);
+		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped, (btbbx_hit *)nullptr,
+				   (uint32_t *)nullptr);
 		hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
 	}
 	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits);
