@@ -58,6 +58,9 @@ __device__ __attribute__((aligned(16))) uint16_t g_advw[7 * 2 * 256];
 // zero bit through the register: invertible), what lane j of the long-payload phase of decode_hits_kernel applies to the
 // register of payload word j alone
 __device__ __attribute__((aligned(16))) uint16_t g_adv64inv[64 * 16];
+// g_adv64fwd[j][k]: the register 64 j zero bits AFTER holding 1 << k -- A^(+64 j): carries the XOR the lanes of an EV4 / EV5
+// payload have accumulated in front of word j back into the true register in front of that word
+__device__ __attribute__((aligned(16))) uint16_t g_adv64fwd[64 * 16];
 
 static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
 {
@@ -189,6 +192,16 @@ int chain_upload(const HostTables &t)
 			}
 		}
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_adv64inv), adv64inv, sizeof(adv64inv)));
+		static uint16_t adv64fwd[64 * 16];
+		for (int k = 0; k < 16; k++) {
+			uint32_t c = 1u << k;
+			for (int j = 0; j < 64; j++) {
+				adv64fwd[j * 16 + k] = (uint16_t)c;
+				for (int b = 0; b < 8; b++)
+					c = host_crc_byte(c, 0);
+			}
+		}
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_adv64fwd), adv64fwd, sizeof(adv64fwd)));
 	}
 	ChainTables c;
 	memset(&c, 0, sizeof(c));
@@ -206,6 +219,9 @@ int chain_upload(const HostTables &t)
 #define F_CLK6_VALID  (1u << 4)
 #define F_HAS_PAYLOAD (1u << 7)
 #define DHL_MIN_BITS  256              // payloads longer than this leave decode_hits_kernel's lanes for its wave phase (= 64 DH_OUT_WORDS)
+#ifndef DH_LONG_EV
+#define DH_LONG_EV 1                   // EV4 / EV5 payloads go there too (0: their lanes walk them, rounds 1-3)
+#endif
 
 // ---- bit helpers ----------------------------------------------------------------------------
 
@@ -527,19 +543,26 @@ __device__ __forceinline__ bool fec23_ok(const PState &s, uint32_t pos, uint32_t
 	return true;
 }
 
-// The payload of s (nbits bits, FEC 2/3 or not) is left to decode_long_kernel: what that kernel needs, sixteen bytes.
+// The payload of s is left to the lane-group phase (long_payloads): what that phase needs, sixteen bytes.
 //   a: address of the stream word the packet starts in | stream words to load << 48 | bit the packet starts at << 55
-//   b: record index | captured length << 8 | payload bits << 20 | fec << 32 | whitened << 33 | whitening phase of the
-//      payload's first bit << 34 | UAP << 41
-__device__ __forceinline__ void defer_payload(PState &s, uint32_t clock, uint32_t nbits, bool fec)
+//   b: record index | captured length << 8 | bits << 20 | kind << 32 | whitened << 34 | whitening phase of the payload's
+//      first bit << 35 | UAP << 42
+// kind / bits: DHL_DH, DHL_DM: payload_length * 8; DHL_EV4: ten per block its loop may look at (min(98, size / 15));
+// DHL_EV5: eight per byte its loop may write (min(182, size / 8))
+#define DHL_DH  0u
+#define DHL_DM  1u
+#define DHL_EV4 2u
+#define DHL_EV5 3u
+__device__ __forceinline__ void defer_payload(PState &s, uint32_t clock, uint32_t nbits, uint32_t kind)
 {
 	// stream words the decoder looks at: 122 symbols of access code and header, then the payload -- FEC 2/3 blocks may
-	// lie behind the captured length (they read as zeros), never behind word 45; nothing behind the stream's end is loaded
-	const uint32_t ext = fec ? 15u * ((nbits + 9u) / 10u) : nbits;
+	// lie behind the captured length (they read as zeros), never behind word 45; EV5 reads one byte; nothing
+	// behind the stream's end is loaded
+	const uint32_t ext = kind == DHL_DH ? nbits : kind == DHL_EV5 ? 8u : 15u * ((nbits + 9u) / 10u);
 	const uint32_t nw = (s.sh + 122u + ext + 63u) >> 6;
 	const uint64_t a = (uint64_t)(uintptr_t)s.w | (uint64_t)(nw < s.wlimit ? nw : s.wlimit) << 48 | (uint64_t)s.sh << 55;
-	const uint64_t b = (uint64_t)s.def_pkt8 | (uint64_t)(uint32_t)s.length << 8 | (uint64_t)nbits << 20 | (uint64_t)fec << 32
-		| (uint64_t)((s.flags & 1u) ? 1u : 0u) << 33 | (uint64_t)wh_start(clock, 18) << 34 | (uint64_t)(s.uap & 0xffu) << 41;
+	const uint64_t b = (uint64_t)s.def_pkt8 | (uint64_t)(uint32_t)s.length << 8 | (uint64_t)nbits << 20 | (uint64_t)kind << 32
+		| (uint64_t)((s.flags & 1u) ? 1u : 0u) << 34 | (uint64_t)wh_start(clock, 18) << 35 | (uint64_t)(s.uap & 0xffu) << 42;
 	*s.def_slot = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 	s.def_nbits = nbits;
 }
@@ -697,7 +720,7 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 		return 1;
 	uint32_t nblocks = (nbits + 9) / 10;
 	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
-		defer_payload(s, clock, (uint32_t)nbits, true);
+		defer_payload(s, clock, (uint32_t)nbits, DHL_DM);
 		return 2;                                           // (replaced by decode_long_kernel's verdict)
 	}
 	// The reference writes nothing when a block fails.  Into HBM that takes a pass over all blocks first; a scratch copy
@@ -755,7 +778,7 @@ __device__ __forceinline__ int do_DH(PState &s, uint32_t clock)
 	if (nbits > size)
 		return 1;
 	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
-		defer_payload(s, clock, (uint32_t)nbits, false);
+		defer_payload(s, clock, (uint32_t)nbits, DHL_DH);
 		return 2;                                           // (replaced by decode_long_kernel's verdict)
 	}
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
@@ -1739,8 +1762,23 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 				if (payload_rv <= 1)
 					payload_rv = do_HV<true>(s, clock);
 				break;
+#if DH_LONG_EV
+			case 12: case 13: {
+				// EV4 / EV5 into HBM: the lane-group phase (payload_length and the verdict come from ev_payloads)
+				const uint32_t size = s.length - 122u, unit = s.type == 12 ? 15u : 8u;
+				if (s.def_slot && !s.out.l && s.length >= 122u + unit) {
+					const uint32_t most = s.type == 12 ? 98u : 182u, units = size / unit < most ? size / unit : most;
+					defer_payload(s, clock, (s.type == 12 ? 10u : 8u) * units, s.type == 12 ? DHL_EV4 : DHL_EV5);
+					payload_rv = 2;
+				} else {
+					payload_rv = s.type == 12 ? do_EV4<true>(s, clock) : do_EV35<true>(s, clock, 182);
+				}
+				break;
+			}
+#else
 			case 12: payload_rv = do_EV4<true>(s, clock); break;
 			case 13: payload_rv = do_EV35<true>(s, clock, 182); break;
+#endif
 			}
 			s.flags |= F_HAS_PAYLOAD;
 		}
@@ -1943,6 +1981,7 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 	dhl_u32_t *const area32 = (dhl_u32_t *)area;
 	const uint32_t G = 1u << logg, R = 64u >> logg;
 	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
+	const uint64_t gmask = G == 64 ? ~0ULL : (1ULL << G) - 1;
 	area[DHL_PB + lane] = 0;
 	if (lane < 2)
 		area[DHL_STG + 128 + lane] = 0;
@@ -1968,8 +2007,7 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 				| (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
 		};
 		// the words of round r on their way: two stream words of the group's packet -- DH: the two that hold payload word
-		// `sub`, DM: words sub and sub + G of the packet -- and, for the lane that will write a partial last word, what the
-		// record holds there
+		// `sub`; DM: words sub and sub + G of the packet
 		auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
 			const uint32_t e = r * R + grp;
 			w0 = 0;
@@ -1977,8 +2015,8 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 			if (e < n_def) {
 				const uint64_t a = uni(area[DHL_LIST + 2 * e]), b = uni(area[DHL_LIST + 2 * e + 1]);
 				dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
-				const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
-				const bool p_fec = (b >> 32) & 1u;
+				const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u, kind = (uint32_t)(b >> 32) & 3u;
+				const bool p_fec = kind == DHL_DM;
 				const uint32_t i0 = p_fec ? sub : sub + ((p_sh + 122u) >> 6), i1 = p_fec ? sub + G : i0 + 1u;
 				if (i0 < p_nw)
 					w0 = src[i0];
@@ -2002,8 +2040,8 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 			}
 			const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
 			const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
-			const uint32_t p_widx = (uint32_t)(pb >> 34) & 127u, p_uap = (uint32_t)(pb >> 41) & 0xffu;
-			const bool p_fec = has && ((pb >> 32) & 1u), p_wht = (pb >> 33) & 1u;
+			const uint32_t kind = (uint32_t)(pb >> 32) & 3u, p_widx = (uint32_t)(pb >> 35) & 127u, p_uap = (uint32_t)(pb >> 42) & 0xffu;
+			const bool p_fec = has && kind == DHL_DM, p_wht = (pb >> 34) & 1u;
 			const uint32_t nblocks = (nbits + 9u) / 10u;
 			const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
 			const bool active = has && sub < nwp;
@@ -2012,7 +2050,7 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 			// path, and the compiler needs no second one in front of the next request)
 			const uint32_t sft = (p_sh + 122u) & 63u;
 			const uint64_t funnel = sft ? (nw0 >> sft) | (nw1 << (64u - sft)) : nw0;
-			uint64_t word = has && !p_fec ? funnel : 0ULL;
+			uint64_t word = has && kind == DHL_DH ? funnel : 0ULL;
 			const uint64_t any_fec = __ballot(p_fec);
 			if (any_fec) {
 				// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
@@ -2074,7 +2112,7 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 			if (active && sub == T)
 				oldw = outs[p_pkt].payload[sub];
 			const uint64_t fail_mask = __ballot(fail);
-			const bool group_fail = ((fail_mask >> gbase) & (G == 64 ? ~0ULL : (1ULL << G) - 1)) != 0;
+			const bool group_fail = ((fail_mask >> gbase) & gmask) != 0;
 			// 3. unwhitened, cut at the payload length
 			uint64_t out = 0, keep_mask = ~0ULL;
 			if (active) {
@@ -2087,13 +2125,12 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 			}
 			// 4. CRC: the word alone (the seed's bits on the first sixteen of the payload), carried back over the words in front of it
 			const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
-			uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
-			reg = apply_columns(col, reg);
-			const uint32_t total = group_xor(reg, logg);
+			const uint32_t reg0 = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+			const uint32_t total = group_xor(apply_columns(col, reg0), logg);
 			int rv = total == 0 ? 10 : 2;
 			if (p_fec && group_fail)
 				rv = 0;
-			// 5. out (nothing when a block failed)
+			// 5. out (DM: nothing when a block failed)
 			st_do = active && rv != 0;
 			st_val = sub == T ? out | (oldw & ~keep_mask) : out;
 			st_pkt = p_pkt;
@@ -2111,22 +2148,231 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 		run(std::false_type{});
 }
 
+// EV4 (:1044-1097) and EV5 (:1099-1128) payloads of a wave, in a loop of their own (rare types; and what they keep in
+// registers -- two more matrices, a prefix over the lanes, eight registers per word -- stays out of long_payloads, whose
+// allocation decides the occupancy of decode_hits_kernel).  n_ev list entries from DHL_LIST + 2 first on; G = 8 .. 32 lanes
+// per packet, one per payload word.  The first byte count L whose CRC register is zero ends the payload:
+//   register in front of word `sub` = A^(64 sub) applied to the XOR over the words j in front of it of A^(-64 (j + 1))
+//   (register of word j alone)  -- a per-lane matrix, a plain XOR prefix over the lanes, a per-lane matrix --,
+// then the lane's eight bytes one by one, a zero register noted per byte; the lowest lane with a noted byte decides.
+// A round's stream words are asked for one round ahead; the record's old last word is read where the length is known.
+__device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uint32_t n_ev, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
+{
+	dhl_u32_t *const area32 = (dhl_u32_t *)area;
+	const uint32_t G = 1u << logg, R = 64u >> logg;
+	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
+	const uint64_t gmask = (1ULL << G) - 1;                     // (G <= 32: an EV payload has at most 23 words)
+	area[DHL_PB + lane] = 0;
+	if (lane < 2)
+		area[DHL_STG + 128 + lane] = 0;
+	const uint32_t wh_lane = (64u * sub) % 127u;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t rounds = (n_ev + R - 1) >> (6 - logg);
+	// this lane's two matrices: A^(-64 (sub + 1)) and A^(64 sub), sixteen 16-bit columns each
+	uint32_t rinv[8], rfwd[8];
+	{
+		const uint4 *si = reinterpret_cast<const uint4 *>(g_adv64inv) + 2 * (sub + 1), *sf = reinterpret_cast<const uint4 *>(g_adv64fwd) + 2 * sub;
+		const uint4 a = si[0], b = si[1], c = sf[0], d = sf[1];
+		rinv[0] = a.x; rinv[1] = a.y; rinv[2] = a.z; rinv[3] = a.w; rinv[4] = b.x; rinv[5] = b.y; rinv[6] = b.z; rinv[7] = b.w;
+		rfwd[0] = c.x; rfwd[1] = c.y; rfwd[2] = c.z; rfwd[3] = c.w; rfwd[4] = d.x; rfwd[5] = d.y; rfwd[6] = d.z; rfwd[7] = d.w;
+	}
+	// the stream words of round r: EV4 words sub and sub + G of the packet (its blocks all lie inside the capture:
+	// min(98, size / 15)); EV5 reads ONE byte, every payload byte is the first one under the whitening of its place
+	auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
+		const uint32_t e = r * R + grp;
+		w0 = 0;
+		w1 = 0;
+		if (e < n_ev) {
+			const uint64_t a = area[DHL_LIST + 2 * (first + e)], b = area[DHL_LIST + 2 * (first + e) + 1];
+			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
+			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
+			const bool is4 = ((uint32_t)(b >> 32) & 3u) == DHL_EV4;
+			const uint32_t i0 = is4 ? sub : (p_sh + 122u) >> 6, i1 = is4 ? sub + G : i0 + 1u;
+			if (is4 || sub == 0) {
+				if (i0 < p_nw)
+					w0 = src[i0];
+				if (i1 < p_nw)
+					w1 = src[i1];
+			}
+		}
+	};
+	uint64_t nw0, nw1;
+	request(0, nw0, nw1);
+#pragma unroll 1
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t e = r * R + grp;
+		const bool has = e < n_ev;
+		uint64_t pa = 0, pb = 0;
+		if (has) {
+			pa = area[DHL_LIST + 2 * (first + e)];
+			pb = area[DHL_LIST + 2 * (first + e) + 1];
+		}
+		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
+		const uint32_t p_pkt = (uint32_t)pb & 0xffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
+		const uint32_t kind = (uint32_t)(pb >> 32) & 3u, p_widx = (uint32_t)(pb >> 35) & 127u, p_uap = (uint32_t)(pb >> 42) & 0xffu;
+		const bool p_wht = (pb >> 34) & 1u, is4 = has && kind == DHL_EV4;
+		const uint32_t nblocks = nbits / 10u;                   // (EV4)
+		// 1. the stream words asked for a round ago
+		const uint64_t w0 = nw0, w1 = nw1;
+		const uint32_t sft = (p_sh + 122u) & 63u;
+		const uint32_t low8 = (uint32_t)(sft ? (w0 >> sft) | (w1 << (64u - sft)) : w0) & 0xffu;
+		const uint32_t first8 = (uint32_t)__shfl((int)low8, (int)gbase);
+		uint64_t word = (uint64_t)(first8 * 0x01010101u) | (uint64_t)(first8 * 0x01010101u) << 32;
+		// 2. EV4: the (15,10) blocks, as in long_payloads -- and which block is the first that does not decode
+		uint32_t first_fail = nblocks;
+		if (__ballot(is4)) {
+			area[DHL_STG + 2 * gbase + sub] = w0;
+			area[DHL_STG + 2 * gbase + G + sub] = w1;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t b0 = 0; ; b0 += G) {
+				const uint32_t b = b0 + sub;
+				const bool on = is4 && b < nblocks;
+				if (!__ballot(on))
+					break;
+				bool bad = false;
+				if (on) {
+					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
+					const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
+					uint32_t data = blk & 0x3ffu;
+					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
+					const int fix = g_lds.fix23[diff & 31u];
+					bad = fix == -2;
+					if (fix >= 0)
+						data ^= 1u << fix;
+					const uint32_t bit = 10u * b, d = 2u * DHL_PB + 2u * gbase + (bit >> 5), s5 = bit & 31u;
+					__hip_atomic_fetch_or(area32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					if (s5 > 22)
+						__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+				const uint64_t gm = (__ballot(bad) >> gbase) & gmask;
+				if (gm && first_fail == nblocks)
+					first_fail = b0 + (uint32_t)__builtin_ctzll(gm);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (is4)
+				word = area[DHL_PB + lane];
+			area[DHL_PB + lane] = 0;
+		}
+		if (r + 1 < rounds)
+			request(r + 1, nw0, nw1);
+		// 3. unwhitened, cut at the bits the decoder may look at
+		const uint32_t T = nbits >> 6;
+		const bool active = has && 64u * sub < nbits;
+		uint64_t out = 0;
+		if (active) {
+			uint32_t idx = p_widx + wh_lane;
+			idx = idx >= 127u ? idx - 127u : idx;
+			out = word ^ (p_wht ? wh_bits(idx, 64) : 0ULL);
+			if (sub == T)
+				out &= (1ULL << (nbits & 63u)) - 1;
+		}
+		// 4. the register in front of this lane's word
+		uint32_t reg;
+		{
+			const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
+			const uint32_t reg0 = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+			const uint32_t q = apply_columns(rinv, reg0);
+			uint32_t x = q, t;                                      // inclusive XOR prefix over the lanes of the group
+			t = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x111, 0xf, 0xf, true); x ^= sub >= 1 ? t : 0u;      // row_shr:1
+			t = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x112, 0xf, 0xf, true); x ^= sub >= 2 ? t : 0u;
+			t = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x114, 0xf, 0xf, true); x ^= sub >= 4 ? t : 0u;
+			if (logg > 3) {
+				t = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x118, 0xf, 0xf, true); x ^= sub >= 8 ? t : 0u;
+			}
+			if (logg > 4) {                                         // the second sixteen of a group of 32: + the first sixteen's total
+				t = (uint32_t)__shfl((int)x, (int)(gbase + 15));
+				x ^= sub >= 16 ? t : 0u;
+			}
+			reg = apply_columns(rfwd, x ^ q);
+		}
+		// 5. byte by byte; which byte counts may end the payload: EV4 2 .. 5 (blocks that decoded - 1) / 4 (byte L - 1 is looked
+		// at by the loop's step b when 8 L <= 10 b), EV5 3 .. bytes - 1
+		const uint32_t ok_blocks = first_fail < nblocks ? first_fail : nblocks;
+		const uint32_t hi = is4 ? (ok_blocks ? 5u * (ok_blocks - 1u) / 4u : 0u) : (nbits >> 3) - 1u, lo = is4 ? 2u : 3u;
+		uint32_t zero = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			uint32_t byte = (uint32_t)(out >> (8 * i)) & 0xffu;
+			if (i == 1 && sub == 0)
+				byte ^= crc_seed(p_uap) >> 8;                       // (the seed sits on bits 8 .. 15 of the first word)
+			reg = crc_byte(reg, byte);
+			const uint32_t L = 8u * sub + (uint32_t)i + 1u;
+			if (reg == 0 && L >= lo && L <= hi)
+				zero |= 1u << i;
+		}
+		const uint64_t hm = (__ballot(has && zero != 0) >> gbase) & gmask;
+		const uint32_t hl = hm ? (uint32_t)__builtin_ctzll(hm) : 0u;
+		const uint32_t hz = (uint32_t)__shfl((int)zero, (int)(gbase + hl));
+		const uint32_t L_hit = hm ? 8u * hl + (uint32_t)__builtin_ctz(hz | 0x100u) + 1u : 0u;
+		// 6. length, verdict, and the bits the decoder wrote before it stopped
+		if (has) {
+			uint32_t plen, wbits;
+			int rv;
+			if (is4) {
+				if (L_hit) {
+					rv = 10; plen = L_hit; wbits = 10u * ((8u * L_hit + 9u) / 10u + 1u);
+				} else {
+					plen = hi + 1u; wbits = 10u * ok_blocks;
+					rv = ok_blocks == 98u ? 2 : first_fail < nblocks && first_fail < 3u ? 0 : 1;    // all 98 | stopped by an undecodable block in the first 45 symbols | later, or by the capture's end
+				}
+			} else {
+				const uint32_t bytes = nbits >> 3;
+				if (L_hit) {
+					rv = 10; plen = L_hit; wbits = 8u * (L_hit + 1u);
+				} else {
+					plen = bytes; wbits = nbits; rv = bytes == 182u ? 2 : 1;
+				}
+			}
+			const uint32_t wT = wbits >> 6, wrem = wbits & 63u;
+			if (64u * sub < wbits) {
+				uint64_t v = out;
+				if (sub == wT) {                                        // (a partial last word keeps what the record held behind it)
+					const uint64_t wm = (1ULL << wrem) - 1;
+					v = (out & wm) | (outs[p_pkt].payload[sub] & ~wm);
+				}
+				outs[p_pkt].payload[sub] = v;
+			}
+			if (sub == 0) {
+				outs[p_pkt].payload_length = (int32_t)plen;
+				outs[p_pkt].payload_rv = rv;
+			}
+		}
+	}
+}
+
 // The deferred payloads of one wave of decode_hits_kernel: dmask = which of its 64 list slots `slots` are filled
-// (defer_payload).  Lanes per packet = one per payload word of the wave's longest payload (the sort of decode_hits_kernel
-// keeps like with like).  `outs` = the records of that workgroup; all 64 lanes.
+// (defer_payload).  DH / DM entries to the front of the LDS list, EV4 / EV5 behind them; lanes per packet = one per
+// payload word of the longest payload of either kind (the sort of decode_hits_kernel keeps like with like).  `outs` = the
+// records of that workgroup; all 64 lanes.
 __device__ __forceinline__ void long_wave(dhl_u64_t *area, const uint4 *slots, uint64_t dmask, btbbx_pkt_out *outs, uint32_t lane)
 {
 	const bool mine = (dmask >> lane) & 1;
-	uint32_t own_words = 0;
+	uint4 e = make_uint4(0, 0, 0, 0);
+	if (mine)
+		e = slots[lane];
+	const bool ev = mine && (e.w & 3u) >= DHL_EV4;
+	const uint64_t ev_mask = __ballot(ev), dh_mask = dmask & ~ev_mask;
+	const uint32_t n_dh = (uint32_t)__popcll(dh_mask), n_ev = (uint32_t)__popcll(ev_mask);
+	const uint32_t own_words = mine ? (((e.z >> 20) & 0xfffu) + 63u) >> 6 : 0u;
 	if (mine) {
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
-		const uint4 e = slots[lane];
+		const uint64_t among = ev ? ev_mask : dh_mask;
+		const uint32_t rank = (ev ? n_dh : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(among >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)among, 0u));
 		area[DHL_LIST + 2 * rank] = (uint64_t)e.x | (uint64_t)e.y << 32;
 		area[DHL_LIST + 2 * rank + 1] = (uint64_t)e.z | (uint64_t)e.w << 32;
-		own_words = (((e.z >> 20) & 0xfffu) + 63u) >> 6;
 	}
-	const uint32_t logg = __ballot(own_words > 32) ? 6u : __ballot(own_words > 16) ? 5u : __ballot(own_words > 8) ? 4u : 3u;
-	long_payloads(area, (uint32_t)__popcll(dmask), logg, outs, lane);
+	if (n_dh) {
+		const uint32_t w = ev ? 0u : own_words;
+		const uint32_t logg = __ballot(w > 32) ? 6u : __ballot(w > 16) ? 5u : __ballot(w > 8) ? 4u : 3u;
+		long_payloads(area, n_dh, logg, outs, lane);
+	}
+	if (n_ev) {
+		const uint32_t w = ev ? own_words : 0u;
+		const uint32_t logg = __ballot(w > 16) ? 5u : __ballot(w > 8) ? 4u : 3u;
+		ev_payloads(area, n_dh, n_ev, logg, outs, lane);
+	}
 }
 
 // -DDH_LONG_FUSED=0: the long payloads in a kernel of their own.  One workgroup per workgroup of decode_hits_kernel, wave w

@@ -192,7 +192,8 @@ LONG_MAXBODY = {synth.TYPE_DM3: 121, synth.TYPE_DH3: 183, synth.TYPE_DM5: 224, s
                 synth.TYPE_DM1: 17, synth.TYPE_DH1: 27, synth.TYPE_EV4: 120, synth.TYPE_EV5: 180}
 
 
-def _long_capture(rng, n_packets, n_streams, n_words, others=(synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_FHS, synth.TYPE_EV4, synth.TYPE_EV5)):
+def _long_capture(rng, n_packets, n_streams, n_words, others=(synth.TYPE_DM1, synth.TYPE_DH1, synth.TYPE_FHS, synth.TYPE_EV4, synth.TYPE_EV5),
+                  longs=None):
     """Streams of noise with mostly multi-slot DM / DH packets in them: full-length bodies, bodies around the 256-bit
     boundary where the wave phase of decode_hits_kernel takes over, every payload_length mod 8, symbol errors in the
     payload (FEC 2/3 blocks that fail), captures cut short; -> (symbols, rows of (stream, offset, meta))."""
@@ -201,7 +202,7 @@ def _long_capture(rng, n_packets, n_streams, n_words, others=(synth.TYPE_DM1, sy
     pos = [64 + int(rng.integers(0, 64)) for _ in range(n_streams)]
     for i in range(n_packets):
         st = i % n_streams
-        t = LONG_TYPES[(i // n_streams) % 4] if i % 5 else others[(i // 5) % len(others)]
+        t = (longs or LONG_TYPES)[(i // n_streams) % 4] if i % 5 else others[(i // 5) % len(others)]
         mb = LONG_MAXBODY.get(t, 0)
         k = i % 7
         if k == 0:
@@ -292,6 +293,119 @@ def test_long_payloads_leave_through_the_wave_phase():
         assert seen.get((t, 10), 0) >= 15, (t, seen)
     assert sum(v for (t, r), v in seen.items() if t in (synth.TYPE_DM3, synth.TYPE_DM5) and r == 0) >= 10, seen
     assert sum(v for (t, r), v in seen.items() if t in LONG_TYPES and r == 2) >= 10, seen
+
+
+def test_ev4_ev5_payloads_leave_through_the_wave_phase():
+    """EV4 / EV5 payloads in HBM are decoded by lane groups too (ev_payloads in packet.hip: the byte count whose CRC register
+    is zero comes from a prefix over the lanes, not from a walk): byte-identical to cutting the packets out and decoding
+    them lane by lane, and equal to the oracle -- every body length, symbol errors (EV4: blocks that do not decode, in the
+    first 45 symbols and behind them), wrong clocks, captures cut short by max_length and by the next packet, records that
+    hold random bytes on entry, and DM / DH packets in the same waves."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(1213)
+    n_streams, n_words = 6, 4096
+    sym, rows = _long_capture(rng, 2400, n_streams, n_words, others=(synth.TYPE_DM3, synth.TYPE_DH5, synth.TYPE_DH1, synth.TYPE_DM1),
+                              longs=(synth.TYPE_EV4, synth.TYPE_EV5, synth.TYPE_EV5, synth.TYPE_EV4))
+    assert len(rows) > 1400
+    # errors in the first three blocks of some EV4 packets (the reference answers 0 there, 1 behind them)
+    for j, (st, off, meta) in enumerate(rows):
+        if meta["type"] == synth.TYPE_EV4 and j % 9 == 0:
+            sym[st, off + 122 + int(rng.integers(0, 45))] ^= 1
+            sym[st, off + 122 + int(rng.integers(0, 45))] ^= 1
+    hits = np.zeros(len(rows), bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(len(rows), bt.PKTIN_DTYPE)
+    clk = np.array([r[2]["clk6"] for r in rows], dtype=np.uint32)
+    clk[::13] ^= 9
+    pin["clkn"] = clk | (rng.integers(0, 1 << 20, len(rows)).astype(np.uint32) << 6)
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    pin["flags"][::29] &= ~np.uint32(1)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    dirty = np.frombuffer(rng.integers(0, 256, len(rows) * bt.PKTOUT_DTYPE.itemsize, dtype=np.uint8).tobytes(),
+                          dtype=bt.PKTOUT_DTYPE).copy()
+    dirty["payload_length"] &= 0x1ff
+    dirty["payload_header_length"] &= 3
+    for max_length in (bt.MAX_SYMBOLS, 900, 400, 140):
+        direct, len_d = bt.run_decode_hits(words, hits, pin, init_out=dirty, max_length=max_length)
+        two_step, len_g = bt.run_decode_hits(words, hits, pin, via_gather=True, init_out=dirty, max_length=max_length)
+        assert np.array_equal(len_d, len_g)
+        bad = [i for i in range(len(rows)) if direct[i].tobytes() != two_step[i].tobytes()]
+        assert not bad, (max_length, len(bad), [(i, rows[i][2]["type"], rows[i][2]["nbody"], int(direct[i]["payload_rv"]),
+                                                 int(two_step[i]["payload_rv"]), int(direct[i]["payload_length"]),
+                                                 int(two_step[i]["payload_length"])) for i in bad[:8]])
+    direct, len_d = bt.run_decode_hits(words, hits, pin)
+    seen = {}
+    for i in range(0, len(rows), 2):
+        st, off, meta = rows[i]
+        if not int(pin["flags"][i]) & 1:
+            continue
+        s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
+        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        o = direct[i]
+        assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, off, meta)
+        if h:
+            assert int(o["payload_length"]) == stt["payload_length"], (i, meta)
+            bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+            assert (bits == stt["payload"]).all(), (i, meta, np.nonzero(bits != stt["payload"])[0][:8])
+            seen[(int(o["type"]), r)] = seen.get((int(o["type"]), r), 0) + 1
+    assert seen.get((synth.TYPE_EV4, 10), 0) >= 40, sorted(seen.items())
+    assert seen.get((synth.TYPE_EV4, 0), 0) >= 5 and seen.get((synth.TYPE_EV4, 1), 0) >= 5, sorted(seen.items())
+    # (EV5: the reference's loop repeats the first payload byte -- SURVEY Q7 --, its CRC matches by chance only)
+    assert seen.get((synth.TYPE_EV5, 1), 0) + seen.get((synth.TYPE_EV5, 2), 0) >= 40, sorted(seen.items())
+
+
+def test_ev5_lengths_found_by_the_prefix_over_the_lanes():
+    """The reference's EV5 loop repeats the first payload byte under the whitening of each place, so where its
+    CRC register reaches zero -- payload_length, verdict 10, the bytes written -- is decided by (first byte, CLK1-6, UAP)
+    alone, once in ~370 packets.  Thousands of EV5 headers in front of noise: every record equal to the lane-by-lane decode of
+    the cut-out packet, and the ones that end early equal to the oracle."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(77)
+    n_streams, per_stream, gap = 8, 768, 1700
+    n_words = (per_stream * gap + 4096) // 64
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    rows = []
+    for st in range(n_streams):
+        for k in range(per_stream):
+            lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+            p = synth.build_packet(lap, uap, clk6, synth.TYPE_EV5, lt_addr=1 + k % 7, body=b"")[:122]
+            off = 64 + k * gap + int(rng.integers(0, 64))
+            sym[st, off:off + len(p)] = p
+            rows.append((st, off, uap, clk6))
+    n = len(rows)
+    hits = np.zeros(n, bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(n, bt.PKTIN_DTYPE)
+    pin["clkn"] = [r[3] for r in rows]
+    pin["uap"] = [r[2] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    dirty = np.frombuffer(rng.integers(0, 256, n * bt.PKTOUT_DTYPE.itemsize, dtype=np.uint8).tobytes(), dtype=bt.PKTOUT_DTYPE).copy()
+    dirty["payload_length"] &= 0x1ff
+    dirty["payload_header_length"] &= 3
+    for max_length in (bt.MAX_SYMBOLS, 122 + 8 * 90):
+        direct, len_d = bt.run_decode_hits(words, hits, pin, init_out=dirty, max_length=max_length)
+        two_step, len_g = bt.run_decode_hits(words, hits, pin, via_gather=True, init_out=dirty, max_length=max_length)
+        assert np.array_equal(len_d, len_g)
+        bad = [i for i in range(n) if direct[i].tobytes() != two_step[i].tobytes()]
+        assert not bad, (max_length, len(bad), [(i, int(direct[i]["payload_rv"]), int(two_step[i]["payload_rv"]),
+                                                 int(direct[i]["payload_length"]), int(two_step[i]["payload_length"])) for i in bad[:8]])
+    direct, len_d = bt.run_decode_hits(words, hits, pin)
+    assert (direct["type"] == synth.TYPE_EV5).sum() > n - 10
+    early = np.nonzero((direct["payload_rv"] == 10) & (direct["type"] == synth.TYPE_EV5))[0]
+    assert len(early) >= 6, len(early)
+    for i in list(early) + list(range(0, n, 97)):
+        st, off, uap, clk6 = rows[i]
+        s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
+        present, h, r, stt = _oracle_decode(orc, s, clk6, uap)
+        o = direct[i]
+        assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, rows[i])
+        assert int(o["payload_length"]) == stt["payload_length"], (i, rows[i])
+        bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+        assert (bits == stt["payload"]).all(), (i, rows[i])
 
 
 def test_decode_with_the_count_in_hbm():
