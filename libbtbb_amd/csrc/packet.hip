@@ -1935,13 +1935,12 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 //      another lane's word, whatever the payload length;
 //   5. stores its word (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
 // tests/_wave_model.py is the numpy model of these steps (pinned against the oracle on the CPU).
-#ifndef DHL_UNIFORM
-#define DHL_UNIFORM 1                        // a second copy of the round loop for one packet per round, its facts in scalar registers
-#endif
-#define DHL_LIST   0u                        // 64 x 2 words: what the owner lanes know about their deferred packets
-#define DHL_STG    128u                      // 130 words: the round's DM packets as they lie in the stream, 2 G words per group
-#define DHL_PB     258u                      // 64 words: decoded FEC 2/3 bits, packed, G words per group
-#define DHL_WORDS  322u
+// two LDS areas per wave (in decode_hits_kernel: its input stage and its result stage, both free by then):
+#define DHL_STG_WORDS 288u                   // `stg`: the round's DM packets as they lie in the stream: 4 G (+ G / 4 + 1: LDS banks) words per group
+#define DHL_LIST   0u                        // `lst`: 64 x 2 words: what the owner lanes know about their deferred packets
+#define DHL_PB     128u                      //        128 words: decoded FEC 2/3 bits, packed, 2 G words per group
+#define DHL_LST_WORDS 256u
+struct __attribute__((packed, aligned(8))) dhl_pair_t { uint64_t a, b; };    // two payload words of a record: one 16-byte store
 typedef __attribute__((address_space(3))) uint64_t dhl_u64_t;
 typedef __attribute__((address_space(3))) uint32_t dhl_u32_t;
 typedef const __attribute__((address_space(1))) uint64_t dhl_g64_t;
@@ -1974,178 +1973,203 @@ __device__ __forceinline__ uint32_t apply_columns(const uint32_t (&c)[8], uint32
 	return (x ^ (x >> 16)) & 0xffffu;
 }
 
-// All 64 lanes of a wave of decode_long_kernel; the wave's n_def list entries (DHL_LIST) are in LDS.  `area` = DHL_WORDS
-// words of LDS of this wave, `outs` = the records of the workgroup of decode_hits_kernel that deferred the packets.
-__device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
+// All 64 lanes of a wave; the wave's n_def DH / DM list entries are in LDS (lst[DHL_LIST ..]).  `stg` = DHL_STG_WORDS words
+// of LDS of this wave, `lst` = DHL_LST_WORDS more; `outs` = the records of the workgroup of decode_hits_kernel that
+// deferred the packets.
+__device__ __forceinline__ void long_payloads(dhl_u64_t *stg, dhl_u64_t *lst, uint32_t n_def, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
 {
-	dhl_u32_t *const area32 = (dhl_u32_t *)area;
+	dhl_u32_t *const stg32 = (dhl_u32_t *)stg, *const lst32 = (dhl_u32_t *)lst;
 	const uint32_t G = 1u << logg, R = 64u >> logg;
 	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
-	const uint64_t gmask = G == 64 ? ~0ULL : (1ULL << G) - 1;
-	area[DHL_PB + lane] = 0;
-	if (lane < 2)
-		area[DHL_STG + 128 + lane] = 0;
-	// this lane's matrix: sixteen columns of A^(-64 sub)
+	const uint64_t gmask = (1ULL << G) - 1;                     // (G <= 32: 43 words at two per lane)
+	lst[DHL_PB + 2 * lane] = 0;
+	lst[DHL_PB + 2 * lane + 1] = 0;
+	// this lane's matrix: sixteen columns of A^(-128 sub)
 	uint32_t col[8];
 	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64inv) + 2 * sub;
+		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64inv) + 4 * sub;
 		const uint4 a = src[0], b = src[1];
 		col[0] = a.x; col[1] = a.y; col[2] = a.z; col[3] = a.w; col[4] = b.x; col[5] = b.y; col[6] = b.z; col[7] = b.w;
 	}
-	const uint32_t wh_lane = (64u * sub) % 127u;               // whitening phase of word `sub` relative to the payload's first bit
+	// a group's staged words: 4 G + G / 4 + 1 words apart, so that the groups' 15-bit reads fall into different LDS banks
+	// (4 G words = a multiple of 256 bytes: every group on the same banks)
+	const uint32_t stg_base = grp * (4u * G + (G >> 2) + 1u);
+	for (uint32_t i = lane; i < DHL_STG_WORDS; i += 64)
+		stg[i] = 0;
+	const uint32_t wh_lane = (128u * sub) % 127u;              // whitening phase of word 2 sub relative to the payload's first bit
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t rounds = (n_def + R - 1) >> (6 - logg);
-	// One packet per round (G = 64: DH5, the longest DH3): everything the round knows about its packet is the same in all
-	// lanes -- read once, kept in scalar registers, unpacked by the scalar unit (`uni`); the loop exists twice for that.
-	auto run = [&](auto uniform_t) {
-		constexpr bool UNI = decltype(uniform_t)::value;
-		auto uni = [&](uint64_t v) -> uint64_t {
-			if (!UNI)
-				return v;
-			return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v)
-				| (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
-		};
-		// the words of round r on their way: two stream words of the group's packet -- DH: the two that hold payload word
-		// `sub`; DM: words sub and sub + G of the packet
-		auto request = [&](uint32_t r, uint64_t &w0, uint64_t &w1) {
-			const uint32_t e = r * R + grp;
-			w0 = 0;
-			w1 = 0;
-			if (e < n_def) {
-				const uint64_t a = uni(area[DHL_LIST + 2 * e]), b = uni(area[DHL_LIST + 2 * e + 1]);
-				dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
-				const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u, kind = (uint32_t)(b >> 32) & 3u;
-				const bool p_fec = kind == DHL_DM;
-				const uint32_t i0 = p_fec ? sub : sub + ((p_sh + 122u) >> 6), i1 = p_fec ? sub + G : i0 + 1u;
-				if (i0 < p_nw)
-					w0 = src[i0];
-				if (i1 < p_nw)
-					w1 = src[i1];
+	// the words of round r on their way: four stream words of the group's packet -- DH: the three that hold payload words
+	// 2 sub and 2 sub + 1; DM: words sub, sub + G, sub + 2 G, sub + 3 G of the packet
+	auto request = [&](uint32_t r, uint64_t (&w)[4]) {
+		const uint32_t e = r * R + grp;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			w[k] = 0;
+		if (e < n_def) {
+			const uint64_t a = lst[DHL_LIST + 2 * e], b = lst[DHL_LIST + 2 * e + 1];
+			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
+			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u, kind = (uint32_t)(b >> 32) & 3u;
+			const bool p_fec = kind == DHL_DM;
+			const uint32_t i0 = p_fec ? sub : 2u * sub + ((p_sh + 122u) >> 6), step = p_fec ? G : 1u;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t i = i0 + (uint32_t)k * step;
+				if (i < p_nw && (p_fec || k < 3))
+					w[k] = src[i];
 			}
-		};
-		uint64_t nw0, nw1;
-		request(0, nw0, nw1);
-		// a round's word is stored at the start of the next round
-		uint64_t st_val = 0;
-		uint32_t st_pkt = 0;
-		bool st_do = false;
-		for (uint32_t r = 0; r < rounds; r++) {
-			const uint32_t e = r * R + grp;
-			const bool has = e < n_def;
-			uint64_t pa = 0, pb = 0;
-			if (has) {
-				pa = uni(area[DHL_LIST + 2 * e]);
-				pb = uni(area[DHL_LIST + 2 * e + 1]);
-			}
-			const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
-			const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
-			const uint32_t kind = (uint32_t)(pb >> 32) & 3u, p_widx = (uint32_t)(pb >> 35) & 127u, p_uap = (uint32_t)(pb >> 42) & 0xffu;
-			const bool p_fec = has && kind == DHL_DM, p_wht = (pb >> 34) & 1u;
-			const uint32_t nblocks = (nbits + 9u) / 10u;
-			const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
-			const bool active = has && sub < nwp;
-			// 2a. DH: payload word `sub` is a funnel shift of the lane's two stream words
-			// (computed by every lane, wanted or not: the one wait for the words asked for a round ago then sits here, on every
-			// path, and the compiler needs no second one in front of the next request)
-			const uint32_t sft = (p_sh + 122u) & 63u;
-			const uint64_t funnel = sft ? (nw0 >> sft) | (nw1 << (64u - sft)) : nw0;
-			uint64_t word = has && kind == DHL_DH ? funnel : 0ULL;
-			const uint64_t any_fec = __ballot(p_fec);
-			if (any_fec) {
-				// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
-				uint64_t v0 = nw0, v1 = nw1;
-				if (__ballot(p_fec && 122u + 15u * nblocks > p_len)) {
-					const uint32_t valid = p_sh + p_len;                        // stream bits of the packet's words that are symbols of the capture
-					const uint32_t h0 = valid > 64u * sub ? valid - 64u * sub : 0u, h1 = valid > 64u * (sub + G) ? valid - 64u * (sub + G) : 0u;
-					if (h0 < 64)
-						v0 &= (1ULL << h0) - 1;
-					if (h1 < 64)
-						v1 &= (1ULL << h1) - 1;
+		}
+	};
+	uint64_t nw[4];
+	request(0, nw);
+	// a round's words are stored at the start of the next round
+	uint64_t st_val0 = 0, st_val1 = 0;
+	uint32_t st_pkt = 0, st_n = 0;
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t e = r * R + grp;
+		const bool has = e < n_def;
+		uint64_t pa = 0, pb = 0;
+		if (has) {
+			pa = lst[DHL_LIST + 2 * e];
+			pb = lst[DHL_LIST + 2 * e + 1];
+		}
+		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
+		const uint32_t p_pkt = (uint32_t)pb & 0xffu, p_len = (uint32_t)(pb >> 8) & 0xfffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
+		const uint32_t kind = (uint32_t)(pb >> 32) & 3u, p_widx = (uint32_t)(pb >> 35) & 127u, p_uap = (uint32_t)(pb >> 42) & 0xffu;
+		const bool p_fec = has && kind == DHL_DM, p_wht = (pb >> 34) & 1u;
+		const uint32_t nblocks = (nbits + 9u) / 10u;
+		const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
+		// 2a. DH: payload words 2 sub, 2 sub + 1 are funnel shifts of the lane's three stream words
+		// (computed by every lane, wanted or not: the one wait for the words asked for a round ago then sits here, on every
+		// path, and the compiler needs no second one in front of the next request)
+		const uint32_t sft = (p_sh + 122u) & 63u;
+		uint64_t word0 = sft ? (nw[0] >> sft) | (nw[1] << (64u - sft)) : nw[0];
+		uint64_t word1 = sft ? (nw[1] >> sft) | (nw[2] << (64u - sft)) : nw[1];
+		if (!(has && kind == DHL_DH)) {
+			word0 = 0;
+			word1 = 0;
+		}
+		const uint64_t any_fec = __ballot(p_fec);
+		bool fail = false;
+		if (any_fec) {
+			// the DM packets of the round into LDS, cut at the captured length when a block reaches behind it
+			if (__ballot(p_fec && 122u + 15u * nblocks > p_len)) {
+				const uint32_t valid = p_sh + p_len;                        // stream bits of the packet's words that are symbols of the capture
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t first = 64u * (sub + (uint32_t)k * G), h = valid > first ? valid - first : 0u;
+					if (h < 64)
+						nw[k] &= (1ULL << h) - 1;
 				}
-				area[DHL_STG + 2 * gbase + sub] = v0;
-				area[DHL_STG + 2 * gbase + G + sub] = v1;
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				__builtin_amdgcn_wave_barrier();
 			}
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				stg[stg_base + (uint32_t)k * G + sub] = nw[k];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 			// 2b. DM: the (15,10) blocks of the packet
-			bool fail = false;
-			if (any_fec) {
-				for (uint32_t b0 = 0; ; b0 += G) {
-					const uint32_t b = b0 + sub;
-					const bool on = p_fec && b < nblocks;
-					if (!__ballot(on))
-						break;
+			// (two blocks per lane and step: their LDS round trips -- words, parity table, correction table, ds_or -- overlap)
+			for (uint32_t b0 = 0; ; b0 += 2u * G) {
+				const uint32_t bA = b0 + sub, bB = bA + G;
+				const bool onA = p_fec && bA < nblocks, onB = p_fec && bB < nblocks;
+				if (!__ballot(onA))
+					break;
+				const uint32_t qA = p_sh + 122u + 15u * bA, qB = qA + 15u * G, iA = 2u * stg_base + (qA >> 5), iB = 2u * stg_base + (qB >> 5);
+				uint32_t blkA = 0, blkB = 0;
+				if (onA)
+					blkA = __builtin_amdgcn_alignbit(stg32[iA + 1], stg32[iA], qA & 31u) & 0x7fffu;
+				if (onB)
+					blkB = __builtin_amdgcn_alignbit(stg32[iB + 1], stg32[iB], qB & 31u) & 0x7fffu;
+				uint32_t dataA = blkA & 0x3ffu, dataB = blkB & 0x3ffu;
+				const uint32_t diffA = (blkA >> 10) ^ g_lds.par23[dataA], diffB = (blkB >> 10) ^ g_lds.par23[dataB];
+				const int fixA = g_lds.fix23[diffA & 31u], fixB = g_lds.fix23[diffB & 31u];
+				if ((onA && fixA == -2) || (onB && fixB == -2))
+					fail = true;
+				if (fixA >= 0)
+					dataA ^= 1u << fixA;
+				if (fixB >= 0)
+					dataB ^= 1u << fixB;
+				auto put = [&](bool on, uint32_t b, uint32_t data) {
 					if (on) {
-						const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
-						const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
-						uint32_t data = blk & 0x3ffu;
-						const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
-						const int fix = g_lds.fix23[diff & 31u];
-						if (fix == -2)
-							fail = true;
-						if (fix >= 0)
-							data ^= 1u << fix;
 						const uint32_t bit = 10u * b, left = nbits - bit;
 						if (left < 10)
-							data &= (1u << left) - 1;                               // (nothing behind payload_length reaches the packed words)
-						const uint32_t d = 2u * DHL_PB + 2u * gbase + (bit >> 5), sft = bit & 31u;
-						__hip_atomic_fetch_or(area32 + d, data << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-						if (sft > 22)
-							__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+							data &= (1u << left) - 1;                           // (nothing behind payload_length reaches the packed words)
+						const uint32_t d = 2u * DHL_PB + 4u * gbase + (bit >> 5), s5 = bit & 31u;
+						__hip_atomic_fetch_or(lst32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+						if (s5 > 22)
+							__hip_atomic_fetch_or(lst32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				if (p_fec)
-					word = area[DHL_PB + lane];
-				area[DHL_PB + lane] = 0;                                // the packed bits are consumed: ready for the next round
+				};
+				put(onA, bA, dataA);
+				put(onB, bB, dataB);
 			}
-			// the stream words are used up: the previous round's word goes out, the next round's words are asked for, and the
-			// lane that writes a partial last word asks for what the record holds there (used at the end of the round) --
-			// all of it behind the last wait of this round for memory, in front of ~150 instructions that need none
-			if (st_do)
-				outs[st_pkt].payload[sub] = st_val;
-			if (r + 1 < rounds)
-				request(r + 1, nw0, nw1);
-			uint64_t oldw = 0;
-			if (active && sub == T)
-				oldw = outs[p_pkt].payload[sub];
-			const uint64_t fail_mask = __ballot(fail);
-			const bool group_fail = ((fail_mask >> gbase) & gmask) != 0;
-			// 3. unwhitened, cut at the payload length
-			uint64_t out = 0, keep_mask = ~0ULL;
-			if (active) {
-				uint32_t idx = p_widx + wh_lane;
-				idx = idx >= 127u ? idx - 127u : idx;
-				const uint64_t wbits = p_wht ? wh_bits(idx, 64) : 0ULL;
-				if (sub == T)                                             // (a partial last word: nbits & 63 != 0)
-					keep_mask = (1ULL << (nbits & 63u)) - 1;
-				out = (word ^ wbits) & keep_mask;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (p_fec) {
+				word0 = lst[DHL_PB + 2 * lane];
+				word1 = lst[DHL_PB + 2 * lane + 1];
 			}
-			// 4. CRC: the word alone (the seed's bits on the first sixteen of the payload), carried back over the words in front of it
-			const uint64_t cw = out ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
-			const uint32_t reg0 = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
-			const uint32_t total = group_xor(apply_columns(col, reg0), logg);
-			int rv = total == 0 ? 10 : 2;
-			if (p_fec && group_fail)
-				rv = 0;
-			// 5. out (DM: nothing when a block failed)
-			st_do = active && rv != 0;
-			st_val = sub == T ? out | (oldw & ~keep_mask) : out;
-			st_pkt = p_pkt;
-			if (has && sub == 0)
-				outs[p_pkt].payload_rv = rv;                            // (decode_hits_kernel left a placeholder)
+			lst[DHL_PB + 2 * lane] = 0;                                 // the packed bits are consumed: ready for the next round
+			lst[DHL_PB + 2 * lane + 1] = 0;
 		}
-		if (st_do)
-			outs[st_pkt].payload[sub] = st_val;
-	};
-#if DHL_UNIFORM
-	if (logg == 6)
-		run(std::true_type{});
-	else
-#endif
-		run(std::false_type{});
+		// the stream words are used up: the previous round's words go out, the next round's words are asked for, and the
+		// lane that writes a partial last word asks for what the record holds there (used at the end of the round) --
+		// all of it behind the last wait of this round for memory, in front of ~200 instructions that need none
+		if (st_n == 2) {
+			*reinterpret_cast<dhl_pair_t *>(outs[st_pkt].payload + 2 * sub) = dhl_pair_t{st_val0, st_val1};
+		} else if (st_n == 1) {
+			outs[st_pkt].payload[2 * sub] = st_val0;
+		}
+		if (r + 1 < rounds)
+			request(r + 1, nw);
+		const uint32_t j0 = 2u * sub;
+		const bool act0 = has && j0 < nwp, act1 = has && j0 + 1u < nwp;
+		const bool part = has && (T >> 1) == sub && (nbits & 63u);  // this lane holds the partial last word
+		uint64_t oldw = 0;
+		if (part)
+			oldw = outs[p_pkt].payload[T];
+		const uint64_t fail_mask = __ballot(fail);
+		const bool group_fail = ((fail_mask >> gbase) & gmask) != 0;
+		// 3. unwhitened, cut at the payload length
+		uint64_t out0 = 0, out1 = 0;
+		const uint64_t keep = (1ULL << (nbits & 63u)) - 1;          // (of the partial last word)
+		if (act0) {
+			uint32_t idx = p_widx + wh_lane;
+			idx = idx >= 127u ? idx - 127u : idx;
+			out0 = word0 ^ (p_wht ? wh_bits(idx, 64) : 0ULL);
+			if (part && !(T & 1u))
+				out0 &= keep;
+			if (act1) {
+				idx += 64u;
+				idx = idx >= 127u ? idx - 127u : idx;
+				out1 = word1 ^ (p_wht ? wh_bits(idx, 64) : 0ULL);
+				if (part && (T & 1u))
+					out1 &= keep;
+			}
+		}
+		// 4. CRC: the lane's two words from a zero register (the seed's bits on the first sixteen of the payload), carried back
+		// over the words in front of them
+		const uint64_t cw = out0 ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
+		uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+		reg = crc_word(crc_word(reg, (uint32_t)out1), (uint32_t)(out1 >> 32));
+		const uint32_t total = group_xor(apply_columns(col, reg), logg);
+		int rv = total == 0 ? 10 : 2;
+		if (p_fec && group_fail)
+			rv = 0;
+		// 5. out (DM: nothing when a block failed)
+		st_n = rv == 0 ? 0u : act1 ? 2u : act0 ? 1u : 0u;
+		st_val0 = part && !(T & 1u) ? out0 | (oldw & ~keep) : out0;
+		st_val1 = part && (T & 1u) ? out1 | (oldw & ~keep) : out1;
+		st_pkt = p_pkt;
+		if (has && sub == 0)
+			outs[p_pkt].payload_rv = rv;                            // (decode_hits_kernel left a placeholder)
+	}
+	if (st_n == 2) {
+		*reinterpret_cast<dhl_pair_t *>(outs[st_pkt].payload + 2 * sub) = dhl_pair_t{st_val0, st_val1};
+	} else if (st_n == 1) {
+		outs[st_pkt].payload[2 * sub] = st_val0;
+	}
 }
 
 // EV4 (:1044-1097) and EV5 (:1099-1128) payloads of a wave, in a loop of their own (rare types; and what they keep in
@@ -2156,15 +2180,15 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *area, uint32_t n_def, u
 //   (register of word j alone)  -- a per-lane matrix, a plain XOR prefix over the lanes, a per-lane matrix --,
 // then the lane's eight bytes one by one, a zero register noted per byte; the lowest lane with a noted byte decides.
 // A round's stream words are asked for one round ahead; the record's old last word is read where the length is known.
-__device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uint32_t n_ev, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
+__device__ __forceinline__ void ev_payloads(dhl_u64_t *stg, dhl_u64_t *lst, uint32_t first, uint32_t n_ev, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
 {
-	dhl_u32_t *const area32 = (dhl_u32_t *)area;
+	dhl_u32_t *const stg32 = (dhl_u32_t *)stg, *const lst32 = (dhl_u32_t *)lst;
 	const uint32_t G = 1u << logg, R = 64u >> logg;
 	const uint32_t sub = lane & (G - 1), grp = lane >> logg, gbase = grp << logg;
 	const uint64_t gmask = (1ULL << G) - 1;                     // (G <= 32: an EV payload has at most 23 words)
-	area[DHL_PB + lane] = 0;
+	lst[DHL_PB + lane] = 0;
 	if (lane < 2)
-		area[DHL_STG + 128 + lane] = 0;
+		stg[128 + lane] = 0;
 	const uint32_t wh_lane = (64u * sub) % 127u;
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
@@ -2184,7 +2208,7 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 		w0 = 0;
 		w1 = 0;
 		if (e < n_ev) {
-			const uint64_t a = area[DHL_LIST + 2 * (first + e)], b = area[DHL_LIST + 2 * (first + e) + 1];
+			const uint64_t a = lst[DHL_LIST + 2 * (first + e)], b = lst[DHL_LIST + 2 * (first + e) + 1];
 			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
 			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
 			const bool is4 = ((uint32_t)(b >> 32) & 3u) == DHL_EV4;
@@ -2205,8 +2229,8 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 		const bool has = e < n_ev;
 		uint64_t pa = 0, pb = 0;
 		if (has) {
-			pa = area[DHL_LIST + 2 * (first + e)];
-			pb = area[DHL_LIST + 2 * (first + e) + 1];
+			pa = lst[DHL_LIST + 2 * (first + e)];
+			pb = lst[DHL_LIST + 2 * (first + e) + 1];
 		}
 		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
 		const uint32_t p_pkt = (uint32_t)pb & 0xffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
@@ -2222,8 +2246,8 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 		// 2. EV4: the (15,10) blocks, as in long_payloads -- and which block is the first that does not decode
 		uint32_t first_fail = nblocks;
 		if (__ballot(is4)) {
-			area[DHL_STG + 2 * gbase + sub] = w0;
-			area[DHL_STG + 2 * gbase + G + sub] = w1;
+			stg[2 * gbase + sub] = w0;
+			stg[2 * gbase + G + sub] = w1;
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			for (uint32_t b0 = 0; ; b0 += G) {
@@ -2233,8 +2257,8 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 					break;
 				bool bad = false;
 				if (on) {
-					const uint32_t q = p_sh + 122u + 15u * b, i = 2u * DHL_STG + 4u * gbase + (q >> 5);
-					const uint32_t blk = __builtin_amdgcn_alignbit(area32[i + 1], area32[i], q & 31u) & 0x7fffu;
+					const uint32_t q = p_sh + 122u + 15u * b, i = 4u * gbase + (q >> 5);
+					const uint32_t blk = __builtin_amdgcn_alignbit(stg32[i + 1], stg32[i], q & 31u) & 0x7fffu;
 					uint32_t data = blk & 0x3ffu;
 					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
 					const int fix = g_lds.fix23[diff & 31u];
@@ -2242,9 +2266,9 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 					if (fix >= 0)
 						data ^= 1u << fix;
 					const uint32_t bit = 10u * b, d = 2u * DHL_PB + 2u * gbase + (bit >> 5), s5 = bit & 31u;
-					__hip_atomic_fetch_or(area32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__hip_atomic_fetch_or(lst32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 					if (s5 > 22)
-						__hip_atomic_fetch_or(area32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+						__hip_atomic_fetch_or(lst32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
 				const uint64_t gm = (__ballot(bad) >> gbase) & gmask;
 				if (gm && first_fail == nblocks)
@@ -2253,8 +2277,8 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			if (is4)
-				word = area[DHL_PB + lane];
-			area[DHL_PB + lane] = 0;
+				word = lst[DHL_PB + lane];
+			lst[DHL_PB + lane] = 0;
 		}
 		if (r + 1 < rounds)
 			request(r + 1, nw0, nw1);
@@ -2347,7 +2371,7 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *area, uint32_t first, uin
 // (defer_payload).  DH / DM entries to the front of the LDS list, EV4 / EV5 behind them; lanes per packet = one per
 // payload word of the longest payload of either kind (the sort of decode_hits_kernel keeps like with like).  `outs` = the
 // records of that workgroup; all 64 lanes.
-__device__ __forceinline__ void long_wave(dhl_u64_t *area, const uint4 *slots, uint64_t dmask, btbbx_pkt_out *outs, uint32_t lane)
+__device__ __forceinline__ void long_wave(dhl_u64_t *stg, dhl_u64_t *lst, const uint4 *slots, uint64_t dmask, btbbx_pkt_out *outs, uint32_t lane)
 {
 	const bool mine = (dmask >> lane) & 1;
 	uint4 e = make_uint4(0, 0, 0, 0);
@@ -2360,18 +2384,18 @@ __device__ __forceinline__ void long_wave(dhl_u64_t *area, const uint4 *slots, u
 	if (mine) {
 		const uint64_t among = ev ? ev_mask : dh_mask;
 		const uint32_t rank = (ev ? n_dh : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(among >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)among, 0u));
-		area[DHL_LIST + 2 * rank] = (uint64_t)e.x | (uint64_t)e.y << 32;
-		area[DHL_LIST + 2 * rank + 1] = (uint64_t)e.z | (uint64_t)e.w << 32;
+		lst[DHL_LIST + 2 * rank] = (uint64_t)e.x | (uint64_t)e.y << 32;
+		lst[DHL_LIST + 2 * rank + 1] = (uint64_t)e.z | (uint64_t)e.w << 32;
 	}
 	if (n_dh) {
-		const uint32_t w = ev ? 0u : own_words;
-		const uint32_t logg = __ballot(w > 32) ? 6u : __ballot(w > 16) ? 5u : __ballot(w > 8) ? 4u : 3u;
-		long_payloads(area, n_dh, logg, outs, lane);
+		const uint32_t w = ev ? 0u : own_words;                 // (two payload words per lane)
+		const uint32_t logg = __ballot(w > 32) ? 5u : __ballot(w > 16) ? 4u : 3u;
+		long_payloads(stg, lst, n_dh, logg, outs, lane);
 	}
 	if (n_ev) {
 		const uint32_t w = ev ? own_words : 0u;
 		const uint32_t logg = __ballot(w > 16) ? 5u : __ballot(w > 8) ? 4u : 3u;
-		ev_payloads(area, n_dh, n_ev, logg, outs, lane);
+		ev_payloads(stg, lst, n_dh, n_ev, logg, outs, lane);
 	}
 }
 
@@ -2380,7 +2404,7 @@ __device__ __forceinline__ void long_wave(dhl_u64_t *area, const uint4 *slots, u
 // Workgroups with nothing to do leave after two scalar loads; the hardware's dispatcher balances the rest.
 __global__ __launch_bounds__(256) void decode_long_kernel(const uint4 *list, const uint64_t *hdr, btbbx_pkt_out *outs)
 {
-	__shared__ uint64_t larea[4][DHL_WORDS];
+	__shared__ uint64_t larea[4][DHL_STG_WORDS + DHL_LST_WORDS];
 	const uint64_t m0 = hdr[blockIdx.x * 4], m1 = hdr[blockIdx.x * 4 + 1], m2 = hdr[blockIdx.x * 4 + 2], m3 = hdr[blockIdx.x * 4 + 3];
 	if (!(m0 | m1 | m2 | m3))
 		return;
@@ -2389,7 +2413,7 @@ __global__ __launch_bounds__(256) void decode_long_kernel(const uint4 *list, con
 	const uint64_t dmask = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
 	if (!dmask)
 		return;
-	long_wave((dhl_u64_t *)&larea[wave][0], list + (size_t)(blockIdx.x * 4 + wave) * 64, dmask, outs + (size_t)blockIdx.x * 256, lane);
+	long_wave((dhl_u64_t *)&larea[wave][0], (dhl_u64_t *)&larea[wave][DHL_STG_WORDS], list + (size_t)(blockIdx.x * 4 + wave) * 64, dmask, outs + (size_t)blockIdx.x * 256, lane);
 }
 
 #ifndef DH_WAVES_PER_EU
@@ -2519,7 +2543,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			// are all but unused otherwise: class 0 has one length, HV packets that are not cut short another)
 			if (DH_LONG_PHASE && !small && want > 126 && (cls == 2 || cls == 3)) {
 				const uint32_t pbits = cls == 2 ? (want - 122) / 15 * 10 : want - 122, words = (pbits + 63) >> 6;   // (about: the grouping only)
-				key = (cls == 2 ? 32u : 1u) + (words > 32 ? 3u : words > 16 ? 2u : words > 8 ? 1u : 0u);
+				key = (cls == 2 ? 32u : 1u) + (words > 32 ? 2u : words > 16 ? 1u : 0u);      // (two words per lane: groups of 32 / 16 / 8)
 			}
 		}
 		const uint32_t r = atomicAdd(&sort_cnt[key], 1u);
@@ -2678,7 +2702,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 	}
 	DH_MARK(7);                                         // decoded, results stored
-	if (DH_LONG_FUSED && long_mask) {
+	if (DH_LONG_FUSED && __builtin_expect(long_mask != 0, 0)) {
 		// The payloads the lanes left alone, a group of lanes per packet (long_payloads), in the wave's input stage: behind
 		// the store phase, when nothing of the lanes' decoders is alive any more.  Fused into this kernel rather than run
 		// as decode_long_kernel behind it: the phase is bound by instruction issue, the lanes' phases by latency -- waves
@@ -2687,8 +2711,14 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the list entries are written
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		long_wave((dhl_u64_t *)(lds_u64_t *)(&stage[wave][0]), long_list + (size_t)(blockIdx.x * 4 + wave) * 64, long_mask,
-			  outs + (size_t)blockIdx.x * blockDim.x, lane);
+		// (nothing of the lanes' phase is handed over in vector registers: lane number and wave number are made afresh, so no
+		// value computed for the long phase is kept alive through the decoders)
+		uint32_t lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+		asm volatile("" : "+v"(lane2));
+		uint32_t wave2 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		asm volatile("" : "+s"(wave2));
+		long_wave((dhl_u64_t *)(lds_u64_t *)(&stage[wave2][0]), (dhl_u64_t *)(lds_u64_t *)(&ostage[wave2][0]), long_list + (size_t)(blockIdx.x * 4 + wave2) * 64, long_mask,
+			  outs + (size_t)blockIdx.x * blockDim.x, lane2);
 	}
 #ifdef DH_PROFILE
 	if (lane == 0)
