@@ -119,6 +119,7 @@ def dh_wave(sym, clk6, uap, ptype):
     ok = _wave_crc_is_zero(words, nbits, uap)
     assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
     assert ok == wave_crc_is_zero_start_aligned([_int_of(w) for w in words], nbits, uap)
+    assert ok == wave_crc_is_zero_two_words_per_lane([_int_of(w) for w in words], nbits, uap)
     return (10 if ok else 2), payload
 
 
@@ -197,6 +198,7 @@ def dm_wave(sym, clk6, uap, ptype):
     ok = _wave_crc_is_zero(words, nbits, uap)
     assert ok == wave_crc_is_zero_u64([_int_of(w) for w in words], nbits, uap)
     assert ok == wave_crc_is_zero_start_aligned([_int_of(w) for w in words], nbits, uap)
+    assert ok == wave_crc_is_zero_two_words_per_lane([_int_of(w) for w in words], nbits, uap)
     return (10 if ok else 2), payload
 
 
@@ -246,7 +248,7 @@ def _adv64inv():
 
 
 def wave_crc_is_zero_start_aligned(words, nbits, uap):
-    """The form the kernel runs: no lane needs another lane's word.  words[w] as in wave_crc_is_zero_u64 (zero behind nbits).
+    """The form the kernel ran until round 4 (one word per lane): no lane needs another lane's word.  words[w] as in wave_crc_is_zero_u64 (zero behind nbits).
     Appending zero bits advances the register by an invertible map, so `register == 0` may be tested on the payload padded
     to whole words; the seed is its bits on the first sixteen message bits; and the register after n words is A^(64 (n - 1))
     of the XOR over the words of A^(-64 w) (register of word w alone) -- again an invertible outer factor."""
@@ -256,4 +258,18 @@ def wave_crc_is_zero_start_aligned(words, nbits, uap):
         if lane == 0:
             word ^= _seed(uap)
         total ^= _apply(inv[lane], _crc_step_bits(0, _bits_of(word)))
+    return total == 0
+
+
+def wave_crc_is_zero_two_words_per_lane(words, nbits, uap):
+    """The kernel as of round 4 (long_payloads): lane l runs payload words 2 l and 2 l + 1 through ONE register from zero
+    (128 steps; a missing second word is 64 zero bits) and applies A^(-128 l), row 2 l of the same table: the XOR over the
+    lanes is A^64 of wave_crc_is_zero_start_aligned's total -- zero exactly when that is."""
+    inv = _adv64inv()
+    total = 0
+    words = list(words) + [0] * (len(words) & 1)
+    for lane in range(len(words) // 2):
+        w0 = words[2 * lane] ^ (_seed(uap) if lane == 0 else 0)
+        reg = _crc_step_bits(_crc_step_bits(0, _bits_of(w0)), _bits_of(words[2 * lane + 1]))
+        total ^= _apply(inv[2 * lane], reg)
     return total == 0
