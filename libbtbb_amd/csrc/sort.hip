@@ -33,7 +33,7 @@ struct OrderParams {
 	uint32_t shift;                            // bucket = lin >> shift
 	uint32_t ticket;                           // last workgroup of the extent pass works the parameters out
 	uint32_t crowded;                          // some bucket has more than ORDER_SMALL members (set by the scan of the counts)
-	uint32_t n_work;                           // records that share their bucket (order_scatter_kernel's worklist)
+	uint32_t any_shared;                       // order_scatter_kernel saw a record that shares its bucket: order_rank_list_kernel has work
 	uint32_t pad;
 };
 
@@ -225,49 +225,42 @@ __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, u
 // `final` (may be null): where a record that is alone in its bucket goes instead of `grouped` -- its bucket start IS its
 // rank, so when the list was parked somewhere else by the scan (btbbx_scan_ordered_device) the scatter is also the copy
 // into place and only the records that share a bucket are looked at again (order_rank_list_kernel)
-// `work` (with `final`): the positions in `grouped` of the records that share a bucket, appended with one counter atomic
-// per wave -- order_rank_list_kernel then ranks exactly those, one thread per record
+// `work` (with `final`): per record of the list, where in `grouped` it went if it shares its bucket with up to ORDER_SMALL
+// others, else ~0 -- four bytes per record that tell order_rank_list_kernel whom to rank (a dense worklist appended with one
+// counter atomic per wave made this kernel 130 us: 20 000 atomics on one address, profiles/r04_paths/chain_kernels_worklist.csv)
 __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, OrderParams *p, const uint32_t *start,
 							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final, uint32_t *work)
 {
 	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
-	const uint32_t rounds = (n + gridDim.x * 256 - 1) / (gridDim.x * 256);       // every lane of a wave runs the same number of rounds (ballots)
-	for (uint32_t r = 0; r < rounds; r++) {
-		const uint32_t i = r * gridDim.x * 256 + blockIdx.x * 256 + threadIdx.x;
-		bool shared = false;
-		uint32_t pos = 0;
-		if (i < n) {
-			const btbbx_hit h = hits[i];
-			const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
-			const uint32_t s0 = start[b], k = start[b + 1] - s0;  // a bucket of one (more than half of the records) needs no cursor
-			pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
-			HitRec *dst = reinterpret_cast<HitRec *>(k == 1 && final ? final : grouped);
-			dst[pos] = *reinterpret_cast<const HitRec *>(&h);
-			shared = k > 1 && k <= ORDER_SMALL;
-		}
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const btbbx_hit h = hits[i];
+		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+		const uint32_t s0 = start[b], k = start[b + 1] - s0;      // a bucket of one (more than half of the records) needs no cursor
+		const uint32_t pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
+		HitRec *dst = reinterpret_cast<HitRec *>(k == 1 && final ? final : grouped);
+		dst[pos] = *reinterpret_cast<const HitRec *>(&h);
 		if (work) {
-			const uint64_t m = __ballot(shared);
-			if (m) {
-				uint32_t base = 0;
-				if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m))
-					base = atomicAdd(&p->n_work, (uint32_t)__popcll(m));
-				base = (uint32_t)__shfl((int)base, __builtin_ctzll(m));
-				if (shared)
-					work[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pos;
-			}
+			const bool shared = k > 1 && k <= ORDER_SMALL;
+			work[i] = shared ? pos : ~0u;
+			if (shared)
+				p->any_shared = 1;                      // (plain store of a one by whoever sees it: order_rank_list_kernel's cue)
 		}
 	}
 }
 
-// one thread per record of the worklist: rank among its bucket-mates (they sit in L1 / L2), into place
+// one thread per record, the ones that share a bucket work: rank among the bucket-mates (they sit in L1 / L2), into place
 __global__ __launch_bounds__(256) void order_rank_list_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
 							      const uint32_t *work, btbbx_hit *out)
 {
-	const uint32_t n_work = p->n_work, shift = p->shift;
+	if (!p->any_shared)
+		return;                                         // every record alone in its bucket (sparse lists: the usual case)
+	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
-	for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < n_work; w += gridDim.x * 256) {
+	for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < n; w += gridDim.x * 256) {
 		const uint32_t i = work[w];
+		if (i == ~0u)
+			continue;                                   // alone in its bucket (in place already) or order_crowded_kernel's
 		const btbbx_hit h = grouped[i];
 		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
 		const uint32_t s = start[b], k = start[b + 1] - s;
@@ -425,18 +418,37 @@ static uint32_t order_nb_log2(uint32_t cap)
 	return l;
 }
 
-struct OrderLayout { size_t params, start, cursor, sums, grouped, parked, work, total; uint32_t nb_log2; };
-static OrderLayout order_layout(uint32_t cap)
+// A caller that knows the bounds of the list (stream count, search length) gets one more bit of buckets: the key space of
+// n_streams x mul keys seldom fills a power of two (79 streams: 62 % of one), so of 2^(nb_log2 + 1) buckets of half the width
+// between half and all are in use -- on the config-3 capture 2 048-bit buckets, narrower than the gap between two packets,
+// and no record shares its bucket (with 2^nb_log2 buckets of 4 096 bits 45 % did).  -> buckets in use
+static uint32_t order_fine_buckets(uint32_t n_streams, unsigned long long mul, uint32_t nb_log2_fine)
+{
+	const uint32_t shift = order_shift(n_streams, mul, nb_log2_fine);
+	const unsigned __int128 total = (unsigned __int128)n_streams * mul, nbu = (total + (((unsigned __int128)1 << shift) - 1)) >> shift;
+	const unsigned __int128 most = (unsigned __int128)1 << nb_log2_fine;
+	return (uint32_t)(nbu < most ? (nbu ? nbu : 1) : most);
+}
+
+struct OrderLayout { size_t params, start, cursor, sums, grouped, parked, work, total; uint32_t nb_log2, nb; };
+// n_streams != 0: the fine buckets (nb_log2 is then one more, nb = the buckets in use); the scratch always has room for them
+static OrderLayout order_layout(uint32_t cap, uint32_t n_streams = 0, unsigned long long mul = 0)
 {
 	OrderLayout L;
 	L.nb_log2 = order_nb_log2(cap);
-	const size_t nb = (size_t)1 << L.nb_log2;
+	const size_t nb_most = (size_t)2 << L.nb_log2;
+	L.nb = 1u << L.nb_log2;
+	if (n_streams) {
+		L.nb_log2 += 1;
+		L.nb = order_fine_buckets(n_streams, mul, L.nb_log2);
+	}
+	const size_t nb = L.nb;
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	L.params = 0;
 	L.start = up(sizeof(OrderParams));
-	L.cursor = L.start + up((nb + 1) * 4);
+	L.cursor = L.start + up((nb + 1) * 4);           // (parameters, counters and cursors of the buckets in use: one memset)
 	L.sums = L.cursor + up(nb * 4);
-	L.grouped = L.sums + up(1024 * 4);
+	L.grouped = L.start + up((nb_most + 1) * 4) + up(nb_most * 4) + up(1024 * 4);
 	L.parked = L.grouped + up((size_t)cap * sizeof(btbbx_hit));      // where btbbx_scan_ordered_device's scan leaves its list
 	L.work = L.parked + up((size_t)cap * sizeof(btbbx_hit));        // positions of the records that share a bucket
 	L.total = L.work + up((size_t)cap * 4);
@@ -456,7 +468,7 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 {
 	if (cap < 2)
 		return BTBBX_OK;
-	const OrderLayout L = order_layout(cap);
+	const OrderLayout L = order_layout(cap, n_streams, (unsigned long long)max_offset + 1);
 	if (!d_scratch || scratch_bytes < L.total || ((uintptr_t)d_scratch & 15) || ((uintptr_t)d_hits & 15)) {
 		set_error("btbbx_order_hits_device: scratch of %zu bytes (16-byte aligned) needed, %zu given", L.total, scratch_bytes);
 		return BTBBX_E_ARG;
@@ -465,7 +477,7 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	OrderParams *p = (OrderParams *)(base + L.params);
 	uint32_t *start = (uint32_t *)(base + L.start), *cursor = (uint32_t *)(base + L.cursor), *sums = (uint32_t *)(base + L.sums);
 	btbbx_hit *grouped = (btbbx_hit *)(base + L.grouped);
-	const uint32_t nb = 1u << L.nb_log2;
+	const uint32_t nb = L.nb;
 	// parameters, bucket counters and cursors are contiguous: one memset (done by btbbx_scan_ordered_device BEFORE its scan
 	// when the scan kernel itself counts the buckets)
 	if (!counted_by_scan)
@@ -494,22 +506,49 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 					   (unsigned long long)max_offset, p);
 		hipLaunchKernelGGL(order_hist_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start);
 	}
+	// BTBBX_ORDER_TIMING=1 (a measuring aid, tools/order_probe.py): HIP events between the launches, printed per call; it
+	// synchronises the stream
+	static const bool timing = getenv("BTBBX_ORDER_TIMING") != nullptr;
+	hipEvent_t ev[8];
+	int n_ev = 0;
+	auto mark = [&]() {
+		if (timing && n_ev < 8 && hipEventCreate(&ev[n_ev]) == hipSuccess)
+			(void)hipEventRecord(ev[n_ev++], stream);
+	};
+	mark();
 	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
 	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
 			   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+	mark();
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	mark();
 	if (counted_by_scan) {
 		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records of the worklist
 		const btbbx_hit *parked = (const btbbx_hit *)(base + L.parked);
 		uint32_t *work = (uint32_t *)(base + L.work);
 		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits, work);
+		mark();
 		hipLaunchKernelGGL(order_rank_list_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, work, d_hits);
 	} else {
 		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped, (btbbx_hit *)nullptr,
 				   (uint32_t *)nullptr);
 		hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
 	}
+	mark();
 	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits);
+	mark();
+	if (timing && n_ev) {
+		(void)hipEventSynchronize(ev[n_ev - 1]);
+		fprintf(stderr, "order_launch (%u buckets):", nb);
+		for (int i = 1; i < n_ev; i++) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+			fprintf(stderr, " %.1f", ms * 1e3f);
+		}
+		fprintf(stderr, " us (sums, apply, scatter, rank, crowded)\n");
+		for (int i = 0; i < n_ev; i++)
+			(void)hipEventDestroy(ev[i]);
+	}
 	HIP_TRY(hipGetLastError());
 	return BTBBX_OK;
 }
@@ -555,7 +594,7 @@ extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_wor
 		set_error("btbbx_scan_ordered_device: bad argument");
 		return BTBBX_E_ARG;
 	}
-	const OrderLayout L = order_layout(cap);
+	const OrderLayout L = order_layout(cap, n_streams, search_bits);
 	if (!d_scratch || scratch_bytes < L.total || ((uintptr_t)d_scratch & 15)) {
 		set_error("btbbx_scan_ordered_device: scratch of %zu bytes (16-byte aligned) needed, %zu given", L.total, scratch_bytes);
 		return BTBBX_E_ARG;
