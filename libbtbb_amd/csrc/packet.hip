@@ -36,6 +36,7 @@ struct __attribute__((aligned(16))) ChainLds {
 	uint16_t crc_z[3][256];    // the same followed by 1, 2, 3 zero bytes (slicing: four bytes per step)
 	uint8_t  par23[1024];      // FEC 2/3 parity of 10 data bits
 	int8_t   fix23[32];
+	uint16_t fixm23[32];       // the same as a mask: the data bit to flip, 0x8000 = undecodable (long_payloads)
 	uint8_t  whiten_idx[64];
 	uint16_t adv32[2][256];    // the CRC register 32 zero bytes later, by its low / high byte (linear: XOR the two)
 };
@@ -94,6 +95,8 @@ int chain_upload(const HostTables &t)
 			img.par23[i] = (uint8_t)par;
 		}
 		memcpy(img.fix23, t.fec23_fix, 32);
+		for (int i = 0; i < 32; i++)
+			img.fixm23[i] = t.fec23_fix[i] == -2 ? 0x8000u : t.fec23_fix[i] >= 0 ? (uint16_t)(1u << t.fec23_fix[i]) : 0u;
 		memcpy(img.whiten_idx, t.whiten_idx, 64);
 		for (int h = 0; h < 2; h++)
 			for (int i = 0; i < 256; i++) {
@@ -2069,33 +2072,27 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *stg, dhl_u64_t *lst, ui
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			// 2b. DM: the (15,10) blocks of the packet
-			// (two blocks per lane and step: their LDS round trips -- words, parity table, correction table, ds_or -- overlap)
+			// (two blocks per lane and step, every read unconditional -- a lane without a block reads the group's first word --:
+			// their LDS round trips -- words, parity table, correction mask -- overlap.  Bits of the last block that lie behind
+			// payload_length need no cut here: they end in the partial last word, which step 3 cuts, or in a word no lane keeps)
 			for (uint32_t b0 = 0; ; b0 += 2u * G) {
 				const uint32_t bA = b0 + sub, bB = bA + G;
 				const bool onA = p_fec && bA < nblocks, onB = p_fec && bB < nblocks;
 				if (!__ballot(onA))
 					break;
-				const uint32_t qA = p_sh + 122u + 15u * bA, qB = qA + 15u * G, iA = 2u * stg_base + (qA >> 5), iB = 2u * stg_base + (qB >> 5);
-				uint32_t blkA = 0, blkB = 0;
-				if (onA)
-					blkA = __builtin_amdgcn_alignbit(stg32[iA + 1], stg32[iA], qA & 31u) & 0x7fffu;
-				if (onB)
-					blkB = __builtin_amdgcn_alignbit(stg32[iB + 1], stg32[iB], qB & 31u) & 0x7fffu;
+				const uint32_t qA = p_sh + 122u + 15u * bA, qB = qA + 15u * G;
+				const uint32_t iA = 2u * stg_base + (onA ? qA >> 5 : 0u), iB = 2u * stg_base + (onB ? qB >> 5 : 0u);
+				const uint32_t blkA = __builtin_amdgcn_alignbit(stg32[iA + 1], stg32[iA], qA & 31u);
+				const uint32_t blkB = __builtin_amdgcn_alignbit(stg32[iB + 1], stg32[iB], qB & 31u);
 				uint32_t dataA = blkA & 0x3ffu, dataB = blkB & 0x3ffu;
-				const uint32_t diffA = (blkA >> 10) ^ g_lds.par23[dataA], diffB = (blkB >> 10) ^ g_lds.par23[dataB];
-				const int fixA = g_lds.fix23[diffA & 31u], fixB = g_lds.fix23[diffB & 31u];
-				if ((onA && fixA == -2) || (onB && fixB == -2))
+				const uint32_t mA = g_lds.fixm23[((blkA >> 10) ^ g_lds.par23[dataA]) & 31u], mB = g_lds.fixm23[((blkB >> 10) ^ g_lds.par23[dataB]) & 31u];
+				if ((onA && mA >> 15) || (onB && mB >> 15))
 					fail = true;
-				if (fixA >= 0)
-					dataA ^= 1u << fixA;
-				if (fixB >= 0)
-					dataB ^= 1u << fixB;
+				dataA ^= mA & 0x3ffu;
+				dataB ^= mB & 0x3ffu;
 				auto put = [&](bool on, uint32_t b, uint32_t data) {
 					if (on) {
-						const uint32_t bit = 10u * b, left = nbits - bit;
-						if (left < 10)
-							data &= (1u << left) - 1;                           // (nothing behind payload_length reaches the packed words)
-						const uint32_t d = 2u * DHL_PB + 4u * gbase + (bit >> 5), s5 = bit & 31u;
+						const uint32_t bit = 10u * b, d = 2u * DHL_PB + 4u * gbase + (bit >> 5), s5 = bit & 31u;
 						__hip_atomic_fetch_or(lst32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 						if (s5 > 22)
 							__hip_atomic_fetch_or(lst32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
