@@ -2072,34 +2072,39 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *stg, dhl_u64_t *lst, ui
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			// 2b. DM: the (15,10) blocks of the packet
-			// (two blocks per lane and step, every read unconditional -- a lane without a block reads the group's first word --:
-			// their LDS round trips -- words, parity table, correction mask -- overlap.  Bits of the last block that lie behind
-			// payload_length need no cut here: they end in the partial last word, which step 3 cuts, or in a word no lane keeps)
-			for (uint32_t b0 = 0; ; b0 += 2u * G) {
-				const uint32_t bA = b0 + sub, bB = bA + G;
-				const bool onA = p_fec && bA < nblocks, onB = p_fec && bB < nblocks;
-				if (!__ballot(onA))
+			// FOUR consecutive blocks per lane and step: 60 stream bits from three staged dwords (every read unconditional:
+			// a lane without blocks reads the group's first words), four parity and four correction look-ups in flight
+			// together, and the 40 payload bits start on a byte of the packed payload -- two ds_or, no branch.  Blocks behind
+			// the packet's last are zeroed before they are decoded (zeros decode to zeros); bits of the last block behind
+			// payload_length end in the partial last word, which step 3 cuts, or in a word no lane keeps.  (Two blocks per
+			// lane and step, one ds_or pair each: 37 instructions per block against 14.)
+			for (uint32_t n0 = 0; ; n0 += G) {
+				const uint32_t n = n0 + sub;
+				const bool on = p_fec && 4u * n < nblocks;
+				if (!__ballot(on))
 					break;
-				const uint32_t qA = p_sh + 122u + 15u * bA, qB = qA + 15u * G;
-				const uint32_t iA = 2u * stg_base + (onA ? qA >> 5 : 0u), iB = 2u * stg_base + (onB ? qB >> 5 : 0u);
-				const uint32_t blkA = __builtin_amdgcn_alignbit(stg32[iA + 1], stg32[iA], qA & 31u);
-				const uint32_t blkB = __builtin_amdgcn_alignbit(stg32[iB + 1], stg32[iB], qB & 31u);
-				uint32_t dataA = blkA & 0x3ffu, dataB = blkB & 0x3ffu;
-				const uint32_t mA = g_lds.fixm23[((blkA >> 10) ^ g_lds.par23[dataA]) & 31u], mB = g_lds.fixm23[((blkB >> 10) ^ g_lds.par23[dataB]) & 31u];
-				if ((onA && mA >> 15) || (onB && mB >> 15))
+				const uint32_t left = nblocks - 4u * n, have = on ? (left < 4u ? left : 4u) : 0u;
+				const uint32_t q = p_sh + 122u + 60u * n, i = 2u * stg_base + (on ? q >> 5 : 0u);
+				const uint32_t w0 = stg32[i], w1 = stg32[i + 1], w2 = stg32[i + 2];
+				const uint64_t vm = (1ULL << (15u * have)) - 1;
+				const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, q & 31u) & (uint32_t)vm;
+				const uint32_t x1 = __builtin_amdgcn_alignbit(w2, w1, q & 31u) & (uint32_t)(vm >> 32);
+				const uint32_t b2 = __builtin_amdgcn_alignbit(x1, x0, 30);
+				uint32_t d0 = x0 & 0x3ffu, d1 = (x0 >> 15) & 0x3ffu, d2 = b2 & 0x3ffu, d3 = (x1 >> 13) & 0x3ffu;
+				const uint32_t m0 = g_lds.fixm23[((x0 >> 10) & 31u) ^ g_lds.par23[d0]], m1 = g_lds.fixm23[((x0 >> 25) & 31u) ^ g_lds.par23[d1]];
+				const uint32_t m2 = g_lds.fixm23[((b2 >> 10) & 31u) ^ g_lds.par23[d2]], m3 = g_lds.fixm23[((x1 >> 23) & 31u) ^ g_lds.par23[d3]];
+				if ((m0 | m1 | m2 | m3) >> 15)
 					fail = true;
-				dataA ^= mA & 0x3ffu;
-				dataB ^= mB & 0x3ffu;
-				auto put = [&](bool on, uint32_t b, uint32_t data) {
-					if (on) {
-						const uint32_t bit = 10u * b, d = 2u * DHL_PB + 4u * gbase + (bit >> 5), s5 = bit & 31u;
-						__hip_atomic_fetch_or(lst32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-						if (s5 > 22)
-							__hip_atomic_fetch_or(lst32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					}
-				};
-				put(onA, bA, dataA);
-				put(onB, bB, dataB);
+				d0 ^= m0 & 0x3ffu;
+				d1 ^= m1 & 0x3ffu;
+				d2 ^= m2 & 0x3ffu;
+				d3 ^= m3 & 0x3ffu;
+				if (on) {
+					const uint32_t byte = 5u * n, d = 2u * DHL_PB + 4u * gbase + (byte >> 2);
+					const uint64_t v = ((uint64_t)(d3 >> 2) << 32 | (d0 | d1 << 10 | d2 << 20 | d3 << 30)) << (8u * (byte & 3u));
+					__hip_atomic_fetch_or(lst32 + d, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__hip_atomic_fetch_or(lst32 + d + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
