@@ -2252,29 +2252,38 @@ __device__ __forceinline__ void ev_payloads(dhl_u64_t *stg, dhl_u64_t *lst, uint
 			stg[2 * gbase + G + sub] = w1;
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			for (uint32_t b0 = 0; ; b0 += G) {
-				const uint32_t b = b0 + sub;
-				const bool on = is4 && b < nblocks;
+			// (four consecutive blocks per lane and step, as in long_payloads)
+			for (uint32_t n0 = 0; ; n0 += G) {
+				const uint32_t n = n0 + sub;
+				const bool on = is4 && 4u * n < nblocks;
 				if (!__ballot(on))
 					break;
-				bool bad = false;
+				const uint32_t left = nblocks - 4u * n, have = on ? (left < 4u ? left : 4u) : 0u;
+				const uint32_t q = p_sh + 122u + 60u * n, i = 4u * gbase + (on ? q >> 5 : 0u);
+				const uint32_t v0 = stg32[i], v1 = stg32[i + 1], v2 = stg32[i + 2];
+				const uint64_t vm = (1ULL << (15u * have)) - 1;
+				const uint32_t x0 = __builtin_amdgcn_alignbit(v1, v0, q & 31u) & (uint32_t)vm;
+				const uint32_t x1 = __builtin_amdgcn_alignbit(v2, v1, q & 31u) & (uint32_t)(vm >> 32);
+				const uint32_t b2 = __builtin_amdgcn_alignbit(x1, x0, 30);
+				uint32_t d0 = x0 & 0x3ffu, d1 = (x0 >> 15) & 0x3ffu, d2 = b2 & 0x3ffu, d3 = (x1 >> 13) & 0x3ffu;
+				const uint32_t m0 = g_lds.fixm23[((x0 >> 10) & 31u) ^ g_lds.par23[d0]], m1 = g_lds.fixm23[((x0 >> 25) & 31u) ^ g_lds.par23[d1]];
+				const uint32_t m2 = g_lds.fixm23[((b2 >> 10) & 31u) ^ g_lds.par23[d2]], m3 = g_lds.fixm23[((x1 >> 23) & 31u) ^ g_lds.par23[d3]];
+				const uint32_t bad = (m0 >> 15) | (m1 >> 15) << 1 | (m2 >> 15) << 2 | (m3 >> 15) << 3;  // which of the four do not decode
+				d0 ^= m0 & 0x3ffu;
+				d1 ^= m1 & 0x3ffu;
+				d2 ^= m2 & 0x3ffu;
+				d3 ^= m3 & 0x3ffu;
 				if (on) {
-					const uint32_t q = p_sh + 122u + 15u * b, i = 4u * gbase + (q >> 5);
-					const uint32_t blk = __builtin_amdgcn_alignbit(stg32[i + 1], stg32[i], q & 31u) & 0x7fffu;
-					uint32_t data = blk & 0x3ffu;
-					const uint32_t diff = (blk >> 10) ^ g_lds.par23[data];
-					const int fix = g_lds.fix23[diff & 31u];
-					bad = fix == -2;
-					if (fix >= 0)
-						data ^= 1u << fix;
-					const uint32_t bit = 10u * b, d = 2u * DHL_PB + 2u * gbase + (bit >> 5), s5 = bit & 31u;
-					__hip_atomic_fetch_or(lst32 + d, data << s5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					if (s5 > 22)
-						__hip_atomic_fetch_or(lst32 + d + 1, data >> (32u - s5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					const uint32_t byte = 5u * n, d = 2u * DHL_PB + 2u * gbase + (byte >> 2);
+					const uint64_t v = ((uint64_t)(d3 >> 2) << 32 | (d0 | d1 << 10 | d2 << 20 | d3 << 30)) << (8u * (byte & 3u));
+					__hip_atomic_fetch_or(lst32 + d, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					__hip_atomic_fetch_or(lst32 + d + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
-				const uint64_t gm = (__ballot(bad) >> gbase) & gmask;
+				const uint64_t gm = (__ballot(bad != 0) >> gbase) & gmask;
+				const uint32_t gl = gm ? (uint32_t)__builtin_ctzll(gm) : 0u;
+				const uint32_t gb = (uint32_t)__shfl((int)bad, (int)(gbase + gl));
 				if (gm && first_fail == nblocks)
-					first_fail = b0 + (uint32_t)__builtin_ctzll(gm);
+					first_fail = 4u * (n0 + gl) + (uint32_t)__builtin_ctz(gb | 16u);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
