@@ -302,7 +302,7 @@ def test_ev4_ev5_payloads_leave_through_the_wave_phase():
     first 45 symbols and behind them), wrong clocks, captures cut short by max_length and by the next packet, records that
     hold random bytes on entry, and DM / DH packets in the same waves."""
     orc = _libs.oracle()
-    rng = np.random.default_rng(1213)
+    rng = np.random.default_rng(_libs.seed(1213))
     n_streams, n_words = 6, 4096
     sym, rows = _long_capture(rng, 2400, n_streams, n_words, others=(synth.TYPE_DM3, synth.TYPE_DH5, synth.TYPE_DH1, synth.TYPE_DM1),
                               longs=(synth.TYPE_EV4, synth.TYPE_EV5, synth.TYPE_EV5, synth.TYPE_EV4))
@@ -362,7 +362,7 @@ def test_ev5_lengths_found_by_the_prefix_over_the_lanes():
     alone, once in ~370 packets.  Thousands of EV5 headers in front of noise: every record equal to the lane-by-lane decode of
     the cut-out packet, and the ones that end early equal to the oracle."""
     orc = _libs.oracle()
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(_libs.seed(77))
     n_streams, per_stream, gap = 8, 768, 1700
     n_words = (per_stream * gap + 4096) // 64
     sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
