@@ -2174,6 +2174,114 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *stg, dhl_u64_t *lst, ui
 	}
 }
 
+// A wave whose deferred payloads are all DH (no FEC 2/3: nothing goes through LDS but the list): THREE payload words per lane,
+// G = 8 / 16 lanes per packet -- a DH5 takes 15 lanes of 16 and four share a round (two words per lane: 22 of 32, two per round),
+// a DH3 eight of eight.  The steps are long_payloads' 1, 2a, 3, 4, 5 with the matrix A^(-192 sub); the lane's four stream words are
+// what a DM lane stages, so the prefetch costs the same registers.
+__device__ __forceinline__ void dh_payloads(dhl_u64_t *lst, uint32_t n_def, uint32_t logg, btbbx_pkt_out *outs, uint32_t lane)
+{
+	const uint32_t G = 1u << logg, R = 64u >> logg;
+	const uint32_t sub = lane & (G - 1), grp = lane >> logg;
+	uint32_t col[8];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(g_adv64inv) + 6 * sub;
+		const uint4 a = src[0], b = src[1];
+		col[0] = a.x; col[1] = a.y; col[2] = a.z; col[3] = a.w; col[4] = b.x; col[5] = b.y; col[6] = b.z; col[7] = b.w;
+	}
+	const uint32_t wh_lane = (192u * sub) % 127u;              // whitening phase of word 3 sub relative to the payload's first bit
+	const uint32_t rounds = (n_def + R - 1) >> (6 - logg);
+	auto request = [&](uint32_t r, uint64_t (&w)[4]) {
+		const uint32_t e = r * R + grp;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			w[k] = 0;
+		if (e < n_def) {
+			const uint64_t a = lst[DHL_LIST + 2 * e];
+			dhl_g64_t *const src = (dhl_g64_t *)(uintptr_t)(a & 0xffffffffffffULL);
+			const uint32_t p_nw = (uint32_t)(a >> 48) & 127u, p_sh = (uint32_t)(a >> 55) & 63u;
+			const uint32_t i0 = 3u * sub + ((p_sh + 122u) >> 6);
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				if (i0 + (uint32_t)k < p_nw)
+					w[k] = src[i0 + (uint32_t)k];
+		}
+	};
+	uint64_t nw[4];
+	request(0, nw);
+	uint64_t st_val[3] = {0, 0, 0};
+	uint32_t st_pkt = 0, st_n = 0;
+	auto store = [&]() {
+		uint64_t *const dst = outs[st_pkt].payload + 3 * sub;
+		if (st_n >= 2)
+			*reinterpret_cast<dhl_pair_t *>(dst) = dhl_pair_t{st_val[0], st_val[1]};
+		else if (st_n == 1)
+			dst[0] = st_val[0];
+		if (st_n == 3)
+			dst[2] = st_val[2];
+	};
+	for (uint32_t r = 0; r < rounds; r++) {
+		const uint32_t e = r * R + grp;
+		const bool has = e < n_def;
+		uint64_t pa = 0, pb = 0;
+		if (has) {
+			pa = lst[DHL_LIST + 2 * e];
+			pb = lst[DHL_LIST + 2 * e + 1];
+		}
+		const uint32_t p_sh = (uint32_t)(pa >> 55) & 63u;
+		const uint32_t p_pkt = (uint32_t)pb & 0xffu, nbits = (uint32_t)(pb >> 20) & 0xfffu;
+		const uint32_t p_widx = (uint32_t)(pb >> 35) & 127u, p_uap = (uint32_t)(pb >> 42) & 0xffu;
+		const bool p_wht = (pb >> 34) & 1u;
+		const uint32_t T = nbits >> 6, nwp = (nbits + 63u) >> 6;
+		// the lane's three payload words: funnel shifts of its four stream words (by every lane, wanted or not: the round's one
+		// wait for memory sits here)
+		const uint32_t sft = (p_sh + 122u) & 63u;
+		uint64_t word[3];
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			word[k] = sft ? (nw[k] >> sft) | (nw[k + 1] << (64u - sft)) : nw[k];
+			if (!has)
+				word[k] = 0;
+		}
+		store();
+		if (r + 1 < rounds)
+			request(r + 1, nw);
+		const uint32_t j0 = 3u * sub, Tq = T / 3u, Tr = T - 3u * Tq;
+		const bool part = has && Tq == sub && (nbits & 63u);        // this lane holds the partial last word
+		uint64_t oldw = 0;
+		if (part)
+			oldw = outs[p_pkt].payload[T];
+		const uint64_t keep = (1ULL << (nbits & 63u)) - 1;          // (of the partial last word)
+		uint64_t out[3] = {0, 0, 0};
+		uint32_t idx = p_widx + wh_lane;
+		idx = idx >= 127u ? idx - 127u : idx;
+		uint32_t n_act = 0;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			if (has && j0 + (uint32_t)k < nwp) {
+				out[k] = word[k] ^ (p_wht ? wh_bits(idx, 64) : 0ULL);
+				if (part && Tr == (uint32_t)k)
+					out[k] &= keep;
+				n_act = (uint32_t)k + 1u;
+			}
+			idx += 64u;
+			idx = idx >= 127u ? idx - 127u : idx;
+		}
+		const uint64_t cw = out[0] ^ (sub == 0 ? (uint64_t)crc_seed(p_uap) : 0ULL);
+		uint32_t reg = crc_word(crc_word(0, (uint32_t)cw), (uint32_t)(cw >> 32));
+		reg = crc_word(crc_word(reg, (uint32_t)out[1]), (uint32_t)(out[1] >> 32));
+		reg = crc_word(crc_word(reg, (uint32_t)out[2]), (uint32_t)(out[2] >> 32));
+		const uint32_t total = group_xor(apply_columns(col, reg), logg);
+		st_n = n_act;
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			st_val[k] = part && Tr == (uint32_t)k ? out[k] | (oldw & ~keep) : out[k];
+		st_pkt = p_pkt;
+		if (has && sub == 0)
+			outs[p_pkt].payload_rv = total == 0 ? 10 : 2;           // (decode_hits_kernel left a placeholder)
+	}
+	store();
+}
+
 // EV4 (:1044-1097) and EV5 (:1099-1128) payloads of a wave, in a loop of their own (rare types; and what they keep in
 // registers -- two more matrices, a prefix over the lanes, eight registers per word -- stays out of long_payloads, whose
 // allocation decides the occupancy of decode_hits_kernel).  n_ev list entries from DHL_LIST + 2 first on; G = 8 .. 32 lanes
@@ -2399,9 +2507,13 @@ __device__ __forceinline__ void long_wave(dhl_u64_t *stg, dhl_u64_t *lst, const 
 		lst[DHL_LIST + 2 * rank + 1] = (uint64_t)e.z | (uint64_t)e.w << 32;
 	}
 	if (n_dh) {
-		const uint32_t w = ev ? 0u : own_words;                 // (two payload words per lane)
-		const uint32_t logg = __ballot(w > 32) ? 5u : __ballot(w > 16) ? 4u : 3u;
-		long_payloads(stg, lst, n_dh, logg, outs, lane);
+		const uint32_t w = ev ? 0u : own_words;
+		if (__ballot(mine && !ev && (e.w & 3u) == DHL_DM)) {    // (two payload words per lane)
+			const uint32_t logg = __ballot(w > 32) ? 5u : __ballot(w > 16) ? 4u : 3u;
+			long_payloads(stg, lst, n_dh, logg, outs, lane);
+		} else {                                                // DH only: three
+			dh_payloads(lst, n_dh, __ballot(w > 24) ? 4u : 3u, outs, lane);
+		}
 	}
 	if (n_ev) {
 		const uint32_t w = ev ? own_words : 0u;
@@ -2554,7 +2666,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			// are all but unused otherwise: class 0 has one length, HV packets that are not cut short another)
 			if (DH_LONG_PHASE && !small && want > 126 && (cls == 2 || cls == 3)) {
 				const uint32_t pbits = cls == 2 ? (want - 122) / 15 * 10 : want - 122, words = (pbits + 63) >> 6;   // (about: the grouping only)
-				key = (cls == 2 ? 32u : 1u) + (words > 32 ? 2u : words > 16 ? 1u : 0u);      // (two words per lane: groups of 32 / 16 / 8)
+				key = cls == 2 ? 32u + (words > 32 ? 2u : words > 16 ? 1u : 0u)          // (DM, two words per lane: groups of 32 / 16 / 8)
+					       : 1u + (words > 24 ? 1u : 0u);                                // (DH, three: 16 / 8)
 			}
 		}
 		const uint32_t r = atomicAdd(&sort_cnt[key], 1u);
