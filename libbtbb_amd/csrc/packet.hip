@@ -1918,26 +1918,31 @@ __device__ __forceinline__ uint32_t payload_extent(const PState &s0, uint32_t ty
 // A lane that walks a DM3 / DH3 / DM5 / DH5 payload alone reads one stream word and writes one record word per step,
 // each a sector of its own, one latency after the other: 1.4 - 3.5 ms per 1.29 M full-length packets against 0.13 - 0.15
 // for the single-slot types (profiles/r03_chain/decode_by_type.txt).  do_DM / do_DH therefore stop after their checks
-// when the payload has more than DHL_MIN_BITS bits (PState::def_nbits) and the wave works those packets off together:
-// G = 8 / 16 / 32 / 64 lanes per packet -- one lane per 64-bit word of the longest deferred PAYLOAD of the wave (the
-// workgroup sort keeps packets of one G together) --, 64 / G packets per round.  Per round, lane `sub` of a group
-//   1. holds two stream words of its packet, requested one round ahead (a round's stores and loads all have a round's
-//      worth of work to complete in: gfx9 counts both in one in-order counter);
-//   2. DH (:962-1011): payload word `sub` is a funnel shift of those two words.  DM (:898-958): the words go to LDS
-//      (zeroed at and behind the captured length when a block reaches there: the reference reads zeros), blocks sub,
-//      sub + G, .. of the (15,10) code are decoded from LDS and their ten bits ORed into the packed payload in LDS
-//      (ds_or); one failing block anywhere in the packet and nothing is written (rv 0), as in the reference;
-//   3. unwhitens its word with the 64 whitening bits from (start + 64 sub) mod 127 and cuts it at payload_length;
-//   4. CRC (:671-690, :772-781): the register is GF(2)-linear; a seed is the same as its bits XORed onto the first
-//      sixteen message bits; zero bits appended to a message advance the register by an invertible map, so "register
-//      == 0" can be tested on the payload padded to whole words; and with A = "advance by one bit" the register after
-//      n words is A^(64 (n - 1)) applied to the XOR over the words of A^(-64 j) (register of word j alone) -- the outer
-//      factor is invertible too.  So every lane runs its own word from a zero register (two four-byte steps), applies
-//      the FIXED matrix A^(-64 sub) -- sixteen 16-bit columns per lane from g_adv64inv, loaded once per wave -- and the
-//      group XORs: zero <=> the reference's compare of the computed with the received CRC succeeds.  No lane needs
-//      another lane's word, whatever the payload length;
-//   5. stores its word (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
-// tests/_wave_model.py is the numpy model of these steps (pinned against the oracle on the CPU).
+// when the payload has more than DHL_MIN_BITS bits, EV4 / EV5 before their loops (PState::def_nbits, defer_payload), and
+// the wave works those packets off together, a group of G lanes per packet, 64 / G packets per round:
+//   long_payloads   DM and DH, TWO payload words per lane, G = 8 / 16 / 32 (the workgroup sort keeps packets of one G
+//                   together).  Per round, lane `sub` of a group
+//     1. holds four stream words of its packet, requested one round ahead (a round's stores and loads all have a round's
+//        worth of work to complete in: gfx9 counts both in one in-order counter);
+//     2. DH (:962-1011): payload words 2 sub, 2 sub + 1 are funnel shifts of three of them.  DM (:898-958): the words go
+//        to LDS (zeroed at and behind the captured length when a block reaches there: the reference reads zeros), FOUR
+//        consecutive blocks of the (15,10) code per lane and step are decoded from LDS and their 40 bits ORed into the
+//        packed payload in LDS (two ds_or: they start on a byte); one failing block anywhere in the packet and nothing
+//        is written (rv 0), as in the reference;
+//     3. unwhitens its words with the whitening bits from (start + 64 j) mod 127 and cuts at payload_length;
+//     4. CRC (:671-690, :772-781): the register is GF(2)-linear; a seed is the same as its bits XORed onto the first
+//        sixteen message bits; zero bits appended to a message advance the register by an invertible map, so "register
+//        == 0" can be tested on the payload padded to whole words; and with A = "advance by one bit" the register after
+//        n words is an invertible map applied to the XOR over the words of A^(-64 j) (register of word j alone).  So
+//        every lane runs its own two words from a zero register (four four-byte steps), applies the FIXED matrix
+//        A^(-128 sub) -- sixteen 16-bit columns per lane from g_adv64inv, loaded once per wave -- and the group XORs:
+//        zero <=> the reference's compare of the computed with the received CRC succeeds.  No lane needs another lane's
+//        word, whatever the payload length;
+//     5. stores its words (344 contiguous bytes for a DH5; the last word keeps the record's bits behind the payload).
+//   dh_payloads     a wave with DH payloads only: the same without step 2's LDS, THREE words per lane, G = 8 / 16.
+//   ev_payloads     EV4 (:1044-1097) / EV5 (:1099-1128), one word per lane: the payload ends at the first byte count whose
+//                   CRC register is zero -- a prefix of registers over the lanes.
+// tests/_wave_model.py is the numpy model of the CRC steps (pinned against the oracle on the CPU).
 // two LDS areas per wave (in decode_hits_kernel: its input stage and its result stage, both free by then):
 #define DHL_STG_WORDS 288u                   // `stg`: the round's DM packets as they lie in the stream: 4 G (+ G / 4 + 1: LDS banks) words per group
 #define DHL_LIST   0u                        // `lst`: 64 x 2 words: what the owner lanes know about their deferred packets

@@ -523,7 +523,7 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
 	mark();
 	if (counted_by_scan) {
-		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records of the worklist
+		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records that share a bucket
 		const btbbx_hit *parked = (const btbbx_hit *)(base + L.parked);
 		uint32_t *work = (uint32_t *)(base + L.work);
 		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits, work);
