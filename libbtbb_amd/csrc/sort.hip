@@ -436,9 +436,10 @@ static OrderLayout order_layout(uint32_t cap, uint32_t n_streams = 0, unsigned l
 {
 	OrderLayout L;
 	L.nb_log2 = order_nb_log2(cap);
-	const size_t nb_most = (size_t)2 << L.nb_log2;
+	// (at most 2^22 buckets either way: the scans of the counts run as up to 1024 workgroups of 4096 counters)
+	const size_t nb_most = (size_t)1 << (L.nb_log2 < 22 ? L.nb_log2 + 1 : 22);
 	L.nb = 1u << L.nb_log2;
-	if (n_streams) {
+	if (n_streams && L.nb_log2 < 22) {
 		L.nb_log2 += 1;
 		L.nb = order_fine_buckets(n_streams, mul, L.nb_log2);
 	}
@@ -517,6 +518,10 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	};
 	mark();
 	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
+	if (scan_blocks > 1024) {                           // (order_layout keeps nb <= 2^22; order_scan_apply_kernel adds up 1024 sums)
+		set_error("btbbx_order_hits_device: %u buckets", nb);
+		return BTBBX_E_ARG;
+	}
 	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
 			   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
 	mark();

@@ -516,7 +516,9 @@ def test_scan_ordered_device(lap):
         want += [(ch, o, l, e) for (o, l, e) in _libs.orc_find_all(sym, n, lap if lap != bt.LAP_ANY else _libs.LAP_ANY, 2)]
     buf = np.concatenate(rows)
     d_w = bt.DeviceBuffer(buf.nbytes).upload(buf)
-    for cap in (len(want) + 100, len(want) // 3):
+    # (capacities around 2^21 and 2^22: the bucket count of the ordering -- one more bit when the caller gives the bounds -- is at
+    # its largest there)
+    for cap in (len(want) + 100, len(want) // 3, (1 << 21) - 3, (1 << 21) + 1, (1 << 22) + 5):
         d_h = bt.DeviceBuffer(cap * 16).zero()
         d_c = bt.DeviceBuffer(16).zero()
         sb = lib.btbbx_order_hits_scratch_bytes(cap)
