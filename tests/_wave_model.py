@@ -273,3 +273,53 @@ def wave_crc_is_zero_two_words_per_lane(words, nbits, uap):
         reg = _crc_step_bits(_crc_step_bits(0, _bits_of(w0)), _bits_of(words[2 * lane + 1]))
         total ^= _apply(inv[2 * lane], reg)
     return total == 0
+
+
+def wave_crc_is_zero_three_words_per_lane(words, nbits, uap):
+    """dh_payloads: lane l runs payload words 3 l .. 3 l + 2 through one register from zero and applies A^(-192 l) (row 3 l)."""
+    inv = _adv64inv()
+    total = 0
+    words = list(words) + [0] * (-len(words) % 3)
+    for lane in range(len(words) // 3):
+        reg = 0
+        for k in range(3):
+            w = words[3 * lane + k] ^ (_seed(uap) if lane == 0 and k == 0 else 0)
+            reg = _crc_step_bits(reg, _bits_of(w))
+        total ^= _apply(inv[3 * lane], reg)
+    return total == 0
+
+
+def ev_registers_by_lane_prefix(words, uap):
+    """ev_payloads: the CRC register IN FRONT of every payload word without a lane walking the words in front of it.
+    q_j = A^(-64 (j + 1)) (register of word j alone, the seed on word 0's first sixteen bits); the register in front of word l
+    is A^(64 l) applied to the XOR of q_0 .. q_(l - 1) -- an exclusive XOR prefix over the lanes between two per-lane
+    matrices (g_adv64inv row l + 1, g_adv64fwd row l).  -> list of registers, one per word"""
+    inv, fwd = _adv64inv(), _adv64()
+    out, acc = [], 0
+    for lane, word in enumerate(words):
+        out.append(_apply(fwd[lane], acc))
+        w = word ^ (_seed(uap) if lane == 0 else 0)
+        acc ^= _apply(inv[lane + 1], _crc_step_bits(0, _bits_of(w)))
+    return out
+
+
+def fec23_quad(stream_bits, q, have):
+    """long_payloads' step 2b for ONE lane: the four (15,10) blocks that start at stream bit q, `have` of them inside the
+    packet -> (40 payload bits as an integer, any undecodable).  Written the way the kernel indexes: three dwords, two
+    funnel shifts, the third block across the 32-bit seam."""
+    dw = [_int_of(stream_bits[32 * i:32 * i + 32]) for i in range((len(stream_bits) + 31) // 32)] + [0, 0, 0]
+    i, s = q >> 5, q & 31
+    align = lambda hi, lo, sh: ((lo >> sh) | (hi << (32 - sh))) & 0xFFFFFFFF if sh else lo      # noqa: E731
+    vm = (1 << (15 * have)) - 1
+    x0 = align(dw[i + 1], dw[i], s) & (vm & 0xFFFFFFFF)
+    x1 = align(dw[i + 2], dw[i + 1], s) & (vm >> 32)
+    b2 = align(x1, x0, 30)
+    blocks = [x0 & 0x7FFF, (x0 >> 15) & 0x7FFF, b2 & 0x7FFF, (x1 >> 13) & 0x7FFF]
+    out, bad = 0, False
+    for k, blk in enumerate(blocks):
+        bits15 = np.array([(blk >> j) & 1 for j in range(15)], dtype=np.uint8)
+        ok, data = _fec23_block(bits15)
+        if k < have and not ok:
+            bad = True
+        out |= _int_of(data) << (10 * k)
+    return out, bad

@@ -63,3 +63,71 @@ def test_lane_matrices_compose():
     for lane in (0, 1, 2, 17, 42, 63):
         reg = int(rng.integers(0, 1 << 16))
         assert wm._apply(adv[lane], reg) == wm._crc_step_bits(reg, np.zeros(64 * lane, np.uint8))
+
+
+def test_three_words_per_lane_and_lane_prefix_registers():
+    """The two CRC forms round 4 added to the kernel, on the CPU against the bit-serial register: three words per lane with
+    A^(-192 l) (dh_payloads), and the register IN FRONT of every word from an XOR prefix over the lanes between two per-lane
+    matrices (ev_payloads: that register, then eight byte steps, is how EV4 / EV5 find where their payload ends)."""
+    rng = np.random.default_rng(_libs.seed(73))
+    for trial in range(60):
+        n_words = int(rng.integers(1, 44))
+        uap = int(rng.integers(0, 256))
+        words = [int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2)) for _ in range(n_words)]
+        nbits = 64 * n_words
+        bits = np.concatenate([wm._bits_of(w) for w in words])
+        # registers in front of every word, serially (the seed is the register's start value)
+        regs, reg = [], wm._seed(uap)
+        for w in range(n_words):
+            regs.append(reg)
+            reg = wm._crc_step_bits(reg, bits[64 * w:64 * w + 64])
+        # (lane 0 starts from zero: the seed rides on the first sixteen bits of word 0, where the kernel's byte steps meet it)
+        assert wm.ev_registers_by_lane_prefix(words, uap) == [0] + regs[1:], trial
+        # make the payload's CRC come out right now and then: the last sixteen bits = the register in front of them
+        if trial % 2:
+            tail = wm._crc_step_bits(wm._seed(uap), bits[:nbits - 16])
+            words[-1] = (words[-1] & ((1 << 48) - 1)) | (tail << 48)
+            bits = np.concatenate([wm._bits_of(w) for w in words])
+        want = wm._crc_step_bits(wm._seed(uap), bits) == 0
+        assert want == bool(trial % 2) or not trial % 2, trial
+        assert wm.wave_crc_is_zero_three_words_per_lane(words, nbits, uap) == want, trial
+        assert wm.wave_crc_is_zero_two_words_per_lane(words, nbits, uap) == want, trial
+        assert wm.wave_crc_is_zero_start_aligned(words, nbits, uap) == want, trial
+
+
+def test_four_fec23_blocks_per_lane():
+    """long_payloads' FEC step the way the kernel indexes it -- three dwords, two funnel shifts, the third block across the
+    seam, blocks behind the packet's last masked to zero -- against one block at a time, at every bit alignment, with symbol
+    errors; and where the 40 bits go: byte 5 n of the packed payload."""
+    rng = np.random.default_rng(_libs.seed(74))
+    for trial in range(200):
+        n_blocks = int(rng.integers(1, 30))
+        start = int(rng.integers(0, 97))
+        data = rng.integers(0, 2, 10 * n_blocks, dtype=np.uint8)
+        coded = synth.fec23_encode(data) if hasattr(synth, "fec23_encode") else None
+        if coded is None:
+            coded = np.concatenate([np.concatenate([data[10 * b:10 * b + 10], _parity(data[10 * b:10 * b + 10])]) for b in range(n_blocks)])
+        stream = np.concatenate([rng.integers(0, 2, start, dtype=np.uint8), coded, rng.integers(0, 2, 200, dtype=np.uint8)])
+        for _ in range(int(rng.integers(0, 4))):
+            stream[start + int(rng.integers(0, 15 * n_blocks))] ^= 1
+        packed, any_bad = 0, False
+        for n in range((n_blocks + 3) // 4):
+            have = min(4, n_blocks - 4 * n)
+            got, bad = wm.fec23_quad(stream, start + 60 * n, have)
+            any_bad |= bad
+            packed |= got << (8 * 5 * n)                      # byte 5 n
+        want, want_bad = 0, False
+        for b in range(n_blocks):
+            ok, d = wm._fec23_block(stream[start + 15 * b:start + 15 * b + 15])
+            want_bad |= not ok
+            want |= wm._int_of(d) << (10 * b)
+        assert any_bad == want_bad, trial
+        assert packed == want, trial
+
+
+def _parity(d10):
+    par = 0
+    for i in range(10):
+        if d10[i]:
+            par ^= wm._F23[i]
+    return np.array([(par >> k) & 1 for k in range(5)], dtype=np.uint8)
