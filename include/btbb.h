@@ -62,6 +62,10 @@
 extern "C"
 {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the names declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct btbb_packet btbb_packet;      /* btbb.h:63 */
 typedef struct btbb_piconet btbb_piconet;    /* btbb.h:161 */
@@ -209,6 +213,9 @@ int btbb_pcap_append_packet(btbb_pcap_handle *h, const uint64_t ns,      /* btbb
 			    const btbb_packet *pkt);
 int btbb_pcap_close(btbb_pcap_handle *h);                            /* btbb.h:270 */
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 } // __cplusplus defined.
 #endif

@@ -32,6 +32,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the names declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BTBBX_OK            0
 #define BTBBX_E_NODEVICE   -2   /* no usable HIP device / runtime error (see btbbx_last_error) */
@@ -185,9 +189,9 @@ int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uin
 				 uint64_t search_bits, void *d_scratch, size_t scratch_bytes, void *hip_stream);
 /* btbbx_scan_device with the list coming back in (stream, offset) order: the scan kernels count every record they write in
  * the bucket the ordering will put it in, so the list is not read again for a histogram.  Arguments as btbbx_scan_device plus
- * the ordering scratch (btbbx_order_hits_scratch_bytes(cap)); cap >= 2; nothing is synchronised.  *d_count must be 0 on
- * entry (the list is built from this call's matches only: records an earlier scan appended are not carried over -- chain
- * scans with btbbx_scan_device and order the whole list once with btbbx_order_hits_device). */
+ * the ordering scratch (btbbx_order_hits_scratch_bytes(cap)); cap >= 2; nothing is synchronised.  The call zeroes
+ * *d_count itself (on hip_stream): the list is built from this call's matches only, records an earlier scan appended
+ * are not carried over -- chain scans with btbbx_scan_device and order the whole list once with btbbx_order_hits_device. */
 int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
 			      uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
 			      uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream);
@@ -278,6 +282,13 @@ int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_t n_words, 
 				     const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
 				     const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t max_length,
 				     btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream);
+/* The call above takes symbol 0 of the buffer for the FIRST symbol of a slot.  A buffer that starts clk_phase symbols
+ * into a slot (0 <= clk_phase < clk_div) is decoded with the clock entry->clkn + (offset + clk_phase) / clk_div: without the
+ * phase, every access code behind the next slot boundary would get a clock one too low and fail its header check. */
+int btbbx_decode_hits_piconet_phase_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+					   const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
+					   const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t clk_phase, uint32_t max_length,
+					   btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream);
 
 /* ---- hop selection and CLK1-27 reversal ------------------------- */
 #define BTBBX_SEQUENCE_LENGTH 134217728u   /* values of CLK1-27, bluetooth_piconet.h:102 */
@@ -326,6 +337,9 @@ void btbbx_hop_reversal_close(btbbx_hop_reversal *h);
 int64_t btbbx_piconet_state(const void *piconet, int field);
 int64_t btbbx_piconet_candidates(const void *piconet, uint32_t *dst, uint64_t cap);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,7 @@ SIGNATURES = {
     "btbbx_decode_hits_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_decode_hits_counted_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_decode_hits_piconet_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "btbbx_decode_hits_piconet_phase_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "btbbx_uap_table_device": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "btbbx_hop_cfg_init": (None, [_vp, _u32, _vp]),
     "btbbx_hop_sequence_device": (C.c_int, [_vp, _u64, _u64, _vp, _vp]),

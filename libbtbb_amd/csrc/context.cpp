@@ -395,8 +395,14 @@ static int upload_tables(int max_ac_errors)
 		binom = binom * (uint64_t)(58 - k + 1) / (uint64_t)k;
 		entries += binom;
 	}
+	// Slots: at least twice the patterns (open addressing, linear probing), and sixteen times while that stays within 2^20
+	// slots (8 MiB).  The exact check of the LAP_ANY scan looks up sixty candidates at a time, two thirds of them false ones
+	// that probe until they meet an empty slot: the batch waits for its LONGEST probe chain, every probe a dependent round trip
+	// to the L2 -- at a load factor of 0.42 (two errors, 4096 slots) six to eight of them, at 0.03 one or two.
 	int bits = 12;
 	while ((1ULL << bits) < 2 * entries + 16)
+		bits++;
+	while (bits < 20 && (1ULL << bits) < 16 * entries)
 		bits++;
 	MapBuilder mb;
 	mb.slots.assign(1ULL << bits, HSLOT_EMPTY);

@@ -17,8 +17,9 @@ static void le_absent(const char *symbol)
 	abort();
 }
 
-#define LE_ABSENT(ret, name, args) extern "C" ret name args { le_absent(#name); return (ret)0; }
-#define LE_ABSENT_VOID(name, args) extern "C" void name args { le_absent(#name); }
+#define LE_EXPORT __attribute__((visibility("default")))
+#define LE_ABSENT(ret, name, args) extern "C" LE_EXPORT ret name args { le_absent(#name); return (ret)0; }
+#define LE_ABSENT_VOID(name, args) extern "C" LE_EXPORT void name args { le_absent(#name); }
 
 struct lell_packet;
 struct lell_pcapng_handle;

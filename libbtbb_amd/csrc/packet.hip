@@ -2106,7 +2106,14 @@ __device__ __forceinline__ void long_payloads(dhl_u64_t *stg, dhl_u64_t *lst, ui
 				d3 ^= m3 & 0x3ffu;
 				if (on) {
 					const uint32_t byte = 5u * n, d = 2u * DHL_PB + 4u * gbase + (byte >> 2);
-					const uint64_t v = ((uint64_t)(d3 >> 2) << 32 | (d0 | d1 << 10 | d2 << 20 | d3 << 30)) << (8u * (byte & 3u));
+					// Bits behind payload_length never leave the group's packed area: at 128 bytes (1024 bits = exactly the sixteen
+					// words of a group of eight lanes) the six spare bits of block 102 would otherwise be ORed into word 0 of the next
+					// group's packet -- non-zero whenever that block is mis-corrected or the packet is noise.
+					const uint32_t room = nbits - 40u * n;                  // > 0: 4 n < nblocks = ceil(nbits / 10)
+					uint64_t dv = (uint64_t)(d3 >> 2) << 32 | (d0 | d1 << 10 | d2 << 20 | d3 << 30);
+					if (room < 40u)
+						dv &= (1ULL << room) - 1;
+					const uint64_t v = dv << (8u * (byte & 3u));
 					__hip_atomic_fetch_or(lst32 + d, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 					__hip_atomic_fetch_or(lst32 + d + 1, (uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				}
@@ -2603,8 +2610,10 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		} else {
 			// a capture of one piconet: every packet enters with the same state, its clock follows from where it was found
 			// (CLK1-27 advances once per clk_div symbols: 625 at 1 Msym/s)
+			// (one_in.length = the symbols of the current slot that had already passed at the buffer's first symbol)
 			pi = one_in;
-			pi.clkn = one_in.clkn + (h.offset >> 32 ? (uint32_t)(h.offset / clk_div) : (uint32_t)h.offset / clk_div);
+			const uint64_t since = h.offset + one_in.length;
+			pi.clkn = one_in.clkn + (since >> 32 ? (uint32_t)(since / clk_div) : (uint32_t)since / clk_div);
 		}
 	}
 	pi.length = len;
@@ -3393,20 +3402,32 @@ extern "C" int btbbx_decode_hits_counted_device(const uint64_t *d_words, uint64_
 // advances once per 625 symbols at 1 Msym/s, so a receiver that knows the clock at the first symbol of its buffer knows
 // it for every access code the scan found in it.  The list's length is read from HBM as above (d_count may be NULL:
 // then `cap` records are decoded).
-extern "C" int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
-						const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
-						const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t max_length,
-						btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
+extern "C" int btbbx_decode_hits_piconet_phase_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+						      const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
+						      const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t clk_phase, uint32_t max_length,
+						      btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
 {
 	int rc = ctx_require();
 	if (rc)
 		return rc;
 	if (!cap)
 		return BTBBX_OK;
-	if (!d_words || !d_hits || !entry || !d_out || !clk_div) {
-		set_error("btbbx_decode_hits_piconet_device: null pointer or clk_div = 0");
+	if (!d_words || !d_hits || !entry || !d_out || !clk_div || clk_phase >= clk_div) {
+		set_error("btbbx_decode_hits_piconet_device: null pointer, clk_div = 0 or clk_phase >= clk_div");
 		return BTBBX_E_ARG;
 	}
-	return launch_decode_hits(d_words, n_words, pitch_words, d_hits, nullptr, cap, d_count, max_length, d_out, d_lengths, *entry, clk_div,
+	btbbx_pkt_in one = *entry;
+	one.length = clk_phase;                     // (the kernel takes the captured length from the stream, the field carries the phase)
+	return launch_decode_hits(d_words, n_words, pitch_words, d_hits, nullptr, cap, d_count, max_length, d_out, d_lengths, one, clk_div,
 				  (hipStream_t)hip_stream);
+}
+
+// ... for a buffer whose first symbol is the first symbol of a slot (clk_phase 0)
+extern "C" int btbbx_decode_hits_piconet_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+						const btbbx_hit *d_hits, const uint32_t *d_count, uint32_t cap,
+						const btbbx_pkt_in *entry, uint32_t clk_div, uint32_t max_length,
+						btbbx_pkt_out *d_out, uint32_t *d_lengths, void *hip_stream)
+{
+	return btbbx_decode_hits_piconet_phase_device(d_words, n_words, pitch_words, d_hits, d_count, cap, entry, clk_div, 0, max_length,
+						      d_out, d_lengths, hip_stream);
 }

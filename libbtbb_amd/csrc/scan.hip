@@ -719,7 +719,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #define SLIDE_WAVES_PER_EU (SLIDE_WGS * SLIDE_THREADS / 256)
 #endif
 #ifndef SLIDE_PREFETCH
-#define SLIDE_PREFETCH 1                   // next tiles loaded while these are worked on (0: 8 VGPRs less, same time at 6 waves per SIMD)
+#define SLIDE_PREFETCH 0                   // 1: next tiles loaded while these are worked on (8 VGPRs more; round 5: 3.38 against 3.35 ms without)
 #endif
 #ifndef SLIDE_SINGLE
 #define SLIDE_SINGLE 1                     // fast path for the event "one lane of the wave holds a candidate" (1 % of the launch)
@@ -737,6 +737,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #endif
 #ifndef SLIDE_SPARSE_TAIL
 #define SLIDE_SPARSE_TAIL 1                // passes behind the fixed ones skip chains that are empty wave-wide
+#endif
+#ifndef SLIDE_RUN
+#define SLIDE_RUN 1                        // chains as shift registers: the survivor in hand sits at bit 0 of its mask and of its check bits
+#endif
+#ifndef SLIDE_PROBE
+#define SLIDE_PROBE 0
+#endif
+#ifndef SLIDE_ABLATE
+#define SLIDE_ABLATE 0
 #endif
 #ifndef SLIDE_DRAIN_AT
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
@@ -857,13 +866,17 @@ void scan_slide_kernel(ScanArgs a)
 		pend += c;
 	};
 	auto drain = [&](uint32_t n) {               // the n <= 64 oldest ring entries through the exact rule
+#if SLIDE_ABLATE == 3                            // timing only: candidates are queued but never verified
+		q_head += n;
+		return;
+#endif
 		bool hit = false;
 		uint32_t stream = 0, lap = 0, nerr = 0;
 		uint64_t offset = 0;
 		if (lane < n) {
 			const u32x4 rec = lds_ld4(ring_off + CAND_BYTES * ((q_head + lane) & (RING - 1)));
 			const uint32_t code = rec.x;
-			const uint64_t w = ((uint64_t)rec.z << 32) | rec.y;
+			const uint64_t w = ((uint64_t)alignbit(rec.w, rec.z, code) << 32) | alignbit(rec.z, rec.y, code);   // (shift = the low five bits)
 			offset = code_word(code, stream) * 64 + (code & 63);
 			hit = verify_lap_any<false>(a, w, lap, nerr);
 		}
@@ -953,8 +966,24 @@ void scan_slide_kernel(ScanArgs a)
 			const uint32_t last = slide32_low_uniform(s2, s3);
 			const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
 			c[u][2] = lane == 63 ? last : next;
+#if SLIDE_ABLATE == 4                            // timing only: no filter -- survivor masks of the same density and raw dwords as check bits
+			m[u][0] = d[u][0] & d[u][1] & d[u][2] & validA;
+			m[u][1] = d[u][1] & d[u][2] & d[u][3] & validB;
+			c[u][0] = d[u][0]; c[u][1] = d[u][1]; c[u][2] = d[u][2];
+#endif
 		}
 
+#if SLIDE_RUN
+		// A chain (32 offsets) as a pair of shift registers: its survivor mask and the 50 check bits its indices are cut from,
+		// both moved down to the survivor in hand (one v_lshrrev_b64 instead of a funnel shift per survivor, no "m - 1").  Bit
+		// 63 is a marker: its distance from the top is the offset the chain stands at, which only a candidate event asks for.
+		uint64_t C[TILES][2];
+#pragma unroll
+		for (int u = 0; u < TILES; u++)
+#pragma unroll
+			for (int h = 0; h < 2; h++)
+				C[u][h] = ((uint64_t)(c[u][h + 1] | 0x80000000u) << 32) | c[u][h];
+#endif
 		struct Stage { uint32_t p[TILES][2], v[TILES][2], bw[TILES][2], live[TILES][2]; };
 		auto any_left = [&]() {
 			uint32_t any = 0;
@@ -979,10 +1008,17 @@ void scan_slide_kernel(ScanArgs a)
 					if (cand) {
 						uint32_t lane6 = lane << 6;
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
-						const uint32_t code = ((it + u) << 12) | lane6 | (h << 5) | (g.p[u][h] & 31);
-						const uint32_t wlo = alignbit(d[u][h + 1], d[u][h], g.p[u][h]);
-						const uint32_t whi = alignbit(d[u][h + 2], d[u][h + 1], g.p[u][h]);
-						const u32x4 rec = {code, wlo, whi, 0u};
+#if SLIDE_RUN
+						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
+						uint32_t pos;
+						asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
+#else
+						const uint32_t pos = g.p[u][h] & 31;
+#endif
+						// the record carries the three stream dwords the window lies in; the drain cuts it out (for sixty
+						// candidates at once) instead of this branch (for one)
+						const uint32_t code = pos | lane6 | (((it + u) << 12) | (h << 5));
+						const u32x4 rec = {code, d[u][h], d[u][h + 1], d[u][h + 2]};
 						if (SLIDE_SINGLE && (cm & (cm - 1)) == 0 && room) {
 							// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
 							lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
@@ -995,6 +1031,7 @@ void scan_slide_kernel(ScanArgs a)
 								uint32_t stream, lap, nerr, cold = code;
 								asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
 								const uint64_t word = code_word(cold, stream);
+								const uint32_t wlo = alignbit(rec.z, rec.y, pos), whi = alignbit(rec.w, rec.z, pos);
 								if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
 									emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
 							}
@@ -1008,15 +1045,39 @@ void scan_slide_kernel(ScanArgs a)
 		// an idle lane whose junk index happens to be in the set triggers an event in EVERY pass.  profiles/r03_ab.)
 		auto pass = [&]() {
 			Stage g;
+#if SLIDE_PROBE
+			uint32_t probe_junk = lane;
+			const uint32_t probe_addr_ = lane << 2;
+			asm volatile("" : "+v"(probe_junk));
+#endif
 #pragma unroll
 			for (int u = 0; u < TILES; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {       // next survivor of every chain: index, set read in flight
+#if SLIDE_RUN
+					const uint32_t p = lowest_bit(m[u][h]);   // ~0 for an empty chain: it shifts itself out, bit 0 stays 0
+					m[u][h] >>= p & 31;
+					C[u][h] >>= p & 63;
+					g.v[u][h] = (uint32_t)C[u][h];
+					g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
+					g.live[u][h] = m[u][h];                   // bit 0: this lane has a survivor
+					m[u][h] &= ~1u;
+#if SLIDE_PROBE == 1                             // marginal cost of one full-rate vector instruction per chain and pass
+					asm volatile("v_xor_b32 %0, %0, %1" : "+v"(probe_junk) : "v"(g.v[u][h]));
+#elif SLIDE_PROBE == 2                           // ... of one funnel shift
+					asm volatile("v_alignbit_b32 %0, %0, %1, %1" : "+v"(probe_junk) : "v"(g.v[u][h]));
+#elif SLIDE_PROBE == 3                           // ... of one more LDS read (conflict-free, its own address register)
+					probe_junk ^= lds_ld(probe_addr_);
+#elif SLIDE_PROBE == 4                           // ... of one more LDS read at the survivor's own (random) address
+					probe_junk ^= lds_ld(((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2)) ^ 4u);
+#endif
+#else
 					g.p[u][h] = lowest_bit(m[u][h]);
 					g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
 					g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
 					g.live[u][h] = m[u][h] >> g.p[u][h];      // bit 0: this lane has a survivor (p = ~0 for m == 0)
 					m[u][h] &= m[u][h] - 1;
+#endif
 				}
 			uint32_t anybit = 0, bit[TILES][2];
 #pragma unroll
@@ -1026,8 +1087,15 @@ void scan_slide_kernel(ScanArgs a)
 					bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
 					anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 				}
+#if SLIDE_PROBE
+			asm volatile("" : : "v"(probe_junk));
+#endif
+#if SLIDE_ABLATE == 1                            // timing only (finds nothing): what the candidate events and everything behind them cost
+			asm volatile("" : : "v"(anybit));
+#else
 			if (__ballot(anybit & 1))                // some lane of the wave holds a candidate (half of the passes)
 				events(g, bit);
+#endif
 		};
 		// Behind the fixed passes a handful of the wave's 2 * TILES * 64 chains still hold survivors (0.8 % have seven or more):
 		// a pass then looks at the chains one by one and skips those that are empty wave-wide (the same ballots are the
@@ -1047,11 +1115,21 @@ void scan_slide_kernel(ScanArgs a)
 						if (!__ballot(m[u][h] != 0))
 							continue;
 						any = true;
+#if SLIDE_RUN
+						const uint32_t p = lowest_bit(m[u][h]);
+						m[u][h] >>= p & 31;
+						C[u][h] >>= p & 63;
+						g.v[u][h] = (uint32_t)C[u][h];
+						g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
+						g.live[u][h] = m[u][h];
+						m[u][h] &= ~1u;
+#else
 						g.p[u][h] = lowest_bit(m[u][h]);
 						g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
 						g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
 						g.live[u][h] = m[u][h] >> g.p[u][h];
 						m[u][h] &= m[u][h] - 1;
+#endif
 						bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
 						anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 					}
@@ -1069,7 +1147,15 @@ void scan_slide_kernel(ScanArgs a)
 #endif
 		PROF_MARK(0);
 		uint32_t pass_no = 1;
+#if SLIDE_ABLATE == 2                            // timing only: loads, barker filter and check stream alone
+#pragma unroll
+		for (int u = 0; u < TILES; u++)
+			asm volatile("" : : "v"(m[u][0]), "v"(m[u][1]), "v"(c[u][0]), "v"(c[u][1]), "v"(c[u][2]));
+		if (true) {
+		} else if (!DENSE) {
+#else
 		if (!DENSE) {
+#endif
 			__builtin_amdgcn_s_setprio(PRIO_LOOP);
 #pragma unroll 1
 			for (int k = 0; k < SLIDE_FIXED; k++) { // practically every trip needs these (TILES * 128 chains of ~4 survivors)

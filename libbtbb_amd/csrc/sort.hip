@@ -607,6 +607,9 @@ extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_wor
 	hipStream_t stream = (hipStream_t)hip_stream;
 	char *base = (char *)d_scratch;
 	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
+	// the list is built from this call's matches only (they are parked in the scratch, not appended to d_hits): the counter
+	// starts at zero whatever the caller left in it -- a stale count would send uninitialised parked records through the ordering
+	HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
 	const uint32_t shift = order_shift(n_streams, search_bits, L.nb_log2);
 	// the scan leaves its records in the scratch (and counts each in its bucket); the ordering puts them into d_hits
 	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, (btbbx_hit *)(base + L.parked), cap, d_count,

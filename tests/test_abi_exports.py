@@ -39,6 +39,24 @@ def test_every_declared_symbol_is_exported(lib, header):
         assert getattr(lib, n) is not None
 
 
+def test_nothing_but_the_abi_is_exported():
+    """The library takes over libbtbb's SONAME, so it exports exactly its ABI: every defined dynamic symbol is a name one
+    of the two headers declares (or a lell_* stub of the reference's header) -- no kernel handles, launchers, table
+    builders or template instantiations (-fvisibility=hidden + csrc/exports.map).  Both builds."""
+    import libbtbb_amd
+    allowed = set(declared("btbb.h")) | set(declared("btbbx.h"))
+    for path in (libbtbb_amd.LIB_PATH, os.path.join(os.path.dirname(libbtbb_amd.LIB_PATH), "libbtbb_amd_asan.so")):
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+        if "asan" in os.path.basename(path):            # the sanitizer runtime interposes a few names of its own
+            names = [n for n in names if not n.startswith(("__asan", "__ubsan", "__sanitizer", "__odr_asan", "__lsan"))]
+        extra = [n for n in names if n not in allowed and not n.startswith("lell_")]
+        assert not extra, (path, extra[:10])
+        assert len([n for n in names if n in allowed]) == len(allowed), sorted(allowed - set(names))[:10]
+
+
 def test_soname():
     import libbtbb_amd
     out = subprocess.run(["readelf", "-d", libbtbb_amd.LIB_PATH], capture_output=True, text=True).stdout

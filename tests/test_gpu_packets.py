@@ -295,6 +295,62 @@ def test_long_payloads_leave_through_the_wave_phase():
     assert sum(v for (t, r), v in seen.items() if t in LONG_TYPES and r == 2) >= 10, seen
 
 
+def test_dm5_of_128_bytes_keeps_its_spare_block_bits_to_itself():
+    """A DM5 with payload_length 128 (body 124 + header 2 + CRC 2) fills exactly the sixteen packed words of a group of eight
+    lanes; its 103rd FEC 2/3 block carries six bits behind the payload.  When that block is hit by two symbol errors
+    (mis-corrected or failing), those bits are not zero -- they must not reach word 0 of the packet the next group of the
+    wave decodes (round-4 advisor finding).  Every packet of the batch has this length, every other one has the errors; the
+    clean neighbours must come out with their CRC intact and every payload bit equal to the oracle's."""
+    orc = _libs.oracle()
+    rng = np.random.default_rng(_libs.seed(87))
+    n_streams, n_words, per_stream = 4, 1 << 14, 96
+    sym = rng.integers(0, 2, (n_streams, n_words * 64), dtype=np.uint8)
+    rows = []
+    for st in range(n_streams):
+        pos = 100 + st
+        for i in range(per_stream):
+            lap, uap, clk6 = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 256)), int(rng.integers(0, 64))
+            p = synth.build_packet(lap, uap, clk6, synth.TYPE_DM5, lt_addr=1 + i % 7, body=rng.integers(0, 256, 124, dtype=np.uint8).tobytes()).copy()
+            # payload symbols start at 122 (sync word 64 + trailer 4 + header 54); block 102 = symbols 122 + 15 * 102 .. + 14, its data
+            # bits 4 .. 9 lie behind payload_length
+            hurt = (i + st) % 2 == 1
+            if hurt:
+                b0 = 122 + 15 * 102
+                assert len(p) == b0 + 15
+                k = rng.choice(np.arange(4, 15), 2, replace=False)
+                p[b0 + k] ^= 1
+            assert pos + len(p) + 400 < n_words * 64
+            sym[st, pos:pos + len(p)] = p
+            rows.append((st, pos, dict(uap=uap, clk6=clk6, hurt=hurt)))
+            pos += len(p) + int(rng.integers(3, 90))
+    hits = np.zeros(len(rows), bt.HIT_DTYPE)
+    hits["stream"] = [r[0] for r in rows]
+    hits["offset"] = [r[1] for r in rows]
+    pin = np.zeros(len(rows), bt.PKTIN_DTYPE)
+    pin["clkn"] = [r[2]["clk6"] for r in rows]
+    pin["uap"] = [r[2]["uap"] for r in rows]
+    pin["flags"] = (1 << 0) | (1 << 2) | (1 << 4)
+    words = np.stack([synth.pack_bits(sym[st]) for st in range(n_streams)])
+    out, lens = bt.run_decode_hits(words, hits, pin)
+    two_step, _ = bt.run_decode_hits(words, hits, pin, via_gather=True)
+    clean_ok = spoiled = 0
+    for i, (st, off, meta) in enumerate(rows):
+        assert out[i].tobytes() == two_step[i].tobytes(), (i, meta)
+        s = np.ascontiguousarray(sym[st, off:off + int(lens[i])])
+        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        o = out[i]
+        assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, meta)
+        assert h and int(o["payload_length"]) == stt["payload_length"] == 128, (i, meta)
+        bits = synth.unpack_bits(np.ascontiguousarray(o["payload"]), 2744)
+        assert (bits == stt["payload"]).all(), (i, meta, np.nonzero(bits != stt["payload"])[0][:8])
+        if meta["hurt"]:
+            spoiled += r != 10
+        else:
+            assert r == 10, (i, meta)
+            clean_ok += 1
+    assert clean_ok >= 150 and spoiled >= 20, (clean_ok, spoiled)
+
+
 def test_ev4_ev5_payloads_leave_through_the_wave_phase():
     """EV4 / EV5 payloads in HBM are decoded by lane groups too (ev_payloads in packet.hip: the byte count whose CRC register
     is zero comes from a prefix over the lanes, not from a walk): byte-identical to cutting the packets out and decoding

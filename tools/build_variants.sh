@@ -22,11 +22,11 @@ while [ $# -gt 0 ]; do
     objs=""; skip=""
     for src in $srcs; do
       o=$tmp/$(basename "${src%.*}").o
-      $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -x hip -c "$src" -o "$o"
+      $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $flags -x hip -c "$src" -o "$o"
       objs="$objs $o"; skip="$skip|$(basename "${src%.*}").o"
     done
     rest=$(ls build/*.o | grep -v "/asan_" | grep -Ev "/(${skip#|})$")
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libbtbb.so.1 $rest $objs -o ../variants/$name.so
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libbtbb.so.1 -Wl,--version-script=exports.map $rest $objs -o ../variants/$name.so
     rm -rf "$tmp"
     echo "built $name"
   ) &

@@ -107,6 +107,66 @@ KERNEL(k_or_inline, OP8_LIT("v_or_b32", "1"))
 KERNEL(k_lshr_sdwa, OP8_SDWA("v_lshrrev_b32_sdwa"))
 KERNEL(k_and_sdwa, OP8_SDWA("v_and_b32_sdwa"))
 
+
+// ---- source-operand VGPR banks (round 5): does it matter whether two or three sources of one instruction sit in the
+// same register bank (register number mod 4)?  Eight independent instructions per body on fixed registers: sources
+// v8..v19, destinations v20..v27, no dependence between them, so the figure is pure issue rate.
+#define BANK_KERNEL(name, i0, i1, i2, i3, i4, i5, i6, i7)                                  \
+__global__ __launch_bounds__(1024) void name(uint32_t *out, uint32_t seed)                  \
+{                                                                                           \
+	uint32_t acc = threadIdx.x ^ seed;                                                      \
+	asm volatile("v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n" \
+		     "v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n v_mov_b32 v14, %0\n v_mov_b32 v15, %0\n"   \
+		     "v_mov_b32 v16, %0\n v_mov_b32 v17, %0\n v_mov_b32 v18, %0\n v_mov_b32 v19, %0\n"   \
+		     : : "v"(acc) : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19"); \
+	for (int i = 0; i < ITERS; i++) {                                                       \
+		_Pragma("unroll") for (int u = 0; u < UNROLL / 8; u++)                              \
+			asm volatile(i0 "\n" i1 "\n" i2 "\n" i3 "\n" i4 "\n" i5 "\n" i6 "\n" i7 "\n" : : :    \
+				     "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+				     "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");                     \
+	}                                                                                       \
+	asm volatile("v_xor_b32 %0, %0, v20\n v_xor_b32 %0, %0, v27" : "+v"(acc) : : "v20", "v27"); \
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                       \
+}
+#define B3(op, d, a, b, c, tail) op " v" #d ", v" #a ", v" #b ", v" #c tail
+#define B2(op, d, a, b) op " v" #d ", v" #a ", v" #b
+// three sources in three banks / two in one bank / all three in one bank
+BANK_KERNEL(k_bitop3_b012, B3("v_bitop3_b32", 20, 8, 9, 10, " bitop3:0x96"), B3("v_bitop3_b32", 21, 9, 10, 11, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 22, 12, 13, 14, " bitop3:0x96"), B3("v_bitop3_b32", 23, 13, 14, 15, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 24, 16, 17, 18, " bitop3:0x96"), B3("v_bitop3_b32", 25, 17, 18, 19, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 26, 10, 11, 12, " bitop3:0x96"), B3("v_bitop3_b32", 27, 14, 15, 16, " bitop3:0x96"))
+BANK_KERNEL(k_bitop3_b001, B3("v_bitop3_b32", 20, 8, 12, 9, " bitop3:0x96"), B3("v_bitop3_b32", 21, 9, 13, 10, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 22, 10, 14, 11, " bitop3:0x96"), B3("v_bitop3_b32", 23, 11, 15, 12, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 24, 12, 16, 13, " bitop3:0x96"), B3("v_bitop3_b32", 25, 13, 17, 14, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 26, 14, 18, 15, " bitop3:0x96"), B3("v_bitop3_b32", 27, 15, 19, 16, " bitop3:0x96"))
+BANK_KERNEL(k_bitop3_b000, B3("v_bitop3_b32", 20, 8, 12, 16, " bitop3:0x96"), B3("v_bitop3_b32", 21, 9, 13, 17, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 22, 10, 14, 18, " bitop3:0x96"), B3("v_bitop3_b32", 23, 11, 15, 19, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 24, 8, 12, 16, " bitop3:0x96"), B3("v_bitop3_b32", 25, 9, 13, 17, " bitop3:0x96"),
+	    B3("v_bitop3_b32", 26, 10, 14, 18, " bitop3:0x96"), B3("v_bitop3_b32", 27, 11, 15, 19, " bitop3:0x96"))
+BANK_KERNEL(k_xor_b01, B2("v_xor_b32", 20, 8, 9), B2("v_xor_b32", 21, 9, 10), B2("v_xor_b32", 22, 10, 11), B2("v_xor_b32", 23, 11, 12),
+	    B2("v_xor_b32", 24, 12, 13), B2("v_xor_b32", 25, 13, 14), B2("v_xor_b32", 26, 14, 15), B2("v_xor_b32", 27, 15, 16))
+BANK_KERNEL(k_xor_b00, B2("v_xor_b32", 20, 8, 12), B2("v_xor_b32", 21, 9, 13), B2("v_xor_b32", 22, 10, 14), B2("v_xor_b32", 23, 11, 15),
+	    B2("v_xor_b32", 24, 12, 16), B2("v_xor_b32", 25, 13, 17), B2("v_xor_b32", 26, 14, 18), B2("v_xor_b32", 27, 15, 19))
+BANK_KERNEL(k_alignbit_b012, B3("v_alignbit_b32", 20, 8, 9, 10, ""), B3("v_alignbit_b32", 21, 9, 10, 11, ""),
+	    B3("v_alignbit_b32", 22, 12, 13, 14, ""), B3("v_alignbit_b32", 23, 13, 14, 15, ""),
+	    B3("v_alignbit_b32", 24, 16, 17, 18, ""), B3("v_alignbit_b32", 25, 17, 18, 19, ""),
+	    B3("v_alignbit_b32", 26, 10, 11, 12, ""), B3("v_alignbit_b32", 27, 14, 15, 16, ""))
+BANK_KERNEL(k_alignbit_b000, B3("v_alignbit_b32", 20, 8, 12, 16, ""), B3("v_alignbit_b32", 21, 9, 13, 17, ""),
+	    B3("v_alignbit_b32", 22, 10, 14, 18, ""), B3("v_alignbit_b32", 23, 11, 15, 19, ""),
+	    B3("v_alignbit_b32", 24, 8, 12, 16, ""), B3("v_alignbit_b32", 25, 9, 13, 17, ""),
+	    B3("v_alignbit_b32", 26, 10, 14, 18, ""), B3("v_alignbit_b32", 27, 11, 15, 19, ""))
+// a funnel shift by a constant reads two registers: same bank / different banks
+BANK_KERNEL(k_alignbitc_b01, "v_alignbit_b32 v20, v8, v9, 7", "v_alignbit_b32 v21, v9, v10, 7", "v_alignbit_b32 v22, v10, v11, 7",
+	    "v_alignbit_b32 v23, v11, v12, 7", "v_alignbit_b32 v24, v12, v13, 7", "v_alignbit_b32 v25, v13, v14, 7",
+	    "v_alignbit_b32 v26, v14, v15, 7", "v_alignbit_b32 v27, v15, v16, 7")
+BANK_KERNEL(k_alignbitc_b00, "v_alignbit_b32 v20, v8, v12, 7", "v_alignbit_b32 v21, v9, v13, 7", "v_alignbit_b32 v22, v10, v14, 7",
+	    "v_alignbit_b32 v23, v11, v15, 7", "v_alignbit_b32 v24, v12, v16, 7", "v_alignbit_b32 v25, v13, v17, 7",
+	    "v_alignbit_b32 v26, v14, v18, 7", "v_alignbit_b32 v27, v15, v19, 7")
+// the running-shift pass of round 5: a 64-bit shift by a per-lane amount
+BANK_KERNEL(k_lshr64_reg, "v_lshrrev_b64 v[20:21], v8, v[12:13]", "v_lshrrev_b64 v[22:23], v9, v[14:15]", "v_lshrrev_b64 v[24:25], v10, v[16:17]",
+	    "v_lshrrev_b64 v[26:27], v11, v[18:19]", "v_lshrrev_b64 v[20:21], v8, v[12:13]", "v_lshrrev_b64 v[22:23], v9, v[14:15]",
+	    "v_lshrrev_b64 v[24:25], v10, v[16:17]", "v_lshrrev_b64 v[26:27], v11, v[18:19]")
+
 template <typename K>
 static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
 {
@@ -124,7 +184,7 @@ static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
 	hipEventElapsedTime(&ms, e0, e1);
 	double wave_instrs_per_simd = (double)ITERS * UNROLL * waves_per_simd;      // each SIMD hosts waves_per_simd waves
 	double cycles = ms * 1e-3 * 2.4e9;
-	printf("%-14s waves/SIMD=%d  %.3f ms  %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n",
+	printf("%-26s waves/SIMD=%d  %.3f ms  %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n",
 	       name, waves_per_simd, ms, cycles / wave_instrs_per_simd);
 }
 
@@ -165,6 +225,16 @@ int main()
 		run("v_mbcnt_lo", k_mbcnt, d_out, w);
 		run("v_bfm_b32", k_bfm, d_out, w);
 		run("v_mov_dpp", k_movdpp, d_out, w);
+		run("bitop3 banks 0,1,2", k_bitop3_b012, d_out, w);
+		run("bitop3 banks 0,0,1", k_bitop3_b001, d_out, w);
+		run("bitop3 banks 0,0,0", k_bitop3_b000, d_out, w);
+		run("xor banks 0,1", k_xor_b01, d_out, w);
+		run("xor banks 0,0", k_xor_b00, d_out, w);
+		run("alignbit banks 0,1,2", k_alignbit_b012, d_out, w);
+		run("alignbit banks 0,0,0", k_alignbit_b000, d_out, w);
+		run("alignbit const banks 0,1", k_alignbitc_b01, d_out, w);
+		run("alignbit const banks 0,0", k_alignbitc_b00, d_out, w);
+		run("lshrrev_b64 by vgpr", k_lshr64_reg, d_out, w);
 	}
 	return 0;
 }
