@@ -133,6 +133,19 @@ int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_
 		      btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
 		      void *hip_stream);
 
+/* The two packed layouts a capture can have in HBM.  BTBBX_FMT_PACKED: LSB-first words (above).  BTBBX_FMT_PACKED_MSB: 8 symbols
+ * per byte with the FIRST symbol in bit 7 -- what a dongle's bit-packed dumps look like.  The scan kernels take
+ * either: MSB-first dwords are turned round in registers as they are loaded, the capture is not rewritten.  (The packet
+ * decoders read LSB-first words: convert once with btbbx_msb_to_lsb_device before handing hits of an MSB capture to them.) */
+#define BTBBX_FMT_PACKED  0      /* LSB-first packed words (const uint64_t *) */
+#define BTBBX_FMT_SYMBOLS 1      /* one 0/1 symbol per byte (const char *), packed on the GPU (streaming ingest only) */
+#define BTBBX_FMT_PACKED_MSB 2   /* 8 symbols per byte, first symbol in bit 7 */
+int btbbx_scan_device_fmt(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+			  uint32_t n_streams, uint64_t search_bits,
+			  uint32_t lap, int max_ac_errors, int format,
+			  btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
+			  void *hip_stream);
+
 /* First match only (btbb_find_ac semantics) of ONE stream: *d_first receives
  * (offset << 32 | lap << 8 | ac_errors) of the smallest matching offset, or
  * UINT64_MAX.  search_bits < 2^32.  The caller presets *d_first to UINT64_MAX. */
@@ -195,6 +208,9 @@ int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uin
 int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
 			      uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
 			      uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream);
+int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
+				  uint64_t search_bits, uint32_t lap, int max_ac_errors, int format, btbbx_hit *d_hits, uint32_t cap,
+				  uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream);
 
 /* symbols (one 0/1 byte each, bit 0 is used) -> packed words; n_words_out =
  * ceil(n_symbols / 64), the tail of the last word is zero */
@@ -202,7 +218,8 @@ int btbbx_pack_device(const uint8_t *d_symbols, uint64_t n_symbols, uint64_t *d_
 		      void *hip_stream);
 int btbbx_unpack_device(const uint64_t *d_words, uint64_t n_symbols, uint8_t *d_symbols,
 			void *hip_stream);
-/* bytes holding 8 symbols MSB first (first received symbol in bit 7) -> LSB-first words, in place */
+/* bytes holding 8 symbols MSB first (first received symbol in bit 7) -> LSB-first words, in place (for the packet decoders;
+ * the scans take BTBBX_FMT_PACKED_MSB directly) */
 int btbbx_msb_to_lsb_device(uint64_t *d_words, uint64_t n_words, void *hip_stream);
 
 /* ---- streaming ingest (live captures) ------------------------------ */
@@ -213,9 +230,7 @@ int btbbx_msb_to_lsb_device(uint64_t *d_words, uint64_t n_words, void *hip_strea
  * symbols.  feed() returns the hits of the chunk fed BEFORE this one (the current one is still
  * in flight); flush() waits for and returns the rest. */
 typedef struct btbbx_stream btbbx_stream;
-#define BTBBX_FMT_PACKED  0      /* LSB-first packed words (const uint64_t *) */
-#define BTBBX_FMT_SYMBOLS 1      /* one 0/1 symbol per byte (const char *), packed on the GPU */
-#define BTBBX_FMT_PACKED_MSB 2   /* 8 symbols per byte, first symbol in bit 7; converted on the GPU */
+/* format: BTBBX_FMT_PACKED, BTBBX_FMT_SYMBOLS (packed on the GPU) or BTBBX_FMT_PACKED_MSB (scanned as it is), see above */
 btbbx_stream *btbbx_stream_open(uint32_t lap, int max_ac_errors, uint64_t max_chunk_symbols, int format);
 int64_t btbbx_stream_feed(btbbx_stream *s, const void *data, uint64_t n_symbols, btbbx_hit *hits, uint64_t cap);
 /* zero-copy variant: write the next chunk straight into the pinned staging buffer returned by

@@ -96,6 +96,7 @@ SIGNATURES = {
     "btbbx_memset": (C.c_int, [_vp, C.c_int, C.c_size_t]),
     "btbbx_sync": (C.c_int, [_vp]),
     "btbbx_scan_device": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, _vp, _u32, _vp, _vp]),
+    "btbbx_scan_device_fmt": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, C.c_int, _vp, _u32, _vp, _vp]),
     "btbbx_scan_first_device": (C.c_int, [_vp, _u64, _u64, _u32, C.c_int, _vp, _vp]),
     "btbbx_scan_host": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
     "btbbx_scan_symbols": (C.c_int64, [_vp, _u64, _u64, _u32, C.c_int, _vp, _u64]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "btbbx_order_hits_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _vp]),
     "btbbx_order_scan_hits_device": (C.c_int, [_vp, _vp, _u32, _u32, _u64, _vp, C.c_size_t, _vp]),
     "btbbx_scan_ordered_device": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
+    "btbbx_scan_ordered_device_fmt": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, C.c_int, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),
     "btbbx_pack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_unpack_device": (C.c_int, [_vp, _u64, _vp, _vp]),
     "btbbx_msb_to_lsb_device": (C.c_int, [_vp, _u64, _vp]),

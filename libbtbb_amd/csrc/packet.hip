@@ -222,9 +222,6 @@ int chain_upload(const HostTables &t)
 #define F_CLK6_VALID  (1u << 4)
 #define F_HAS_PAYLOAD (1u << 7)
 #define DHL_MIN_BITS  256              // payloads longer than this leave decode_hits_kernel's lanes for its wave phase (= 64 DH_OUT_WORDS)
-#ifndef DH_LONG_EV
-#define DH_LONG_EV 1                   // EV4 / EV5 payloads go there too (0: their lanes walk them, rounds 1-3)
-#endif
 
 // ---- bit helpers ----------------------------------------------------------------------------
 
@@ -419,7 +416,7 @@ struct PState {
 	bool spoiled = false;    // out is the caller's scratch copy (LDS) and holds a payload the reference would not have written
 	// decode_hits_kernel: a DM / DH payload of more than 256 bits is not walked by its lane; do_DM / do_DH return after
 	// their checks with the bit count here and the wave works it off afterwards, a group of lanes per packet (long_payloads)
-	// (decode_long_kernel); the sixteen bytes that kernel needs to know go straight into def_slot from here
+	// (long_wave, at the end of decode_hits_kernel); the sixteen bytes that phase needs to know go straight into def_slot from here
 	uint4 *def_slot = nullptr;   // where (null: every payload is walked by its lane)
 	uint32_t def_pkt8 = 0;       // the record's index in its workgroup's 256
 	uint32_t def_nbits = 0;      // != 0: deferred
@@ -724,7 +721,7 @@ __device__ __forceinline__ int do_DM(PState &s, uint32_t clock)
 	uint32_t nblocks = (nbits + 9) / 10;
 	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
 		defer_payload(s, clock, (uint32_t)nbits, DHL_DM);
-		return 2;                                           // (replaced by decode_long_kernel's verdict)
+		return 2;                                           // (replaced by the lane-group phase's verdict)
 	}
 	// The reference writes nothing when a block fails.  Into HBM that takes a pass over all blocks first; a scratch copy
 	// is written as the blocks decode and marked as not to be kept when one fails.
@@ -782,7 +779,7 @@ __device__ __forceinline__ int do_DH(PState &s, uint32_t clock)
 		return 1;
 	if (WRITE && s.def_slot && !s.out.l && nbits > DHL_MIN_BITS) {
 		defer_payload(s, clock, (uint32_t)nbits, DHL_DH);
-		return 2;                                           // (replaced by decode_long_kernel's verdict)
+		return 2;                                           // (replaced by the lane-group phase's verdict)
 	}
 	Sink<WRITE> sink(crc_seed(s.uap), s.out);
 	uint32_t idx = wh_start(clock, 18);
@@ -1033,30 +1030,10 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 	return *(volatile __attribute__((address_space(3))) const uint32_t *)p;
 }
 
-#ifndef TL_OPAQUE
-#define TL_OPAQUE 1                     // trials_linear_kernel: no hoisted index arithmetic, FEC loop not unrolled (spills, see fetch)
-#endif
-#ifndef TL_MERGE34
-#define TL_MERGE34 1                    // trials_linear_kernel: type bases per wave in registers, one barrier less per batch
-#endif
-#ifndef TL_LDSNOW
-#define TL_LDSNOW 1                     // trials_linear_kernel reads a_fail through lds_now (0: the volatile generic read of rounds 2-3)
-#endif
-#ifndef TL_THREADS
 #define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
-#endif
 #define TL_PACKETS (TL_THREADS / 16)
-#ifndef TL_WGS_PER_CU
 #define TL_WGS_PER_CU 1
-#endif
 #define TL_TRIALS  (TL_PACKETS * 64)
-// wave priority by phase (only meaningful with more than one workgroup per CU: the phases of ONE workgroup are
-// separated by barriers, its waves are always in the same phase)
-#ifdef TL_PRIO
-#define TL_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define TL_SETPRIO(x) do { } while (0)
-#endif
 #define TL_A_BLOCKS 183                     // DM5: 228 bytes = 1824 bits
 #define TL_A_BYTES  232                     // >= 229, multiple of 4
 #define TL_B_BLOCKS 10                      // DV: 12 bytes
@@ -1073,11 +1050,7 @@ __device__ unsigned long long g_tl_prof[16];
 #define TL_PROF(k) do { } while (0)
 #define TL_PROF_END do { } while (0)
 #endif
-#if TL_LDSNOW
 #define TL_AFAIL(p) lds_now(&a_fail[p])
-#else
-#define TL_AFAIL(p) (*(volatile uint32_t *)&a_fail[p])
-#endif
 __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 							     uint32_t n_packets, btbbx_trial *trials)
 {
@@ -1092,11 +1065,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
 	__shared__ uint32_t type_count[16];
-#if TL_MERGE34
 	__shared__ uint32_t type_base_w[TL_THREADS / 64][16];
-#else
-	__shared__ uint32_t type_base[16];
-#endif
 	// per packet
 	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
 	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];       // ... DV data at 202
@@ -1138,9 +1107,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	auto fetch = [&](uint32_t b) {
 		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
 		uint32_t tv = tid;
-#if TL_OPAQUE
 		asm volatile("" : "+v"(tv));
-#endif
 #pragma unroll
 		for (uint32_t k = 0; k < PER_THREAD; k++) {
 			const uint32_t i = tv + TL_THREADS * k;
@@ -1159,9 +1126,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	auto stage_in = [&](uint32_t b) {
 		const uint32_t f = b * TL_PACKETS, have = b < n_batches ? (n_packets - f < TL_PACKETS ? n_packets - f : TL_PACKETS) : 0;
 		uint32_t tv = tid;
-#if TL_OPAQUE
 		asm volatile("" : "+v"(tv));
-#endif
 #pragma unroll
 		for (uint32_t k = 0; k < PER_THREAD; k++) {
 			const uint32_t i = tv + TL_THREADS * k;
@@ -1187,7 +1152,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 
 	__syncthreads();                                        // this batch is in LDS, the previous batch's results are read
 	TL_PROF(0);
-	TL_SETPRIO(1);
 
 	// 1. try_clock (:1178-1195).  uap_from_hec (:693-705) and the type field are GF(2)-linear in the 18 header
 	// bits and unwhitening XORs a clock-dependent constant onto them, so try_clock(c) = U(header) ^ U(whitening
@@ -1221,9 +1185,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 					atomicMin(&b_fail[p], sub);
 				b10[p][sub] = (uint16_t)d;
 			}
-#if TL_OPAQUE
 #pragma unroll 1
-#endif
 			for (uint32_t k0 = 0; k0 < TL_A_BLOCKS; k0 += 16) {
 				const uint32_t k = k0 + sub;
 				if (k < TL_A_BLOCKS) {
@@ -1346,15 +1308,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(8);
-#if !TL_MERGE34
-	if (tid == 0) {
-		uint32_t run = 0;
-		for (uint32_t t = 0; t < 16; t++) {
-			type_base[t] = run;
-			run += type_count[t];
-		}
-	}
-#endif
 	if (tid >= 64 && tid < 64 + 3 * mine) {
 		const uint32_t p = (tid - 64) / 3, layout = (tid - 64) % 3;
 		const uint32_t r0 = layout == 0 ? 0 : layout == 1 ? 11 : 19;
@@ -1366,7 +1319,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
 		}
 	}
-#if TL_MERGE34
 	// (round 4) no barrier here: the chunk starts above are wanted by the trials, not by the order pass, and where a type's
 	// trials start is worked out by every wave for itself from the sixteen counters (lanes 0 .. 15, a scan in registers)
 	// instead of by thread 0 in sixteen dependent LDS steps behind a barrier of their own
@@ -1384,16 +1336,8 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		for (uint32_t i = tid; i < total; i += TL_THREADS)
 			order[type_base_w[tid >> 6][(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
 	}
-#else
-	__syncthreads();
-	TL_PROF(9);
-	TL_PROF(3);
-	for (uint32_t i = tid; i < total; i += TL_THREADS)
-		order[type_base[(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
-#endif
 	__syncthreads();
 	TL_PROF(4);
-	TL_SETPRIO(3);
 
 	// 3. crc_check (:708-769) in type order
 	for (uint32_t kk = tid; kk < total; kk += TL_THREADS) {
@@ -1543,7 +1487,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	}
 	__syncthreads();
 	TL_PROF(5);
-	TL_SETPRIO(0);
 	// The next batch moves in and the one after that is requested BEFORE this batch's results are stored: gfx9
 	// counts loads and stores in one in-order counter, so a wait for prefetched words that comes after the
 	// stores also waits for the stores (47 % of the kernel when it was written the other way round).
@@ -1765,7 +1708,6 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 				if (payload_rv <= 1)
 					payload_rv = do_HV<true>(s, clock);
 				break;
-#if DH_LONG_EV
 			case 12: case 13: {
 				// EV4 / EV5 into HBM: the lane-group phase (payload_length and the verdict come from ev_payloads)
 				const uint32_t size = s.length - 122u, unit = s.type == 12 ? 15u : 8u;
@@ -1778,10 +1720,6 @@ __device__ __forceinline__ void decode_view(PState &s, const btbbx_pkt_in &pi, b
 				}
 				break;
 			}
-#else
-			case 12: payload_rv = do_EV4<true>(s, clock); break;
-			case 13: payload_rv = do_EV35<true>(s, clock, 182); break;
-#endif
 			}
 			s.flags |= F_HAS_PAYLOAD;
 		}
@@ -1847,9 +1785,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 //   E  the wave stores head + payload of packet after packet as consecutive words (one 64-byte sector for most)
 // s_bits() takes words the staging did not cover (DH_STAGE_WORDS per wave) from the stream as before, so the extents
 // only decide where a word comes from, never what it is.
-#ifndef DH_STAGE_WORDS
 #define DH_STAGE_WORDS 384u                  // LDS words per wave for staged packets (3 KiB; 4 waves per workgroup)
-#endif
 __device__ __forceinline__ uint32_t symbols_of_type(uint32_t type)
 {
 	// 122 symbols of access code + trailer + header, then the longest payload of the type (FEC 2/3: 15 symbols per
@@ -1861,18 +1797,13 @@ __device__ __forceinline__ uint32_t symbols_of_type(uint32_t type)
 	return 366;
 }
 
-#ifndef DH_SORT
-#define DH_SORT 1
-#endif
 // which payload decoder a type runs (decode_view's switch)
 __device__ __forceinline__ uint32_t decoder_of_type(uint32_t type)
 {
 	// 0 none, 1 FHS, 2 DM, 3 DH, 4 HV, 5 EV3 (+ HV), 6 EV4, 7 EV5: a nibble per type
 	return (uint32_t)(0x3276323254432100ULL >> (4 * type)) & 0xf;
 }
-#ifndef DH_OUT_WORDS
 #define DH_OUT_WORDS 4u                      // payload words per lane that leave through LDS
-#endif
 #define DH_OUT_SECTOR 3u                     // ... of which these share the 64-byte sector of the record's head
 // How many symbols of the packet the payload decoder of `type` will look at under this clock, and whether what it
 // writes fits DH_OUT_WORDS words (small; wide: it needs the last of them, which lies in the record's second sector).
@@ -2534,38 +2465,13 @@ __device__ __forceinline__ void long_wave(dhl_u64_t *stg, dhl_u64_t *lst, const 
 	}
 }
 
-// -DDH_LONG_FUSED=0: the long payloads in a kernel of their own.  One workgroup per workgroup of decode_hits_kernel, wave w
-// takes what wave w of that workgroup left: hdr[4 b + w] = which of its list slots list[(4 b + w) * 64 ..] are filled.
-// Workgroups with nothing to do leave after two scalar loads; the hardware's dispatcher balances the rest.
-__global__ __launch_bounds__(256) void decode_long_kernel(const uint4 *list, const uint64_t *hdr, btbbx_pkt_out *outs)
-{
-	__shared__ uint64_t larea[4][DHL_STG_WORDS + DHL_LST_WORDS];
-	const uint64_t m0 = hdr[blockIdx.x * 4], m1 = hdr[blockIdx.x * 4 + 1], m2 = hdr[blockIdx.x * 4 + 2], m3 = hdr[blockIdx.x * 4 + 3];
-	if (!(m0 | m1 | m2 | m3))
-		return;
-	chain_lds_init();
-	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint64_t dmask = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
-	if (!dmask)
-		return;
-	long_wave((dhl_u64_t *)&larea[wave][0], (dhl_u64_t *)&larea[wave][DHL_STG_WORDS], list + (size_t)(blockIdx.x * 4 + wave) * 64, dmask, outs + (size_t)blockIdx.x * 256, lane);
-}
-
-#ifndef DH_WAVES_PER_EU
 #define DH_WAVES_PER_EU 6
-#endif
-#ifndef DH_LONG_FUSED
-#define DH_LONG_FUSED 1                      // the deferred payloads are decoded at the end of decode_hits_kernel (0: by decode_long_kernel)
-#endif
-#ifndef DH_LONG_PHASE
-#define DH_LONG_PHASE 1                      // 0: every lane walks its payload itself, whatever its length (round 3)
-#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH_WAVES_PER_EU, DH_WAVES_PER_EU)))
 void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_words,
 							  const btbbx_hit *hits, const btbbx_pkt_in *in, uint32_t n_packets,
 							  const uint32_t *d_count, uint32_t max_length, btbbx_pkt_out *outs,
 							  uint32_t *lengths, uint32_t mode, btbbx_pkt_in one_in, uint32_t clk_div,
-							  uint4 *long_list, uint32_t *long_hdr)
+							  uint4 *long_list)
 {
 	__shared__ uint64_t stage[4][DH_STAGE_WORDS];
 	__shared__ uint64_t ostage[4][64 * DH_OUT_WORDS];
@@ -2575,11 +2481,8 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	if (d_count)                                        // the list's length lives in HBM (no host round trip): n_packets is its capacity
 		n_packets = min(n_packets, *d_count);
 	bool live = pkt < n_packets;
-	if (blockIdx.x * blockDim.x >= n_packets) {
-		if (long_hdr && lane == 0)
-			reinterpret_cast<uint64_t *>(long_hdr)[blockIdx.x * 4 + wave] = 0;      // (decode_long_kernel is launched for the capacity too)
+	if (blockIdx.x * blockDim.x >= n_packets)
 		return;
-	}
 #ifdef DH_PROFILE
 	uint32_t dh_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t dh_t;
@@ -2655,7 +2558,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	s.staged = 0;
 	if (live && lengths)
 		lengths[pkt] = len;
-#if DH_SORT
 	// The workgroup's 256 packets change hands so that a wave decodes packets of one kind and about one length: a wave
 	// with DM, DH and FHS packets in it runs the three decoders one after the other with a third of its lanes each,
 	// and a loop over FEC blocks runs as long as its longest packet.  (With the stores, the staging and the exact
@@ -2678,7 +2580,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 			key = cls * 8 + (lb < 7 ? lb : 7);
 			// payloads that go to the wave phase (long_payloads): together, by the lanes a packet takes there (keys that
 			// are all but unused otherwise: class 0 has one length, HV packets that are not cut short another)
-			if (DH_LONG_PHASE && !small && want > 126 && (cls == 2 || cls == 3)) {
+			if (!small && want > 126 && (cls == 2 || cls == 3)) {
 				const uint32_t pbits = cls == 2 ? (want - 122) / 15 * 10 : want - 122, words = (pbits + 63) >> 6;   // (about: the grouping only)
 				key = cls == 2 ? 32u + (words > 32 ? 2u : words > 16 ? 1u : 0u)          // (DM, two words per lane: groups of 32 / 16 / 8)
 					       : 1u + (words > 24 ? 1u : 0u);                                // (DH, three: 16 / 8)
@@ -2725,7 +2627,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		dtype = (uint32_t)(x3 >> 24) & 0xfu;
 		dis = (uint32_t)(x3 >> 32);
 	}
-#endif
 	s.has_pre = true;
 	s.pre_hdr = hdr;
 	s.pre_dis = dis;
@@ -2749,7 +2650,7 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	if (nw > s.wlimit)
 		nw = s.wlimit;
 	// a payload that will be left to the wave phase: its lane reads the header and the payload header, four words
-	if (DH_LONG_PHASE && live && !small && want > 126 && nw > 4 && (decoder_of_type(dtype) == 2 || decoder_of_type(dtype) == 3))
+	if (live && !small && want > 126 && nw > 4 && (decoder_of_type(dtype) == 2 || decoder_of_type(dtype) == 3))
 		nw = 4;
 	// LDS slots in lane order; a packet that does not fit the wave's budget any more stays in the stream
 	uint32_t before = nw;
@@ -2820,8 +2721,6 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 	__builtin_amdgcn_wave_barrier();                    // every lane is done with the staged packets
 	// which of the wave's 64 list slots hold a payload that was left for later (do_DM / do_DH, defer_payload)
 	const uint64_t long_mask = long_list ? __ballot(live && s.def_nbits != 0) : 0ULL;
-	if (!DH_LONG_FUSED && long_hdr && lane == 0)
-		reinterpret_cast<uint64_t *>(long_hdr)[blockIdx.x * 4 + wave] = long_mask;
 	const uint64_t keep_mask = __ballot(small && !s.spoiled);
 #pragma unroll
 	for (int k = 0; k < 5; k++)
@@ -2840,10 +2739,10 @@ void decode_hits_kernel(const uint64_t *words, uint64_t n_words, uint64_t pitch_
 		}
 	}
 	DH_MARK(7);                                         // decoded, results stored
-	if (DH_LONG_FUSED && __builtin_expect(long_mask != 0, 0)) {
+	if (__builtin_expect(long_mask != 0, 0)) {
 		// The payloads the lanes left alone, a group of lanes per packet (long_payloads), in the wave's input stage: behind
 		// the store phase, when nothing of the lanes' decoders is alive any more.  Fused into this kernel rather than run
-		// as decode_long_kernel behind it: the phase is bound by instruction issue, the lanes' phases by latency -- waves
+		// as a kernel of its own behind it (round 4 measured both): the phase is bound by instruction issue, the lanes' phases by latency -- waves
 		// in the one fill the gaps of waves in the other (DH5 at full length: 497 against 562 us per 1.29 M packets).  What
 		// is known about a packet comes back from the list its lane wrote (defer_payload): 16 bytes, still in the L2.
 		asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the list entries are written
@@ -3297,42 +3196,43 @@ extern "C" int btbbx_decode_device(const uint64_t *d_packets, const btbbx_pkt_in
 	return launch_decode(d_packets, d_in, n_packets, d_out, DEC_HEADER | DEC_PAYLOAD, nullptr, (hipStream_t)hip_stream);
 }
 
-// decode_hits_kernel, then decode_long_kernel over the lists it left (DM / DH payloads beyond 256 bits).  The lists live in
-// a block from the device's stream-ordered pool -- asked for and given back on the caller's stream, so concurrent callers
-// on other streams share nothing and nothing is synchronised; the pool keeps what it has (release threshold raised once).
+// decode_hits_kernel with the list its lanes leave for its own lane-group phase (DM / DH / EV payloads beyond 256 bits, sixteen
+// bytes per packet).  The list lives in a block from the device's stream-ordered pool -- asked for and given back on the
+// caller's stream, so concurrent callers on other streams share nothing and nothing is synchronised; the pool keeps what it has
+// (release threshold raised once).  A runtime or device without such a pool still decodes: the kernel takes a null list, and
+// every lane then walks its payload itself as in round 3 (slower for multi-slot packets, same results).
 static int launch_decode_hits(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, const btbbx_hit *d_hits,
 			      const btbbx_pkt_in *d_in, uint32_t n_packets, const uint32_t *d_count, uint32_t max_length,
 			      btbbx_pkt_out *d_out, uint32_t *d_lengths, const btbbx_pkt_in &one_in, uint32_t clk_div, hipStream_t stream)
 {
 	const uint32_t groups = (uint32_t)(((uint64_t)n_packets + 255) / 256);
-	uint4 *list = nullptr;
-	uint32_t *hdr = nullptr;
 	void *block = nullptr;
-#if DH_LONG_PHASE
 	{
-		static std::atomic<uint64_t> pool_ready{0};
+		static std::atomic<uint64_t> pool_ready{0}, pool_absent{0};
 		int dev = 0;
 		HIP_TRY(hipGetDevice(&dev));
-		if (dev < 64 && !((pool_ready.load() >> dev) & 1)) {
+		const bool tracked = dev >= 0 && dev < 64;
+		bool usable = !tracked || !((pool_absent.load() >> dev) & 1);
+		if (usable && tracked && !((pool_ready.load() >> dev) & 1)) {
 			hipMemPool_t pool;
 			uint64_t keep = UINT64_MAX;
-			HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
-			HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-			pool_ready.fetch_or(1ULL << dev);
+			if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess &&
+			    hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) {
+				pool_ready.fetch_or(1ULL << dev);
+			} else {
+				(void)hipGetLastError();
+				pool_absent.fetch_or(1ULL << dev);
+				usable = false;
+			}
 		}
-		const size_t list_bytes = (size_t)groups * 4 * 64 * sizeof(uint4);
-		HIP_TRY(hipMallocAsync(&block, list_bytes + (size_t)groups * 32, stream));
-		list = (uint4 *)block;
-		hdr = (uint32_t *)((char *)block + list_bytes);
+		if (usable && hipMallocAsync(&block, (size_t)groups * 4 * 64 * sizeof(uint4), stream) != hipSuccess) {
+			(void)hipGetLastError();
+			block = nullptr;
+		}
 	}
-#endif
 	hipLaunchKernelGGL(decode_hits_kernel, dim3(groups), dim3(256), 0, stream, d_words, n_words, pitch_words, d_hits, d_in, n_packets,
-			   d_count, max_length, d_out, d_lengths, DEC_HEADER | DEC_PAYLOAD, one_in, clk_div, list, hdr);
+			   d_count, max_length, d_out, d_lengths, DEC_HEADER | DEC_PAYLOAD, one_in, clk_div, (uint4 *)block);
 	hipError_t e = hipGetLastError();
-	if (e == hipSuccess && block && !DH_LONG_FUSED) {
-		hipLaunchKernelGGL(decode_long_kernel, dim3(groups), dim3(256), 0, stream, (const uint4 *)list, (const uint64_t *)hdr, d_out);
-		e = hipGetLastError();
-	}
 	if (block) {
 		const hipError_t f = hipFreeAsync(block, stream);
 		if (e == hipSuccess)

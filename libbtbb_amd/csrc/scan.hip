@@ -43,6 +43,7 @@ struct ScanArgs {
 	uint32_t ring_margin;    // scan_slide_kernel: free ring entries below which the pass loop is left for a drain
 	uint32_t full_tiles;     // leading tiles of a stream whose words, halo word and offsets are all in range
 	uint32_t n_streams;
+	uint32_t msb;            // the words hold their symbols MSB first in every byte (BTBBX_FMT_PACKED_MSB): converted in registers
 	uint32_t lap;            // known-LAP mode
 	uint64_t syncword;       // known-LAP mode
 	int max_err;
@@ -107,14 +108,19 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uin
 	}
 }
 
-// Stream words are read once: STREAM_NT loads them non-temporally (they then do not push the L2-resident tables of the
-// >= 4-error kernels -- the 2^26-bit second-level bitmap -- out of the cache).
-#ifndef STREAM_NT
-#define STREAM_NT 0
-#endif
+// (Stream words are read once; loading them non-temporally so that they do not push the L2-resident tables of the
+// >= 4-error kernels out of the cache changed nothing: 12.0 against 12.06 ms per GiB at five errors, round 3.)
 __device__ __forceinline__ uint64_t stream_ld(const uint64_t *p)
 {
-	return STREAM_NT ? __builtin_nontemporal_load(p) : *p;
+	return *p;
+}
+// MSB-first bytes (first received symbol in bit 7, the order a radio front end delivers) -> the library's LSB-first dword:
+// reverse the dword's 32 bits, put the four bytes back in order (v_bfrev_b32 + v_perm_b32).  The scan kernels do this to the
+// four dwords of a lane behind a wave-uniform branch -- in the filter phase, which runs in the other waves' gaps -- instead of
+// a conversion pass over the capture in HBM (4 GiB read + 4 GiB written before a 4 GiB scan).
+__device__ __forceinline__ uint32_t msb_dword(uint32_t x)
+{
+	return __builtin_bswap32(__brev(x));
 }
 __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, uint64_t n_words)
 {
@@ -255,10 +261,6 @@ __device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
 	return (proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2);
 }
 
-// SCAN_SLIDE 0 builds the library with the table-probe kernel of rounds 1-2 (scan_lap_any_kernel<0>) for A/B runs
-#ifndef SCAN_SLIDE
-#define SCAN_SLIDE 1
-#endif
 // Wave priorities (s_setprio) by phase of a trip.  The four waves of a SIMD otherwise run in step -- all in the
 // VALU-dense pre-filter, then all waiting on LDS round trips in the survivor loop -- and compete for the same unit.
 // With the pre-filter lowest, the loop above it and the candidate handling (the longest latencies: LDS batches,
@@ -564,6 +566,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		for (int u = 0; u < UNROLL; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			if (a.msb) {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					d[u][k] = msb_dword(d[u][k]);
+			}
 			// offsets of this word that lie inside [0, search_bits)
 			uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
 			if (tc[u].stream >= a.n_streams) {
@@ -706,50 +713,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // not divide evenly over the four SIMDs) 4.4-5.6; the 2^20-bit set (128 KiB, one workgroup per CU only) 3.81.
 // Candidates ranked beyond the ring's free entries are checked in place, never dropped (a stream made of sync
 // words: tests/test_gpu_scan.py adversarial cases).
-#ifndef SLIDE_TILES
-#define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane)
-#endif
-#ifndef SLIDE_WGS
+// Geometry and tuning (every A/B behind these values is in profiles/: r03_ab, r05_scan).
+#define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
-#endif
-#ifndef SLIDE_THREADS
-#define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD)
-#endif
-#ifndef SLIDE_WAVES_PER_EU
+#define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
 #define SLIDE_WAVES_PER_EU (SLIDE_WGS * SLIDE_THREADS / 256)
-#endif
-#ifndef SLIDE_PREFETCH
-#define SLIDE_PREFETCH 0                   // 1: next tiles loaded while these are worked on (8 VGPRs more; round 5: 3.38 against 3.35 ms without)
-#endif
-#ifndef SLIDE_SINGLE
-#define SLIDE_SINGLE 1                     // fast path for the event "one lane of the wave holds a candidate" (1 % of the launch)
-#endif
-#ifndef SLIDE_FIXED
-#define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (0: +3 %)
-#endif
-#ifndef SLIDE_FOR_4
-#define SLIDE_FOR_4 0                      // 1: tables for 4 errors through scan_slide_kernel<1, WGS, DENSE> -- measured 6.26 ms per GiB
-                                           // against 3.27 for scan_lap_any_kernel<9>: 58 % of the survivors are candidates there, and the
-                                           // full exact check per candidate costs more than that kernel's in-loop probe of the L2 bitmap
-#endif
-#ifndef SLIDE_MARGIN_4
-#define SLIDE_MARGIN_4 44u
-#endif
-#ifndef SLIDE_SPARSE_TAIL
-#define SLIDE_SPARSE_TAIL 1                // passes behind the fixed ones skip chains that are empty wave-wide
-#endif
-#ifndef SLIDE_RUN
-#define SLIDE_RUN 1                        // chains as shift registers: the survivor in hand sits at bit 0 of its mask and of its check bits
-#endif
-#ifndef SLIDE_PROBE
-#define SLIDE_PROBE 0
-#endif
-#ifndef SLIDE_ABLATE
-#define SLIDE_ABLATE 0
-#endif
-#ifndef SLIDE_DRAIN_AT
+#define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
-#endif
 #define SLIDE_SET_WORDS  (1u << (SLIDE_BITS - 5))
 #define SLIDE_SET_BYTES  (4u * SLIDE_SET_WORDS)
 template <int WGS> struct SlideGeom {
@@ -866,10 +836,6 @@ void scan_slide_kernel(ScanArgs a)
 		pend += c;
 	};
 	auto drain = [&](uint32_t n) {               // the n <= 64 oldest ring entries through the exact rule
-#if SLIDE_ABLATE == 3                            // timing only: candidates are queued but never verified
-		q_head += n;
-		return;
-#endif
 		bool hit = false;
 		uint32_t stream = 0, lap = 0, nerr = 0;
 		uint64_t offset = 0;
@@ -929,23 +895,17 @@ void scan_slide_kernel(ScanArgs a)
 	}
 
 	for (uint32_t it = 0; tc[0].stream < a.n_streams; it += TILES) {
-		Cursor nc[TILES];
-		uint64_t nlo[TILES], nhi[TILES];
-		if (SLIDE_PREFETCH) {
-#pragma unroll
-			for (int u = 0; u < TILES; u++) {       // software prefetch: the loads fly while these tiles are worked on
-				nc[u] = cur;
-				load_pair(cur, nlo[u], nhi[u]);
-				advance(cur);
-			}
-		}
-
 		__builtin_amdgcn_s_setprio(PRIO_FILTER);
 		uint32_t d[TILES][4], m[TILES][2], c[TILES][3];
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			if (a.msb) {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					d[u][k] = msb_dword(d[u][k]);
+			}
 			uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
 			if (tc[u].stream >= a.n_streams) {
 				validA = validB = 0;
@@ -966,14 +926,8 @@ void scan_slide_kernel(ScanArgs a)
 			const uint32_t last = slide32_low_uniform(s2, s3);
 			const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
 			c[u][2] = lane == 63 ? last : next;
-#if SLIDE_ABLATE == 4                            // timing only: no filter -- survivor masks of the same density and raw dwords as check bits
-			m[u][0] = d[u][0] & d[u][1] & d[u][2] & validA;
-			m[u][1] = d[u][1] & d[u][2] & d[u][3] & validB;
-			c[u][0] = d[u][0]; c[u][1] = d[u][1]; c[u][2] = d[u][2];
-#endif
 		}
 
-#if SLIDE_RUN
 		// A chain (32 offsets) as a pair of shift registers: its survivor mask and the 50 check bits its indices are cut from,
 		// both moved down to the survivor in hand (one v_lshrrev_b64 instead of a funnel shift per survivor, no "m - 1").  Bit
 		// 63 is a marker: its distance from the top is the offset the chain stands at, which only a candidate event asks for.
@@ -983,7 +937,6 @@ void scan_slide_kernel(ScanArgs a)
 #pragma unroll
 			for (int h = 0; h < 2; h++)
 				C[u][h] = ((uint64_t)(c[u][h + 1] | 0x80000000u) << 32) | c[u][h];
-#endif
 		struct Stage { uint32_t p[TILES][2], v[TILES][2], bw[TILES][2], live[TILES][2]; };
 		auto any_left = [&]() {
 			uint32_t any = 0;
@@ -1008,18 +961,14 @@ void scan_slide_kernel(ScanArgs a)
 					if (cand) {
 						uint32_t lane6 = lane << 6;
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
-#if SLIDE_RUN
 						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
 						uint32_t pos;
 						asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
-#else
-						const uint32_t pos = g.p[u][h] & 31;
-#endif
 						// the record carries the three stream dwords the window lies in; the drain cuts it out (for sixty
 						// candidates at once) instead of this branch (for one)
 						const uint32_t code = pos | lane6 | (((it + u) << 12) | (h << 5));
 						const u32x4 rec = {code, d[u][h], d[u][h + 1], d[u][h + 2]};
-						if (SLIDE_SINGLE && (cm & (cm - 1)) == 0 && room) {
+						if ((cm & (cm - 1)) == 0 && room) {
 							// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
 							lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
 						} else {
@@ -1045,16 +994,10 @@ void scan_slide_kernel(ScanArgs a)
 		// an idle lane whose junk index happens to be in the set triggers an event in EVERY pass.  profiles/r03_ab.)
 		auto pass = [&]() {
 			Stage g;
-#if SLIDE_PROBE
-			uint32_t probe_junk = lane;
-			const uint32_t probe_addr_ = lane << 2;
-			asm volatile("" : "+v"(probe_junk));
-#endif
 #pragma unroll
 			for (int u = 0; u < TILES; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {       // next survivor of every chain: index, set read in flight
-#if SLIDE_RUN
 					const uint32_t p = lowest_bit(m[u][h]);   // ~0 for an empty chain: it shifts itself out, bit 0 stays 0
 					m[u][h] >>= p & 31;
 					C[u][h] >>= p & 63;
@@ -1062,22 +1005,6 @@ void scan_slide_kernel(ScanArgs a)
 					g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
 					g.live[u][h] = m[u][h];                   // bit 0: this lane has a survivor
 					m[u][h] &= ~1u;
-#if SLIDE_PROBE == 1                             // marginal cost of one full-rate vector instruction per chain and pass
-					asm volatile("v_xor_b32 %0, %0, %1" : "+v"(probe_junk) : "v"(g.v[u][h]));
-#elif SLIDE_PROBE == 2                           // ... of one funnel shift
-					asm volatile("v_alignbit_b32 %0, %0, %1, %1" : "+v"(probe_junk) : "v"(g.v[u][h]));
-#elif SLIDE_PROBE == 3                           // ... of one more LDS read (conflict-free, its own address register)
-					probe_junk ^= lds_ld(probe_addr_);
-#elif SLIDE_PROBE == 4                           // ... of one more LDS read at the survivor's own (random) address
-					probe_junk ^= lds_ld(((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2)) ^ 4u);
-#endif
-#else
-					g.p[u][h] = lowest_bit(m[u][h]);
-					g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
-					g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
-					g.live[u][h] = m[u][h] >> g.p[u][h];      // bit 0: this lane has a survivor (p = ~0 for m == 0)
-					m[u][h] &= m[u][h] - 1;
-#endif
 				}
 			uint32_t anybit = 0, bit[TILES][2];
 #pragma unroll
@@ -1087,15 +1014,8 @@ void scan_slide_kernel(ScanArgs a)
 					bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
 					anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 				}
-#if SLIDE_PROBE
-			asm volatile("" : : "v"(probe_junk));
-#endif
-#if SLIDE_ABLATE == 1                            // timing only (finds nothing): what the candidate events and everything behind them cost
-			asm volatile("" : : "v"(anybit));
-#else
 			if (__ballot(anybit & 1))                // some lane of the wave holds a candidate (half of the passes)
 				events(g, bit);
-#endif
 		};
 		// Behind the fixed passes a handful of the wave's 2 * TILES * 64 chains still hold survivors (0.8 % have seven or more):
 		// a pass then looks at the chains one by one and skips those that are empty wave-wide (the same ballots are the
@@ -1115,7 +1035,6 @@ void scan_slide_kernel(ScanArgs a)
 						if (!__ballot(m[u][h] != 0))
 							continue;
 						any = true;
-#if SLIDE_RUN
 						const uint32_t p = lowest_bit(m[u][h]);
 						m[u][h] >>= p & 31;
 						C[u][h] >>= p & 63;
@@ -1123,13 +1042,6 @@ void scan_slide_kernel(ScanArgs a)
 						g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
 						g.live[u][h] = m[u][h];
 						m[u][h] &= ~1u;
-#else
-						g.p[u][h] = lowest_bit(m[u][h]);
-						g.v[u][h] = alignbit(c[u][h + 1], c[u][h], g.p[u][h]);
-						g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
-						g.live[u][h] = m[u][h] >> g.p[u][h];
-						m[u][h] &= m[u][h] - 1;
-#endif
 						bit[u][h] = g.bw[u][h] >> (g.v[u][h] & 31);
 						anybit = BITOP3(bit[u][h], g.live[u][h], anybit, 0xea);
 					}
@@ -1147,15 +1059,7 @@ void scan_slide_kernel(ScanArgs a)
 #endif
 		PROF_MARK(0);
 		uint32_t pass_no = 1;
-#if SLIDE_ABLATE == 2                            // timing only: loads, barker filter and check stream alone
-#pragma unroll
-		for (int u = 0; u < TILES; u++)
-			asm volatile("" : : "v"(m[u][0]), "v"(m[u][1]), "v"(c[u][0]), "v"(c[u][1]), "v"(c[u][2]));
-		if (true) {
-		} else if (!DENSE) {
-#else
 		if (!DENSE) {
-#endif
 			__builtin_amdgcn_s_setprio(PRIO_LOOP);
 #pragma unroll 1
 			for (int k = 0; k < SLIDE_FIXED; k++) { // practically every trip needs these (TILES * 128 chains of ~4 survivors)
@@ -1163,16 +1067,8 @@ void scan_slide_kernel(ScanArgs a)
 				PROF_MARK(pass_no < 13 ? pass_no : 13);
 				pass_no++;
 			}
-			if (SLIDE_SPARSE_TAIL) {
-				sparse_tail();
-				PROF_MARK(pass_no < 13 ? pass_no : 13);
-			} else {
-				while (any_left()) {
-					pass();
-					PROF_MARK(pass_no < 13 ? pass_no : 13);
-					pass_no++;
-				}
-			}
+			sparse_tail();
+			PROF_MARK(pass_no < 13 ? pass_no : 13);
 			__builtin_amdgcn_s_setprio(PRIO_CAND);
 			PROF_MARK(16);
 			if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
@@ -1205,15 +1101,11 @@ void scan_slide_kernel(ScanArgs a)
 		PROF_MARK(18);
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
-			if (SLIDE_PREFETCH) {
-				tc[u] = nc[u];
-				lo[u] = nlo[u];
-				hi[u] = nhi[u];
-			} else {                                // no prefetch (8 registers less): the other waves of the SIMD cover the loads
-				tc[u] = cur;
-				load_pair(cur, lo[u], hi[u]);
-				advance(cur);
-			}
+			// no software prefetch: the other five waves of the SIMD cover the loads, and the eight registers it took are
+			// worth more (round 5: 3.35 against 3.38 ms)
+			tc[u] = cur;
+			load_pair(cur, lo[u], hi[u]);
+			advance(cur);
 		}
 		PROF_MARK(19);
 	}
@@ -1253,9 +1145,6 @@ __device__ __forceinline__ uint32_t bitop3_tt(uint32_t a, uint32_t b, uint32_t c
 // (window bit 52 + k of offset p is bit p + 20 + k of dh:dm), a carry-save adder tree to a 4-bit
 // count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
 // 79 / 4096 = 1.9 % of the offsets of a random stream.
-#ifndef KL_SATURATE
-#define KL_SATURATE 1
-#endif
 template <int CLS>
 __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
 {
@@ -1282,13 +1171,11 @@ __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);
 	const uint32_t t1 = FA_SUM(c3, k0, k1), f1 = FA_CARRY(c3, k0, k1);
 	const uint32_t twos = t0 ^ t1, f2 = t0 & t1;
-#if KL_SATURATE
 	if (limit <= 3) {                                   // (see top16_filter)
 		const uint32_t ge4 = BITOP3(f0, f1, f2, 0xfe);
 		const uint32_t low = limit == 0 ? (twos | ones) : limit == 1 ? twos : limit == 2 ? (twos & ones) : 0u;
 		return ~(ge4 | low);
 	}
-#endif
 	const uint32_t fours = FA_SUM(f0, f1, f2), eights = FA_CARRY(f0, f1, f2);
 #undef FA_SUM
 #undef FA_CARRY
@@ -1338,7 +1225,6 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 	const uint32_t t1 = FA_SUM(c3, c4, k0), f1 = FA_CARRY(c3, c4, k0);
 	const uint32_t t2 = FA_SUM(k1, k2, t0), f2 = FA_CARRY(k1, k2, t0);
 	const uint32_t twos = t1 ^ t2, f3 = t1 & t2;
-#if KL_SATURATE
 	// limit <= 3: "count >= 4" is all that matters of the upper weights, and it is the OR of the four carries out of the
 	// twos column -- six adder instructions and the compare become three (the compiler cannot find this: it is not the
 	// same function as the sum it replaces)
@@ -1347,7 +1233,6 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 		const uint32_t low = limit == 0 ? (twos | ones) : limit == 1 ? twos : limit == 2 ? (twos & ones) : 0u;
 		return ~BITOP3(ge4, f3, low, 0xfe);
 	}
-#endif
 	// weight 4: f0..f3
 	const uint32_t g0 = FA_SUM(f0, f1, f2), h0 = FA_CARRY(f0, f1, f2);
 	const uint32_t fours = g0 ^ f3, h1 = g0 & f3;
@@ -1371,15 +1256,9 @@ __device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const
 // counter atomic per 64 hits (a single counter word saturates near 88 M atomics/s on this
 // chip, which a dense hit stream would otherwise run into).
 #define KRING 128
-#ifndef KL_WORDS
-#define KL_WORDS 2                             // stream words per lane and tile (tile = KL_WORDS x 256 words)
-#endif
-#ifndef KL_PREFETCH
-#define KL_PREFETCH 1
-#endif
-#ifndef KL_SELECT_LIMIT
+#define KL_WORDS 2                             // stream words per lane and tile (tile = KL_WORDS x 256 words); the next tile's
+                                               // words are loaded while this one is worked on (0.466 against 0.4865 ms, round 3)
 #define KL_SELECT_LIMIT 1                      // limits up to here: one survivor per lane and pass (scan_known_lap_kernel)
-#endif
 struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per staged hit
 
 // LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
@@ -1470,7 +1349,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		stream++;
 	}
 	// a tile is KL_WORDS x 256 words: every lane owns KL_WORDS words 256 apart.  The next tile's words are loaded while
-	// this one is worked on (KL_PREFETCH): the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per
+	// this one is worked on: the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per
 	// SIMD taking turns at their loads (profiles/r03_chain/pmc_known_before.json).
 	uint64_t nlo[KL_WORDS], nhi[KL_WORDS];
 	auto fetch = [&](uint32_t ft, uint32_t fstream) {
@@ -1519,8 +1398,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			t -= tiles_per_stream;
 			stream++;
 		}
-		if (KL_PREFETCH)
-			fetch(t, stream);
+		fetch(t, stream);
 		PROF_MARK(4);
 #ifdef SCAN_PROFILE
 #pragma unroll
@@ -1533,6 +1411,11 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		for (int u = 0; u < KL_WORDS; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
+			if (a.msb) {
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					d[u][k] = msb_dword(d[u][k]);
+			}
 			if (wide) {
 				m[u][0] = top16_filter<CLS>(d[u][1], d[u][2], flip, limit);
 				m[u][1] = top16_filter<CLS>(d[u][2], d[u][3], flip, limit);
@@ -1612,8 +1495,6 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		PROF_MARK(2);
 		while (q_tail - q_head >= 64)
 			flush(64);
-		if (!KL_PREFETCH)
-			fetch(t, stream);
 		PROF_MARK(3);
 	}
 	if (q_tail != q_head)
@@ -1714,7 +1595,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
 		btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
 		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt = nullptr, uint64_t bucket_mul = 0,
-		uint32_t bucket_shift = 0)
+		uint32_t bucket_shift = 0, bool msb = false)
 {
 	int rc = ctx_require();
 	if (rc)
@@ -1735,6 +1616,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 	a.pitch_words = pitch_words;
 	a.search_bits = search_bits;
 	a.n_streams = n_streams;
+	a.msb = msb ? 1u : 0u;
 	a.lap = lap;
 	a.syncword = 0;
 	a.max_err = max_ac_errors;
@@ -1754,9 +1636,9 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
 		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one); everything else
 		// runs the sliding-check kernel
-		int run_variant = SCAN_SLIDE ? 1 : 0;
+		int run_variant = 1;
 		if (a.t.bitmap2 && table_errors >= 4)
-			run_variant = table_errors == 4 ? (SLIDE_FOR_4 ? 1 : 9) : 8;
+			run_variant = table_errors == 4 ? 9 : 8;
 		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : SCAN_THREADS;      // one word per thread
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
@@ -1786,15 +1668,9 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		case 1: {
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
-			if (table_errors >= 4) {
-				// 4 errors: 58 % of the survivors pass the 2^19-bit set -- one tile per trip (two chains), the ring drained after
-				// practically every pass, every candidate through the 2^26-bit second-level bitmap in L2 (verify_lap_any) at
-				// full lanes instead of one probe per surviving lane inside the lock-step loop (scan_lap_any_kernel<9>)
-				a.ring_margin = SLIDE_MARGIN_4;
-				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<1, SLIDE_WGS, true>),
-							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-				hipLaunchKernelGGL((scan_slide_kernel<1, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
-			} else if (table_errors >= 3) {
+			// (tables for 4 errors through this kernel -- one tile per trip, a drain after practically every pass: 58 % of the
+			// survivors are candidates there -- ran 6.26 ms per GiB against 3.27 for scan_lap_any_kernel<9>, round 3; removed)
+			if (table_errors >= 3) {
 				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>),
 							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
@@ -1805,7 +1681,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			}
 			break;
 		}
-		default: LAUNCH_VARIANT(0); break;
+		default: set_error("btbbx_scan: internal: no LAP_ANY kernel for this table set"); return BTBBX_E_ARG;
 		}
 #ifdef SCAN_PROFILE
 		{
@@ -1873,6 +1749,18 @@ extern "C" int btbbx_scan_device(const uint64_t *d_words, uint64_t n_words, uint
 	}
 	return launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors,
 			   d_hits, hit_cap, d_hit_count, nullptr, (hipStream_t)hip_stream);
+}
+
+extern "C" int btbbx_scan_device_fmt(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
+				     uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors, int format,
+				     btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count, void *hip_stream)
+{
+	if (!d_words || !d_hit_count || (!d_hits && hit_cap) || (format != BTBBX_FMT_PACKED && format != BTBBX_FMT_PACKED_MSB)) {
+		set_error("btbbx_scan_device_fmt: null pointer or a format that is not BTBBX_FMT_PACKED / BTBBX_FMT_PACKED_MSB");
+		return BTBBX_E_ARG;
+	}
+	return launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors,
+			   d_hits, hit_cap, d_hit_count, nullptr, (hipStream_t)hip_stream, nullptr, 0, 0, format == BTBBX_FMT_PACKED_MSB);
 }
 
 extern "C" int btbbx_scan_first_device(const uint64_t *d_words, uint64_t n_words, uint64_t search_bits,

@@ -589,13 +589,14 @@ extern "C" int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d
 // leaves it.  Nothing is synchronised.
 int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams, uint64_t search_bits,
 		uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
-		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift);
+		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift, bool msb);
 
-extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
-					 uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
-					 uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream)
+extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
+					     uint64_t search_bits, uint32_t lap, int max_ac_errors, int format, btbbx_hit *d_hits, uint32_t cap,
+					     uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream)
 {
-	if (!d_words || !d_hits || !d_count || !n_streams || !search_bits || cap < 2) {
+	if (!d_words || !d_hits || !d_count || !n_streams || !search_bits || cap < 2 ||
+	    (format != BTBBX_FMT_PACKED && format != BTBBX_FMT_PACKED_MSB)) {
 		set_error("btbbx_scan_ordered_device: bad argument");
 		return BTBBX_E_ARG;
 	}
@@ -613,10 +614,18 @@ extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_wor
 	const uint32_t shift = order_shift(n_streams, search_bits, L.nb_log2);
 	// the scan leaves its records in the scratch (and counts each in its bucket); the ordering puts them into d_hits
 	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, (btbbx_hit *)(base + L.parked), cap, d_count,
-			     nullptr, stream, (uint32_t *)(base + L.start), search_bits, shift);
+			     nullptr, stream, (uint32_t *)(base + L.start), search_bits, shift, format == BTBBX_FMT_PACKED_MSB);
 	if (rc)
 		return rc;
 	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, stream, n_streams, search_bits - 1, true);
+}
+
+extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
+					 uint64_t search_bits, uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t cap,
+					 uint32_t *d_count, void *d_scratch, size_t scratch_bytes, void *hip_stream)
+{
+	return btbbx_scan_ordered_device_fmt(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, BTBBX_FMT_PACKED,
+					     d_hits, cap, d_count, d_scratch, scratch_bytes, hip_stream);
 }
 
 // one scratch block per device for the signature without caller scratch

@@ -204,15 +204,21 @@ extern "C" int64_t btbbx_stream_submit(btbbx_stream *s, uint64_t n_symbols, btbb
 		if (rc)
 			return rc;
 	} else {
-		if ((n_symbols & 63) && s->format == BTBBX_FMT_PACKED)      // clear the unused tail of the last word
-			((uint64_t *)sl.h_in)[chunk_words - 1] &= (1ULL << (n_symbols & 63)) - 1;
+		if (n_symbols & 63) {                                       // clear the unused tail of the last word
+			if (s->format == BTBBX_FMT_PACKED) {
+				((uint64_t *)sl.h_in)[chunk_words - 1] &= (1ULL << (n_symbols & 63)) - 1;
+			} else {                                            // MSB first: symbol i is bit 7 - i % 8 of byte i / 8
+				uint8_t *bytes = (uint8_t *)sl.h_in;
+				const uint64_t full = n_symbols / 8, part = n_symbols & 7;
+				if (part)
+					bytes[full] &= (uint8_t)(0xff00u >> part);
+				memset(bytes + full + (part ? 1 : 0), 0, chunk_words * 8 - full - (part ? 1 : 0));
+			}
+		}
 		if (hipMemcpyAsync(sl.d_words + 1, sl.h_in, chunk_words * 8, hipMemcpyHostToDevice, sl.stream) != hipSuccess)
 			return hip_fail(hipGetLastError(), "h2d words");
-		if (s->format == BTBBX_FMT_PACKED_MSB) {
-			int rc = btbbx_msb_to_lsb_device(sl.d_words + 1, chunk_words, sl.stream);
-			if (rc)
-				return rc;
-		}
+		// (an MSB-first chunk stays as it is: the scan turns its dwords round as it loads them; carry and zero word are
+		// format-neutral -- a raw copy of the previous chunk's last word, and zeros)
 	}
 	// carry = last word of the previous chunk (its packing must have finished)
 	if (first) {
@@ -234,8 +240,9 @@ extern "C" int64_t btbbx_stream_submit(btbbx_stream *s, uint64_t n_symbols, btbb
 	// o <= n; offset 0 was the last offset of the previous launch and offsets below 64 of the
 	// first chunk start in the (fake) carry: collect() drops both.
 	const uint64_t search_bits = n_symbols + 1;
-	int rc = btbbx_scan_device(sl.d_words, sl.n_words + 1, sl.n_words + 1, 1, search_bits, s->lap, s->max_err,
-				   sl.d_hits, s->hit_cap, sl.d_count, sl.stream);
+	int rc = btbbx_scan_device_fmt(sl.d_words, sl.n_words + 1, sl.n_words + 1, 1, search_bits, s->lap, s->max_err,
+				       s->format == BTBBX_FMT_PACKED_MSB ? BTBBX_FMT_PACKED_MSB : BTBBX_FMT_PACKED,
+				       sl.d_hits, s->hit_cap, sl.d_count, sl.stream);
 	if (rc)
 		return rc;
 	if (hipMemcpyAsync(sl.h_count, sl.d_count, 4, hipMemcpyDeviceToHost, sl.stream) != hipSuccess)

@@ -540,6 +540,61 @@ def test_scan_ordered_device(lap):
     d_w.free()
 
 
+@pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33, 0x1E8B33])
+def test_msb_first_capture_scanned_as_it_is(lap):
+    """BTBBX_FMT_PACKED_MSB (8 symbols per byte, first symbol in bit 7 -- a dongle's dump): the scan kernels turn the dwords
+    round in registers, the capture in HBM is not rewritten.  Hit for hit what the LSB-first words of the same symbols give
+    and what the oracle finds, for several streams with a pitch, ragged search lengths around word and tile boundaries, through
+    btbbx_scan_device_fmt and btbbx_scan_ordered_device_fmt (the latter entered with a stale counter: it zeroes it itself)."""
+    lib = bt.lib()
+    kw = dict(stride=512) if lap == bt.LAP_ANY else dict(stride=512, lap=lap)
+    olap = lap if lap != bt.LAP_ANY else _libs.LAP_ANY
+    n_streams, nwords, pitch = 3, 2 * 768 + 131, 2 * 768 + 140
+    lsb_rows, msb_rows, syms = [], [], []
+    for ch in range(n_streams):
+        words, sym, _ = stream(170 + ch, nwords, **kw)
+        msb = np.packbits(sym, bitorder="big").view(np.uint64)          # the same symbols, MSB first in every byte
+        assert len(msb) == nwords and not np.array_equal(msb, words)
+        lsb_rows.append(np.concatenate([words, np.zeros(pitch - nwords, np.uint64)]))
+        msb_rows.append(np.concatenate([msb, np.zeros(pitch - nwords, np.uint64)]))
+        syms.append(sym)
+    d_l = bt.DeviceBuffer(pitch * n_streams * 8).upload(np.concatenate(lsb_rows))
+    d_m = bt.DeviceBuffer(pitch * n_streams * 8).upload(np.concatenate(msb_rows))
+    cap = 1 << 16
+    d_h = bt.DeviceBuffer(cap * 16)
+    d_c = bt.DeviceBuffer(16)
+    sb = lib.btbbx_order_hits_scratch_bytes(cap)
+    d_s = bt.DeviceBuffer(sb)
+
+    def plain(d_w, fmt, bits):
+        d_c.zero()
+        bt.check(lib.btbbx_scan_device_fmt(d_w.ptr, nwords, pitch, n_streams, bits, lap, 2, fmt, d_h.ptr, cap, d_c.ptr, None), "scan_fmt")
+        bt.check(lib.btbbx_sync(None))
+        cnt = int(d_c.download(np.uint32, 4)[0])
+        return sorted((int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt])
+
+    def ordered(d_w, fmt, bits):
+        d_c.upload(np.array([12345, 0, 0, 0], np.uint32))               # stale: the call must not trust it
+        bt.check(lib.btbbx_scan_ordered_device_fmt(d_w.ptr, nwords, pitch, n_streams, bits, lap, 2, fmt, d_h.ptr, cap, d_c.ptr,
+                                                   d_s.ptr, sb, None), "scan_ordered_fmt")
+        bt.check(lib.btbbx_sync(None))
+        cnt = int(d_c.download(np.uint32, 4)[0])
+        return [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt]]
+
+    total = 0
+    for bits in (nwords * 64 - 63, nwords * 64 - 63 - 29, 768 * 64, 768 * 64 + 1, 768 * 64 - 1, 64 * 700 + 33, 65, 1):
+        want = sorted((ch, o, l, e) for ch in range(n_streams) for (o, l, e) in _libs.orc_find_all(syms[ch], bits, olap, 2))
+        got_m = plain(d_m, 2, bits)
+        assert got_m == plain(d_l, 0, bits) == want, (lap, bits, len(got_m), len(want))
+        assert ordered(d_m, 2, bits) == want == ordered(d_l, 0, bits), (lap, bits)
+        total += len(want)
+    assert total > 300
+    with pytest.raises(bt.BtbbError):
+        bt.check(lib.btbbx_scan_device_fmt(d_m.ptr, nwords, pitch, n_streams, 64, lap, 2, 1, d_h.ptr, cap, d_c.ptr, None), "scan_fmt")
+    for b in (d_l, d_m, d_h, d_c, d_s):
+        b.free()
+
+
 @pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33])
 def test_sharded_product_scan_equals_single_scan(lap):
     """btbbx_scan_host_multi (the C-ABI form of the N-GPU path): the library's own shard plan --

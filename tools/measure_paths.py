@@ -60,15 +60,16 @@ def main():
     out["scan_host_symbols"] = {"symbols": ns, "seconds": round(dt, 4), "Gbit_s": round(ns / dt / 1e9, 2), "hits": int(n2)}
 
     # ---- streaming ingest: pinned double buffers, chunked
-    for fmt, name, chunk in ((0, "stream_packed", 1 << 29), (1, "stream_symbols", 1 << 26)):
+    host_msb = np.packbits(sym, bitorder="big").view(np.uint64)              # (the first 2^30 symbols, MSB first in every byte)
+    for fmt, name, chunk in ((0, "stream_packed", 1 << 29), (1, "stream_symbols", 1 << 26), (2, "stream_packed_msb", 1 << 29)):
         h = lib.btbbx_stream_open(bt.LAP_ANY, 2, chunk, fmt)
-        src = host_words if fmt == 0 else sym
+        src = host_words if fmt == 0 else sym if fmt == 1 else host_msb
         total = nw * 64 if fmt == 0 else ns
-        per = chunk // 64 if fmt == 0 else chunk
+        per = chunk // 64 if fmt != 1 else chunk
         nh = 0
         t0 = time.perf_counter()
         for pos in range(0, total, chunk):
-            a0 = pos // 64 if fmt == 0 else pos
+            a0 = pos // 64 if fmt != 1 else pos
             part = src[a0:a0 + per]
             nh += bt.check(lib.btbbx_stream_feed(h, part.ctypes.data, min(chunk, total - pos), hits.ctypes.data, len(hits)))
         nh += bt.check(lib.btbbx_stream_flush(h, hits.ctypes.data, len(hits)))
@@ -81,7 +82,7 @@ def main():
         h = lib.btbbx_stream_open(bt.LAP_ANY, 2, chunk, fmt)
         nh = 0
         for k in range(2):
-            a0 = (k * chunk) // 64 if fmt == 0 else k * chunk
+            a0 = (k * chunk) // 64 if fmt != 1 else k * chunk
             part = src[a0:a0 + per]
             dst = lib.btbbx_stream_acquire(h)
             C.memmove(dst, part.ctypes.data, part.nbytes)
@@ -121,6 +122,35 @@ def main():
                                        hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
     t = ev_time(known)
     out["known_lap_4GiB"] = {"ms": round(t * 1e3, 3), "Gbit_s": round(nw4 * 64 / t / 1e9, 1), "hits": int(cnt_t.item())}
+
+    # ---- the same 4 GiB as an MSB-first capture (first symbol in bit 7 of its byte): scanned as it is (round 5) against the
+    # LSB-first words, and against round 4's way (conversion pass in place, then the scan)
+    def scan_fmt(fmt, lap_):
+        def run():
+            cnt_t.zero_()
+            bt.check(lib.btbbx_scan_device_fmt(d4.data_ptr(), nw4, nw4, 1, nw4 * 64 - 63, lap_, 2, fmt,
+                                               hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
+        return run
+    res = {}
+    for name, lap_ in (("lap_any", bt.LAP_ANY), ("known_lap", 0x9E8B33)):
+        t_l = ev_time(scan_fmt(0, lap_))
+        n_l = int(cnt_t.item())
+        bt.check(lib.btbbx_msb_to_lsb_device(d4.data_ptr(), nw4, hs))          # an involution: the words now hold MSB-first bytes
+        t_m = ev_time(scan_fmt(2, lap_))
+        n_m = int(cnt_t.item())
+
+        def old_way():
+            bt.check(lib.btbbx_msb_to_lsb_device(d4.data_ptr(), nw4, hs))
+            scan_fmt(0, lap_)()
+            bt.check(lib.btbbx_msb_to_lsb_device(d4.data_ptr(), nw4, hs))      # (back to MSB for the next repetition: counted out below)
+        t_o = ev_time(old_way)
+        t_c = ev_time(lambda: bt.check(lib.btbbx_msb_to_lsb_device(d4.data_ptr(), nw4, hs)), reps=5)      # (1 + 5 passes: an even number)
+        bt.check(lib.btbbx_msb_to_lsb_device(d4.data_ptr(), nw4, hs))          # LSB again
+        res[name] = {"lsb_ms": round(t_l * 1e3, 3), "msb_fused_ms": round(t_m * 1e3, 3), "msb_over_lsb": round(t_m / t_l, 4),
+                     "convert_then_scan_ms": round((t_o - t_c) * 1e3, 3), "convert_pass_ms": round(t_c * 1e3, 3),
+                     "hits_lsb": n_l, "hits_msb": n_m}
+        assert n_l == n_m > 1000, (name, n_l, n_m)
+    out["msb_first_4GiB"] = res
     del d4
 
     # ---- config 3: 79 channels x 2^21 words, DM1/DH1/DM3/FHS packets every 4096 symbols, known LAP
