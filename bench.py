@@ -39,7 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_MIN_PER_WORD = 132        # fewest vector instructions per 64 offsets of an exact LAP_ANY filter of this shape
+VALU_MIN_PER_WORD = 124        # fewest vector instructions per 64 offsets of an exact LAP_ANY filter of this shape (30 + 30 + 8 x 8)
 SEED = 20260926
 STRIDE = 4096
 
@@ -689,6 +689,48 @@ def channels79(args, bt, lib, shard, dev, rank, world, red_dev):
     return 0
 
 
+def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t, cap, unordered_ms):
+    """The headline scan with its hit list in (stream, offset) order -- what the host wrappers (btbbx_scan_host*, the streaming
+    ingest) and btbb_find_ac hand out, and what the reference's loop produces by construction: btbbx_scan_ordered_device on the
+    headline stream (the scan kernel counts every record in the bucket the ordering will put it in and parks its list in the
+    scratch; scan of the counts, scatter, rank: sort.hip).  Checked in the run: strictly increasing offsets, and the same set
+    of records as the unordered list of the timed headline loop."""
+    unordered = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:int(cnt_t.item())].copy()
+    order_bytes = lib.btbbx_order_hits_scratch_bytes(cap)
+    scratch = torch.empty(order_bytes, dtype=torch.uint8, device=dev)
+
+    def step():
+        bt.check(lib.btbbx_scan_ordered_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2, hits_t.data_ptr(), cap,
+                                               cnt_t.data_ptr(), scratch.data_ptr(), order_bytes, hs))
+    step()
+    torch.cuda.synchronize()
+    reps = 10
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(cur)
+    for _ in range(reps):
+        step()
+    b.record(cur)
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    n = int(cnt_t.item())
+    got = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:n].copy()
+    increasing = bool(np.all(got["offset"][1:] > got["offset"][:-1]))
+    full = ["offset", "lap", "ac_errors", "stream"]
+    same = n == len(unordered) and bool(np.array_equal(got[full], np.sort(unordered, order="offset")[full]))
+    alg = nbits / 8 + 16 * n + 32 * n                  # the stream once, every record written, read and written again by the ordering
+    del scratch
+    return {
+        "config": "BASELINE configs[1] with the list in offset order: btbbx_scan_ordered_device on the headline stream "
+                  "(scan + bucket counts, scan of the counts, scatter, ranks of shared buckets), one stream, no host round trip",
+        "value": round(nbits / (ms * 1e-3) / 1e9, 2), "unit": "Gbit/s", "ms_per_step": round(ms, 4), "hits": n,
+        "ordering_ms": round(ms - unordered_ms, 4), "unordered_kernel_ms": round(unordered_ms, 4),
+        "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
+                     "kernel": "scan_slide_kernel + order_*", "traffic": None},
+        "parity": bool(increasing and same), "strictly_increasing": increasing, "equals_sorted_unordered_list": same,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -700,7 +742,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 block")
     ap.add_argument("--only-secondary", default=None, metavar="NAME", help="run one line of the secondary block only (with the input it "
-                    "needs): known_lap_79ch_chain_full_payloads, known_lap_79ch_chain, clk6_bruteforce, clk6_bruteforce_all_types")
+                    "needs): lap_any_4gib_ordered, known_lap_79ch_chain_full_payloads, known_lap_79ch_chain, clk6_bruteforce, clk6_bruteforce_all_types")
     ap.add_argument("--layout", default="single", choices=["single", "channels79"],
                     help="single: one stream of --gib GiB per GPU (weak scaling, BASELINE configs[1], the default line); "
                          "channels79: BASELINE configs[3] as written -- 79 channel streams, --gib GiB IN TOTAL (default 64), every "
@@ -862,9 +904,15 @@ def main():
         else:
             result["cpu_baseline"] = None
         if world == 1 and not args.no_secondary:
+            ordered = None
+            if args.only_secondary in (None, "lap_any_4gib_ordered"):
+                ordered = ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t, cap, kern_ms)
             del stream, hits_t
             torch.cuda.empty_cache()
-            result["secondary"] = secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu, args.only_secondary)
+            result["secondary"] = {} if args.only_secondary == "lap_any_4gib_ordered" else \
+                secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu, args.only_secondary)
+            if ordered is not None:
+                result["secondary"]["lap_any_4gib_ordered"] = ordered
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -107,6 +107,44 @@ def _oracle_decode(orc, sym, clkn, uap, clk_valid=True):
     return present, h, r, st
 
 
+def _ref_decode(ref, sym, clkn, uap, clk_valid=True):
+    """The same calls on the compiled, unmodified reference (oracle/_ref): btbb_packet_set_data, btbb_header_present,
+    btbb_decode_header, btbb_decode_payload (lib/src/bluetooth_packet.c:467-480, 1198-1297, 1371-1408); the packet's fields
+    are read through their real offsets."""
+    sym = np.ascontiguousarray(sym, dtype=np.uint8)
+    p = C.c_void_p(ref.btbb_packet_new())
+    view = _libs.RefPacketView(ref, p.value)
+    C.c_uint32.from_address(p.value + view._off("LAP")).value = 0
+    C.c_uint8.from_address(p.value + view._off("ac_errors")).value = 0
+    C.c_uint32.from_address(p.value + view._off("flags")).value = 0
+    ref.btbb_packet_set_flag(p, 0, 1)
+    ref.btbb_packet_set_data(p, _libs.ptr(sym), len(sym), 0, clkn << 1)
+    ref.btbb_packet_set_uap(p, uap)
+    ref.btbb_packet_set_flag(p, 4, 1 if clk_valid else 0)
+    present = ref.btbb_header_present(p)
+    h = ref.btbb_decode_header(p)
+    r = ref.btbb_decode_payload(p) if h else 0
+    st = _pkt.ref_state(ref, p)
+    ref.btbb_packet_unref(p)
+    return present, h, r, st
+
+
+def _both_decode(orc, sym, clkn, uap, ctx=None):
+    """The oracle port's verdict and state -- and, where the compiled reference is at hand (it is on the GPU box: oracle/_ref
+    travels with the snapshot), the same from it, which must agree in every field the decoders write."""
+    got = _oracle_decode(orc, sym, clkn, uap)
+    ref = _libs.ref()
+    if ref is not None:
+        want = _ref_decode(ref, sym, clkn, uap)
+        assert got[:3] == want[:3], (ctx, got[:3], want[:3])
+        _pkt.assert_same(got[3], want[3], ctx)
+        _both_decode.with_ref += 1
+    return got
+
+
+_both_decode.with_ref = 0
+
+
 def test_batch_decode():
     orc = _libs.oracle()
     rng = np.random.default_rng(_libs.seed(32))
@@ -281,7 +319,7 @@ def test_long_payloads_leave_through_the_wave_phase():
         # (the oracle unwhitens whenever asked to decode: only whitened packets are compared with it)
         if not int(pin["flags"][i]) & 1:
             continue
-        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        present, h, r, stt = _both_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
         o = direct[i]
         assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, off, meta)
         if h:
@@ -337,7 +375,7 @@ def test_dm5_of_128_bytes_keeps_its_spare_block_bits_to_itself():
     for i, (st, off, meta) in enumerate(rows):
         assert out[i].tobytes() == two_step[i].tobytes(), (i, meta)
         s = np.ascontiguousarray(sym[st, off:off + int(lens[i])])
-        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        present, h, r, stt = _both_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
         o = out[i]
         assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, meta)
         assert h and int(o["payload_length"]) == stt["payload_length"] == 128, (i, meta)
@@ -398,7 +436,7 @@ def test_ev4_ev5_payloads_leave_through_the_wave_phase():
         if not int(pin["flags"][i]) & 1:
             continue
         s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
-        present, h, r, stt = _oracle_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
+        present, h, r, stt = _both_decode(orc, s, int(pin["clkn"][i]), int(pin["uap"][i]))
         o = direct[i]
         assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, off, meta)
         if h:
@@ -456,7 +494,7 @@ def test_ev5_lengths_found_by_the_prefix_over_the_lanes():
     for i in list(early) + list(range(0, n, 97)):
         st, off, uap, clk6 = rows[i]
         s = np.ascontiguousarray(sym[st, off:off + int(len_d[i])])
-        present, h, r, stt = _oracle_decode(orc, s, clk6, uap)
+        present, h, r, stt = _both_decode(orc, s, clk6, uap)
         o = direct[i]
         assert (int(o["header_present"]), int(o["header_rv"]), int(o["payload_rv"])) == (present, h, r), (i, rows[i])
         assert int(o["payload_length"]) == stt["payload_length"], (i, rows[i])
