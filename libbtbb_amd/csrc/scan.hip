@@ -736,7 +736,9 @@ template <int WGS> struct SlideGeom {
 // the pass loop then watches the ring's room and is left for a drain; the sparse form runs six passes blind and checks in
 // place the few candidates a full ring turns away (measured: the room test in every pass costs the sparse case 4 %, the
 // in-place path costs the dense case a factor of three).
-template <int TILES, int WGS, bool DENSE>
+// MSB: the words hold their symbols MSB first in every byte (BTBBX_FMT_PACKED_MSB); a template flag, not a run-time branch: the
+// branch alone cost the LSB path 1 % here and 7 % in scan_known_lap_kernel (the words' registers become merge points)
+template <int TILES, int WGS, bool DENSE, bool MSB>
 __global__ __launch_bounds__(SLIDE_THREADS) __attribute__((amdgpu_waves_per_eu(SLIDE_WAVES_PER_EU, SLIDE_WAVES_PER_EU)))
 void scan_slide_kernel(ScanArgs a)
 {
@@ -901,7 +903,7 @@ void scan_slide_kernel(ScanArgs a)
 		for (int u = 0; u < TILES; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
-			if (a.msb) {
+			if constexpr (MSB) {
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					d[u][k] = msb_dword(d[u][k]);
@@ -1264,7 +1266,7 @@ struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per s
 // LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
 // and / andn of the count planes; with the limit in a register it is sixteen instructions with SGPR masks), -1 = any
 // CLS = bit 23 of the LAP (the barker class of its sync word), -1 = not specialised
-template <int LIMIT, int CLS>
+template <int LIMIT, int CLS, bool MSB>
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
 	__shared__ KnownHit ring_mem[4][KRING];
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		for (int u = 0; u < KL_WORDS; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
 			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
-			if (a.msb) {
+			if constexpr (MSB) {
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					d[u][k] = msb_dword(d[u][k]);
@@ -1670,15 +1672,16 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
 			// (tables for 4 errors through this kernel -- one tile per trip, a drain after practically every pass: 58 % of the
 			// survivors are candidates there -- ran 6.26 ms per GiB against 3.27 for scan_lap_any_kernel<9>, round 3; removed)
+#define LAUNCH_SLIDE(DENSE_, MSB_) do { \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, DENSE_, MSB_>), \
+						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+			hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, DENSE_, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
 			if (table_errors >= 3) {
-				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>),
-							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, true>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+				if (msb) LAUNCH_SLIDE(true, true); else LAUNCH_SLIDE(true, false);
 			} else {
-				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, false>),
-							    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-				hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, false>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a);
+				if (msb) LAUNCH_SLIDE(false, true); else LAUNCH_SLIDE(false, false);
 			}
+#undef LAUNCH_SLIDE
 			break;
 		}
 		default: set_error("btbbx_scan: internal: no LAP_ANY kernel for this table set"); return BTBBX_E_ARG;
@@ -1712,8 +1715,9 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			return BTBBX_E_ARG;
 		}
 		const bool cls1 = ((a.syncword >> 57) & 1) != 0;          // = bit 23 of the LAP
-#define LAUNCH_KNOWN(L) do { if (cls1) hipLaunchKernelGGL((scan_known_lap_kernel<L, 1>), dim3((uint32_t)grid), dim3(256), 0, stream, a); \
-		else hipLaunchKernelGGL((scan_known_lap_kernel<L, 0>), dim3((uint32_t)grid), dim3(256), 0, stream, a); } while (0)
+#define LAUNCH_KNOWN_(L, C_, M_) hipLaunchKernelGGL((scan_known_lap_kernel<L, C_, M_>), dim3((uint32_t)grid), dim3(256), 0, stream, a)
+#define LAUNCH_KNOWN(L) do { if (cls1) { if (msb) LAUNCH_KNOWN_(L, 1, true); else LAUNCH_KNOWN_(L, 1, false); } \
+		else { if (msb) LAUNCH_KNOWN_(L, 0, true); else LAUNCH_KNOWN_(L, 0, false); } } while (0)
 		switch (max_ac_errors) {
 		case 0: LAUNCH_KNOWN(0); break;
 		case 1: LAUNCH_KNOWN(1); break;
@@ -1723,6 +1727,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		default: LAUNCH_KNOWN(-1); break;
 		}
 #undef LAUNCH_KNOWN
+#undef LAUNCH_KNOWN_
 #ifdef SCAN_PROFILE
 		{
 			unsigned long long prof[32], total = 0;

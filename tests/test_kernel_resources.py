@@ -67,7 +67,7 @@ def _waves_per_simd(vgprs):
 
 def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
     """2 x 768 threads per CU = 6 waves per SIMD; the set + rings are dynamic LDS (76 KiB per workgroup)."""
-    for pat in (r"scan_slide_kernelILi2ELi2ELb0E", r"scan_slide_kernelILi2ELi2ELb1E"):
+    for pat in (r"scan_slide_kernelILi2ELi2ELb0ELb0E", r"scan_slide_kernelILi2ELi2ELb1ELb0E", r"scan_slide_kernelILi2ELi2ELb0ELb1E"):
         k = _one(kernels, pat)
         assert k["vgpr_count"] <= 80 and _waves_per_simd(k["vgpr_count"]) >= 6, k
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
@@ -76,7 +76,7 @@ def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
 
 def test_known_lap_kernel_eight_waves_per_simd(kernels):
     for cls in (0, 1):
-        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dE" % cls)
+        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dELb0E" % cls)
         assert k["vgpr_count"] <= 64 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
         assert k["group_segment_fixed_size"] * 7 <= LDS_PER_CU, k
 
