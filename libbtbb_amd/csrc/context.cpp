@@ -447,6 +447,13 @@ static int upload_tables(int max_ac_errors)
 		const int rc_slide = build_slide_set(t, max_ac_errors, slide_bitmap);
 		if (rc_slide < 0)
 			return rc_slide;
+		// scan_slide_kernel lets a chain that has run out of survivors shift itself out: its index is then 0 or 1.  Those two
+		// must not be members, or a lane without a survivor would look like a candidate (true for every table set of this code;
+		// the tables for >= 4 errors run the probe kernels, which do not rely on it).
+		if (max_ac_errors <= 3 && (slide_bitmap[0] & 3u)) {
+			set_error("btbbx_init: internal: index 0 / 1 of the sliding checks is a member of the candidate set");
+			return BTBBX_E_ARG;
+		}
 	}
 
 	// one block: tabA | tabB | bitmap | slide bitmap
