@@ -72,6 +72,23 @@ static uint32_t host_crc_byte(uint32_t crc, uint32_t byte)
 
 int chain_upload(const HostTables &t)
 {
+	// trials_linear_kernel puts the trials of a batch into type order by arithmetic (its step 1b), which rests on one property of
+	// the whitening sequence: the four bits that whiten the header's type field (header bits 3 .. 6) take every value for
+	// exactly four of the 64 CLK1-6 candidates.  Checked here, once, on the table the kernels are built from.
+	{
+		int seen[16] = {0};
+		for (int clk = 0; clk < 64; clk++) {
+			uint32_t v = 0;
+			for (int j = 0; j < 4; j++)
+				v |= (uint32_t)t.whiten[(t.whiten_idx[clk] + 3 + j) % 127] << j;
+			seen[v]++;
+		}
+		for (int v = 0; v < 16; v++)
+			if (seen[v] != 4) {
+				set_error("btbbx_init: internal: the type-field whitening is not four clocks per value");
+				return BTBBX_E_ARG;
+			}
+	}
 	// the LDS image of the decoders
 	{
 		static ChainLds img;
@@ -1061,11 +1078,11 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ __attribute__((aligned(16))) uint16_t pw20[64];   // register after the 20 whitening bytes of an FHS attempt
 	__shared__ __attribute__((aligned(16))) uint16_t lin[LIN_MAXLEN * 16];
 	__shared__ __attribute__((aligned(16))) uint16_t advw[7 * 2 * 256];
-	__shared__ uint16_t order[TL_TRIALS], t_slot[TL_TRIALS];
+	__shared__ uint16_t order[TL_TRIALS];
 	__shared__ uint32_t t_info[TL_TRIALS];            // per trial: try_clock's return value | type << 8 | UAP << 16
 	__shared__ int16_t t_rv[TL_TRIALS];
-	__shared__ uint32_t type_count[16];
-	__shared__ uint32_t type_base_w[TL_THREADS / 64][16];
+	__shared__ uint32_t pk_sort[TL_PACKETS];          // per packet: type key | varies with the clock << 4 | rank among its like << 8
+	__shared__ uint32_t type_base[18];                // first trial slot of every type; [17] = packets whose type varies with the clock
 	// per packet
 	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
 	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];       // ... DV data at 202
@@ -1084,7 +1101,17 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	chain_lds_init();                                       // ends with a barrier
 	if (tid >= 64 && tid < 128) {
 		const uint32_t wb = (uint32_t)wh_bits(wh_start(tid - 64, 0), 18);
-		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (((wb >> 3) & 0xf) << 8));
+		// bits 12, 13: the clock's rank among the FOUR clocks that whiten the type field alike (the 64 clocks map onto the
+		// sixteen 4-bit values four times each -- an affine map of full rank; tables.cpp checks it on the host): with that,
+		// where a trial stands in type order is arithmetic (step 1b below)
+		const uint32_t wt = (wb >> 3) & 0xf;
+		uint32_t crank = 0;
+		for (uint32_t k = 0; k < 16; k++) {
+			const uint64_t mk = __ballot(wt == k);
+			if (wt == k)
+				crank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+		}
+		clk_ut[tid - 64] = (uint16_t)(uap_from_hec(wb & 0x3ff, wb >> 10) | (wt << 8) | (crank << 12));
 		const uint32_t v = (uint32_t)wh_bits(wh_start(tid - 64, 18), 7);
 		uint32_t x = 0;
 		for (int j = 0; j < 7; j++)
@@ -1136,8 +1163,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			else if (i < PK_ELEMS + IN_ELEMS)
 				reinterpret_cast<uint64_t *>(pin)[i - PK_ELEMS] = pre[k];
 		}
-		if (tid < 16)
-			type_count[tid] = 0;
 		if (tid < TL_PACKETS) {
 			a_fail[tid] = TL_A_BLOCKS;
 			b_fail[tid] = TL_B_BLOCKS;
@@ -1161,10 +1186,53 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	// that order, a wave's 64 consecutive entries being trials of ONE type except at the few type boundaries.
 	// (Trials are independent of each other -- the one cross-trial dependency of the reference, EV4 reading
 	// the llid / flow a previous trial left, cannot change a result, see do_EV4 -- so their order is free.)
-	if (tid < mine) {
-		uint32_t dis;
-		const uint32_t hdr = header_fec13(pk[tid], dis);
-		hdr_ut[tid] = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
+	// 1b. (round 5) The trial numbers in type order WITHOUT a sort over the 4096 trials.  The type of trial (packet, clock)
+	// is the packet's four raw type bits XOR four whitening bits that depend on the clock alone, and every 4-bit value is the
+	// whitening of exactly four clocks: a packet whose type varies with the clock (whitened, header FEC 1/3 decodable) puts
+	// exactly FOUR trials into EVERY type.  So type t starts at slot 4 nvar t + 64 x (packets of fixed type < t), the trial of
+	// varying packet number r and clock c is slot base[type] + 4 r + (rank of c among its four), and the 64 trials of a
+	// fixed-type packet (not whitened, or FEC 1/3 failed: SURVEY Q5) lie together behind them.  One wave ranks the 64 packets;
+	// rounds 2-4 counted every trial into its type with an LDS atomic (sixteen counters, 4096 atomics per batch) and scattered
+	// the trial numbers in a second pass behind a scan of the counters.
+	static_assert(TL_PACKETS == 64, "one wave ranks the packets of a batch");
+	if (tid < 64) {
+		const bool live = tid < mine;
+		uint32_t h = 0;
+		if (live) {
+			uint32_t dis;
+			const uint32_t hdr = header_fec13(pk[tid], dis);
+			h = uap_from_hec(hdr & 0x3ff, hdr >> 10) | (((hdr >> 3) & 0xf) << 8) | ((dis < 4 ? 1u : 0u) << 16);
+			hdr_ut[tid] = h;
+		}
+		const bool fec_ok = (h & 0x10000u) != 0;
+		const bool var = live && fec_ok && (pin[live ? tid : 0].flags & F_WHITENED);
+		const uint32_t key = !live ? 0u : fec_ok ? (h >> 8) & 0xfu : (uint32_t)pin[tid].type & 0xfu;
+		const uint64_t vm = __ballot(var);
+		const uint32_t nvar = (uint32_t)__popcll(vm);
+		uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0));
+		const bool fixed = live && !var;
+		uint32_t cf = 0;                                    // lane k: packets of fixed type k
+		if (__ballot(fixed)) {
+			for (uint32_t k = 0; k < 16; k++) {
+				const uint64_t fm = __ballot(fixed && key == k);
+				if (fixed && key == k)
+					rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+				if (lane == k)
+					cf = (uint32_t)__popcll(fm);
+			}
+		}
+		uint32_t incl = cf;
+#pragma unroll
+		for (int dd = 1; dd < 16; dd <<= 1) {
+			const uint32_t up = __shfl_up(incl, dd);
+			if (lane >= (uint32_t)dd)
+				incl += up;
+		}
+		if (lane < 17)
+			type_base[lane] = 4u * nvar * lane + 64u * (incl - cf);      // (lane 16: the end of the last type)
+		if (lane == 17)
+			type_base[17] = nvar;
+		pk_sort[tid] = key | ((var ? 1u : 0u) << 4) | (rank << 8);
 	}
 	// 2a. FEC 2/3 of both layouts: sixteen threads per packet (one quarter of a wave), sixteen blocks of the
 	// payload layout per round, and no further round once a block of the packet has failed -- nothing behind
@@ -1237,13 +1305,17 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		const uint32_t p = i >> 6;
 		const uint32_t h = hdr_ut[p];
 		uint32_t uap = pin[p].uap, type = pin[p].type, ret = 0;     // FEC 1/3 failure: nothing changes
+		const uint32_t ps = pk_sort[p], cu = clk_ut[lane];
 		if (h & 0x10000u) {
-			const uint32_t v = (h ^ ((pin[p].flags & F_WHITENED) ? clk_ut[lane] : 0u)) & 0xffff;
+			const uint32_t v = (h ^ ((pin[p].flags & F_WHITENED) ? (cu & 0xfffu) : 0u)) & 0xffff;
 			uap = ret = v & 0xff;
 			type = v >> 8;
 		}
 		t_info[i] = ret | (type << 8) | (uap << 16);
-		t_slot[i] = (uint16_t)atomicAdd(&type_count[type & 15], 1u);
+		// where this trial stands in type order (step 1b)
+		const uint32_t slot = (ps & 0x10u) ? type_base[type & 15] + 4u * (ps >> 8) + (cu >> 12)
+						   : type_base[type & 15] + 4u * type_base[17] + 64u * (ps >> 8) + lane;
+		order[slot] = (uint16_t)i;
 	}
 	// 2c. reg(0, data, 4 i) for the three layouts (raw: 86 words, FEC at 122: 58, FEC at 202: 4), in chunks of
 	// eight words = twenty chunks per packet: (i) every chunk from 0, all in parallel, storing the register in front
@@ -1318,23 +1390,6 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			chunk_reg[p][r0 + j] = (uint16_t)start;
 			start = g_lds.adv32[0][start & 0xff] ^ g_lds.adv32[1][start >> 8] ^ c;
 		}
-	}
-	// (round 4) no barrier here: the chunk starts above are wanted by the trials, not by the order pass, and where a type's
-	// trials start is worked out by every wave for itself from the sixteen counters (lanes 0 .. 15, a scan in registers)
-	// instead of by thread 0 in sixteen dependent LDS steps behind a barrier of their own
-	{
-		uint32_t c = lane < 16 ? type_count[lane] : 0u, incl = c;
-#pragma unroll
-		for (int d = 1; d < 16; d <<= 1) {
-			const uint32_t u = __shfl_up(incl, d);
-			if (lane >= (uint32_t)d)
-				incl += u;
-		}
-		if (lane < 16)
-			type_base_w[tid >> 6][lane] = incl - c;             // the wave's own copy (LDS operations of a wave complete in order)
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		for (uint32_t i = tid; i < total; i += TL_THREADS)
-			order[type_base_w[tid >> 6][(t_info[i] >> 8) & 15] + t_slot[i]] = (uint16_t)i;
 	}
 	__syncthreads();
 	TL_PROF(4);
