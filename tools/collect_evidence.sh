@@ -3,8 +3,8 @@
 #   tools/collect_evidence.sh gpurun_out/r04_v1 ; then, in the build container: python tools/make_traffic.py profiles/r04_v1
 #   csrc_sha16.txt    fingerprint of the sources measured (bench.csrc_fingerprint)
 #   bench.json        the default `python bench.py` line
-#   kernel_stats.csv  rocprofv3 --kernel-trace --stats over `python bench.py --steps 10 --warmup 2 --no-cpu` (headline AND the
-#                     secondary block: every kernel of configs 3 and 5 has a row)
+#   kernel_stats_<line>.csv  rocprofv3 --kernel-trace over ONE bench line at a time (headline: `bench.py --steps 10 --warmup 2
+#                     --no-cpu --no-secondary`; the others `--only-secondary <line>`), a row per kernel, warm-up launches dropped
 #   pmc_scan.json     separate --pmc passes (never combined with traces) over the headline loop: FETCH_SIZE, WRITE_SIZE, SQ_*
 #   pmc_sec_<line>.json  the same for ONE line of the secondary block at a time (bench.py --only-secondary <line>): a kernel's
 #                     mean per launch then belongs to one workload (the two config-3 captures share their kernels)
@@ -14,15 +14,14 @@ mkdir -p $out
 export TMPDIR=/tmp
 python -c "import bench; print(bench.csrc_fingerprint())" > $out/csrc_sha16.txt
 timeout 300 python bench.py 2>/dev/null | tail -1 > $out/bench.json
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu > /dev/null 2>&1 )
-find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
-rm -rf $out/stats
+# per-kernel durations: one file per bench line, warm-up launches dropped (tools/kstats_by_line.py)
+timeout 900 python tools/kstats_by_line.py $out > $out/kstats.log 2>&1
 timeout 300 python tools/pmc_collect.py --out $out/pmc --kernel scan_ --groups FETCH_SIZE WRITE_SIZE \
   SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES \
   SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
   -- python bench.py --steps 4 --warmup 1 --no-cpu --no-secondary > $out/pmc_scan.json 2> $out/pmc.err
 rm -rf $out/pmc
-for line in known_lap_79ch_chain_full_payloads known_lap_79ch_chain clk6_bruteforce clk6_bruteforce_all_types; do
+for line in lap_any_4gib_ordered known_lap_79ch_chain_full_payloads known_lap_79ch_chain clk6_bruteforce clk6_bruteforce_all_types; do
   timeout 300 python tools/pmc_collect.py --out $out/pmc2 --kernel "" --groups FETCH_SIZE WRITE_SIZE \
     SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_WAVE_CYCLES SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
     -- python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary $line > $out/pmc_sec_$line.json 2> $out/pmc2.err

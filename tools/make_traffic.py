@@ -29,7 +29,7 @@ json.dump({
     "source": "%s/pmc_scan.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 4 "
               "--warmup 1 --no-cpu` (tools/collect_evidence.sh)" % rel,
     "derivation": "(2 x FETCH_SIZE + WRITE_SIZE) KB x 1024; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for "
-                  "gfx950 and as calibrated on this kernel's own load shape (profiles/r01_calib: 0.5105 of the true bytes)",
+                  "gfx950 and as calibrated on this kernel's own load shape (profiles/r01_calib: 0.5105 of the true bytes) and on the packet kernels' shapes (profiles/r05_calib: every fabric request is a whole 128-byte line, tallied at 64)",
     "FETCH_SIZE_KB": pmc[name]["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc[name]["WRITE_SIZE"]["mean_per_launch"],
     "algorithmic_bytes_per_launch": alg, "ratio_to_algorithmic": round(b / alg, 3), "kernel": name + ", 4 GiB LAP_ANY bench workload",
     # the VALU-issue ceiling bench.py quotes next to the HBM roofline (roofline.valu): wave-instructions per launch from the same
@@ -45,8 +45,8 @@ print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / al
 out = {"csrc_sha16": fp, "source": "%s/pmc_sec_<line>.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
        "`python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary <line>` (one line of the block at a time: a kernel's mean "
        "per launch then belongs to one workload); (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
-CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel", "decode_long_kernel")
-for line, keys in (("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
+CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel")
+for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_")), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
                    ("clk6_bruteforce", ("trials_linear_kernel", "trials_wave_kernel")),
                    ("clk6_bruteforce_all_types", ("trials_linear_kernel", "trials_wave_kernel"))):
     path = os.path.join(d, "pmc_sec_%s.json" % line)
