@@ -39,7 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_MIN_PER_WORD = 124        # fewest vector instructions per 64 offsets of an exact LAP_ANY filter of this shape (30 + 30 + 8 x 8)
+VALU_MIN_PER_WORD = 124        # fewest vector instructions per 64 offsets of an exact LAP_ANY filter of this shape (NOTEBOOK.md 6.4 for the derivation: 30 + 30 + 8 x 8)
 SEED = 20260926
 STRIDE = 4096
 
@@ -856,8 +856,8 @@ def main():
                     valu = {"insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
                             "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kern_ms * 1e-3), 4)}
                     # ... and how far the instruction stream itself is from the fewest vector instructions ANY exact filter of
-                    # this shape needs per 64-bit stream word (7 barker planes + their adder tree for both halves
-                    # 30, the sliding check stream 30, eight survivors x (find, funnel shift, set address, bit test, clear) 72):
+                    # this shape needs per 64-bit stream word (NOTEBOOK.md 6.4: 7 barker planes + their adder tree for both halves
+                    # 30, the sliding check stream 30, eight survivors x eight instructions since round 5: 64):
                     # kernel time x bound / measured = what this kernel would take at its own measured issue rate
                     per_word = v["insts_per_launch"] / (nwords / 64.0)
                     valu["bound"] = {"min_valu_per_word": VALU_MIN_PER_WORD, "measured_valu_per_word": round(per_word, 1),

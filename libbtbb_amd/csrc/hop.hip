@@ -130,7 +130,7 @@ __device__ __forceinline__ uint32_t ctl_mask(uint32_t ctl, int k)
 	return (uint32_t)__builtin_amdgcn_sbfe((int)ctl, k, 1);          // 0 or ~0
 }
 
-// the 14 stages in array order (stage 0 first, see the composition note in DESIGN.md 3.6)
+// the 14 stages in array order (stage 0 first, see the composition note in NOTEBOOK.md 3.6)
 __device__ __forceinline__ void hop_permute_array(uint32_t (&r)[8], uint32_t ctl)
 {
 	swap_index_bits<0, 1>(r, ctl_mask(ctl, 0));

@@ -1831,7 +1831,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint64_t *packets, con
 //
 // A lane walking its packet word by word from HBM fetched 753 B per packet for ~300 needed (every 8-byte read
 // drags a 64-byte sector through the L2, profiles/traffic_secondary.json, round 2) and sat out a latency per step.
-// The kernel's phases now (DESIGN.md 3.4 has the numbers behind each):
+// The kernel's phases now (NOTEBOOK.md 3.4 has the numbers behind each):
 //   A  every lane loads its hit and, in one batch, words 1 .. 4 of its packet; from those it decodes the header and
 //      the payload header under its clock: the packet's type and EXACTLY how many symbols its decoder will read
 //   B  the workgroup's 256 packets change hands (counting sort on decoder and length): one decoder per wave

@@ -25,7 +25,7 @@
 //
 // scan_slide_kernel: two persistent 768-thread workgroups per CU (6 waves per SIMD; 64 KiB set + 12 KiB rings of LDS
 // each) stride over tiles of 768 words; scan_known_lap_kernel: 256-thread workgroups, tiles of 512 words.  Pure integer
-// work, no MFMA; bound by VALU issue, not by HBM (see DESIGN.md 3.1 / 6.3 for the roofline accounting).
+// work, no MFMA; bound by VALU issue, not by HBM (DESIGN.md 3.1 and 6 say what it is bound by).
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
@@ -283,7 +283,7 @@ constexpr SlideTapList slide_tap_list()
 }
 // 32 positions of the sliding check stream (slide.h): bit b = parity of the stream bits b + k over the taps k,
 // stream bit i = bit i of e2:e1:e0.  Taps and shifts are compile-time constants (a funnel shift by a
-// run-time amount costs more, see 3.2 of DESIGN.md).
+// run-time amount costs more, see 3.2 of NOTEBOOK.md).
 __device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e2)
 {
 	constexpr SlideTapList taps = slide_tap_list();

@@ -210,7 +210,7 @@ static void smap_put(uint64_t syndrome, uint64_t error)
 			return;
 		}
 		if (smap.key[h] == syndrome)
-			return;   /* cannot happen: minimum distance 14 */
+			return;   /* cannot happen: minimum distance 14 (see NOTEBOOK.md 4) */
 	}
 }
 

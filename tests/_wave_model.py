@@ -1,4 +1,4 @@
-"""A numpy model of ONE WAVE decoding ONE long packet -- the arithmetic a wave-per-packet
+"""A numpy model of ONE WAVE decoding ONE long packet (NOTEBOOK.md 9, item 4) -- the arithmetic a wave-per-packet
 `decode_hits` path for DH3 / DH5 / DM3 / DM5 would run, so that it can be checked against the oracle before a kernel
 exists.  64 lanes x one 64-bit word is a whole 3 125-symbol capture:
 

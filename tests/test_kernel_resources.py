@@ -66,7 +66,7 @@ def _waves_per_simd(vgprs):
 
 
 def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
-    """DESIGN 6.3: 2 x 768 threads per CU = 6 waves per SIMD; the set + rings are dynamic LDS (76 KiB per workgroup)."""
+    """DESIGN 3.1: 2 x 768 threads per CU = 6 waves per SIMD; the set + rings are dynamic LDS (76 KiB per workgroup)."""
     for pat in (r"scan_slide_kernelILi2ELi2ELb0ELb0E", r"scan_slide_kernelILi2ELi2ELb1ELb0E", r"scan_slide_kernelILi2ELi2ELb0ELb1E"):
         k = _one(kernels, pat)
         assert k["vgpr_count"] <= 80 and _waves_per_simd(k["vgpr_count"]) >= 6, k
@@ -82,7 +82,7 @@ def test_known_lap_kernel_eight_waves_per_simd(kernels):
 
 
 def test_decode_hits_kernel_six_workgroups_per_cu(kernels):
-    """256 threads, six workgroups per CU by LDS (stage + result copies + tables), six waves per SIMD by
+    """DESIGN 3.4 / NOTEBOOK 3.4: 256 threads, six workgroups per CU by LDS (stage + result copies + tables), six waves per SIMD by
     registers; the decoder state lives in registers (a few dwords of spill are tolerated, a PState in scratch is not)."""
     k = _one(kernels, r"decode_hits_kernel")
     assert k["vgpr_count"] <= 80, k

@@ -1,4 +1,4 @@
-"""The arithmetic of a wave-per-packet decoder for long packets (tests/_wave_model.py) against the
+"""The arithmetic of a wave-per-packet decoder for long packets (tests/_wave_model.py, NOTEBOOK.md 9 item 4) against the
 oracle: per-lane unwhitening of 64-bit payload words, FEC 2/3 three blocks per lane with the 30-bit pieces gathered
 into words, and the CRC as per-lane registers advanced by fixed matrices and XORed across the wave.  No kernel is
 involved: this pins the algorithm (bit order, block alignment, the reference's early returns) before one is written."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How many lock-step passes the LAP_ANY survivor loop needs, for the arrangement the kernel uses and for the
-alternatives DESIGN.md 9 talks about -- from the real barker pre-filter over a random stream, not from a binomial
+alternatives NOTEBOOK.md 6.3 / 9 talk about -- from the real barker pre-filter over a random stream, not from a binomial
 guess (windows at neighbouring offsets exclude each other, so counts per 32 offsets are narrower than binomial).
 CPU only:  python tools/lockstep_model.py [log2 of the number of symbols, default 24]
 
