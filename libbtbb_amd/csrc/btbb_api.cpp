@@ -152,8 +152,6 @@ static int ac_window_lookup(const char *stream, uint64_t search_length, uint32_t
 	if (stream < w.base || stream + search_length + 63 > w.base + w.n_sym)
 		return -1;
 	const uint64_t delta = (uint64_t)(stream - w.base);
-	if (memcmp(stream, w.copy + delta, search_length + 63) != 0)
-		return -1;
 	uint64_t lo = 0, hi = w.n_hits;              // first remembered match at or behind `delta`
 	while (lo < hi) {
 		const uint64_t mid = (lo + hi) / 2;
@@ -162,9 +160,17 @@ static int ac_window_lookup(const char *stream, uint64_t search_length, uint32_t
 		else
 			hi = mid;
 	}
-	if (lo == w.n_hits)
-		return w.found > w.n_hits ? -1 : 0;      // behind the last one remembered: only known when the list is complete
-	if (w.hits[lo].offset >= delta + search_length)
+	const bool inside = lo < w.n_hits && w.hits[lo].offset < delta + search_length;
+	if (!inside && lo == w.n_hits && w.found > w.n_hits)
+		return -1;                               // behind the last one remembered: only known when the list is complete
+	/* The answer rests on the symbols it was worked out from, and on no others: "first match at offset h" on the windows
+	 * that start in [delta, h], i.e. symbols [delta, h + 64); "none" on the whole window.  Comparing just those keeps a
+	 * walk over a buffer with N matches at one pass over the buffer in total (round 4 compared the rest of the window on
+	 * every call: N passes). */
+	const uint64_t depends = inside ? w.hits[lo].offset - delta + 64 : search_length + 63;
+	if (memcmp(stream, w.copy + delta, depends) != 0)
+		return -1;
+	if (!inside)
 		return 0;
 	*first = w.hits[lo];
 	first->offset -= delta;

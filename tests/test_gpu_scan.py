@@ -318,6 +318,18 @@ def test_find_ac_walk_is_answered_from_the_remembered_window_and_only_while_it_i
         sym[off + nxt + 200:off + nxt + 264] = planted          # and a new one stands 200 symbols behind where it was
     m = walk(sym, bt.LAP_ANY, 2, pkt, mutate=(5, change))
     assert m in (n_all, n_all + 1)
+    # (round 5: a call compares only the symbols its answer rests on -- up to the end of the match it returns.)  A change
+    # FAR in front of the cursor, behind several matches still to come, must be seen when the walk gets there
+    def change_far(off):
+        p = off
+        for _ in range(4):
+            nxt = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + p), len(sym) - 63 - p, bt.LAP_ANY, 2, C.byref(C.c_uint32(0)), C.byref(C.c_uint8(0)))
+            assert nxt >= 0
+            p += nxt + 1
+        sym[p - 1 + 5:p - 1 + 25] ^= 1                          # the fourth match from here is gone
+        sym[p + 300:p + 364] = synth.access_code(0x5C3A91)[:64]  # and another one stands behind it
+    m2 = walk(sym, bt.LAP_ANY, 2, pkt, mutate=(3, change_far))
+    assert abs(m2 - m) <= 1
     # parameters alternate call by call on one buffer; windows with other ends
     for k in range(12):
         off = int(rng.integers(0, len(sym) - 3000))
