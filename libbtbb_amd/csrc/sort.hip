@@ -8,7 +8,7 @@
 //
 //   1. extent:   max offset / max stream of the list (the count itself is read from HBM: no `n` from the host)
 //   2. buckets:  lin = stream * (max_offset + 1) + offset, bucket = lin >> shift with as many buckets as the
-//                list can have records (<= 2^22): histogram, exclusive scan, scatter -- records grouped by bucket
+//                list can have records (<= 2^24): histogram, exclusive scan, scatter -- records grouped by bucket
 //   3. rank:     inside a bucket the rank of a record is the number of bucket-mates with a smaller key: for the
 //                usual handful of mates a loop over them; for a crowded bucket (a stream made of sync words) a
 //                presence bitmap of the bucket's 2^shift possible keys in LDS and a prefix popcount -- O(k), and
@@ -38,7 +38,9 @@ struct OrderParams {
 };
 
 #define ORDER_SMALL 48u                        // bucket-mates up to here are ranked by a plain loop
-#define ORDER_SCAN_ITEMS 4                     // counters per thread of the scan kernels (1024 threads)
+#define ORDER_MAX_LOG2 24                      // at most 1024 workgroups x 1024 threads x 16 counters per thread in the scans of the counts
+                                               // (four per thread up to 2^22 buckets: lists of up to 4 M records; sixteen for longer ones --
+                                               // the 4 GiB LAP_ANY list of 6.4 M records: 2^22 buckets 0.63 ms, 2^24 0.37 ms of ordering)
 #define ORDER_BIG_BITS 20                      // a crowded bucket's presence bitmap covers 2^20 keys at a time (128 KiB of LDS)
 #define ORDER_PAIRS 4096u                      // crowded buckets up to here: every record against every other
 
@@ -158,6 +160,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 
 // (bounds_streams != 0: the caller knows the list's bounds, and thread 0 of the grid writes the parameters
 // order_bounds_kernel would have -- one launch less on the stream)
+template <int ORDER_SCAN_ITEMS>
 __global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums, OrderParams *p,
 							       const uint32_t *d_count, uint32_t n_imm, uint32_t cap, uint32_t nb_log2,
 							       uint32_t bounds_streams, unsigned long long max_offset)
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *c
 
 // every workgroup adds up the sums of the workgroups before it itself (at most 1024 numbers from L2: cheaper than a
 // launch for a one-workgroup scan in between)
+template <int ORDER_SCAN_ITEMS>
 __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, uint32_t nb, const uint32_t *block_sums)
 {
 	__shared__ uint32_t lds_wave[16];
@@ -411,9 +415,9 @@ __global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *gr
 
 static uint32_t order_nb_log2(uint32_t cap)
 {
-	// as many buckets as the list can have records, 2^8 .. 2^22
+	// as many buckets as the list can have records, 2^8 .. 2^ORDER_MAX_LOG2
 	uint32_t l = 8;
-	while (l < 22 && (1u << l) < cap)
+	while (l < ORDER_MAX_LOG2 && (1u << l) < cap)
 		l++;
 	return l;
 }
@@ -436,10 +440,10 @@ static OrderLayout order_layout(uint32_t cap, uint32_t n_streams = 0, unsigned l
 {
 	OrderLayout L;
 	L.nb_log2 = order_nb_log2(cap);
-	// (at most 2^22 buckets either way: the scans of the counts run as up to 1024 workgroups of 4096 counters)
-	const size_t nb_most = (size_t)1 << (L.nb_log2 < 22 ? L.nb_log2 + 1 : 22);
+	// (at most 2^ORDER_MAX_LOG2 buckets either way: the scans of the counts run as up to 1024 workgroups of 1024 x ORDER_SCAN_ITEMS counters)
+	const size_t nb_most = (size_t)1 << (L.nb_log2 < ORDER_MAX_LOG2 ? L.nb_log2 + 1 : ORDER_MAX_LOG2);
 	L.nb = 1u << L.nb_log2;
-	if (n_streams && L.nb_log2 < 22) {
+	if (n_streams && L.nb_log2 < ORDER_MAX_LOG2) {
 		L.nb_log2 += 1;
 		L.nb = order_fine_buckets(n_streams, mul, L.nb_log2);
 	}
@@ -517,15 +521,23 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 			(void)hipEventRecord(ev[n_ev++], stream);
 	};
 	mark();
-	const uint32_t scan_blocks = (nb + 1024 * ORDER_SCAN_ITEMS - 1) / (1024 * ORDER_SCAN_ITEMS);
-	if (scan_blocks > 1024) {                           // (order_layout keeps nb <= 2^22; order_scan_apply_kernel adds up 1024 sums)
+	const uint32_t scan_items = nb <= (1u << 22) ? 4u : 16u;
+	const uint32_t scan_blocks = (nb + 1024 * scan_items - 1) / (1024 * scan_items);
+	if (scan_blocks > 1024) {                           // (order_layout keeps nb <= 2^ORDER_MAX_LOG2; order_scan_apply_kernel adds up 1024 sums)
 		set_error("btbbx_order_hits_device: %u buckets", nb);
 		return BTBBX_E_ARG;
 	}
-	hipLaunchKernelGGL(order_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
-			   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
-	mark();
-	hipLaunchKernelGGL(order_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	if (scan_items == 4) {
+		hipLaunchKernelGGL(order_scan_sums_kernel<4>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
+				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+		mark();
+		hipLaunchKernelGGL(order_scan_apply_kernel<4>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	} else {
+		hipLaunchKernelGGL(order_scan_sums_kernel<16>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
+				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+		mark();
+		hipLaunchKernelGGL(order_scan_apply_kernel<16>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+	}
 	mark();
 	if (counted_by_scan) {
 		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records that share a bucket

@@ -497,6 +497,11 @@ def test_device_hit_order_with_the_count_in_hbm():
     run(hits(off, st), cap=79 * 16000 + 5000, bounded=1)               # bounds given: exactly the extent ...
     run(hits(off, st), cap=79 * 16000 + 5000, bounded=12345)           # ... and loose ones
     run(hits(off, st)[:3000], cap=2000, count=3000)                    # the counter ran past the capacity
+    # a list of more than 4 M records (round 5: up to 2^24 buckets, sixteen counters per thread in the scans of the counts):
+    # 6 M hits of one stream, one per ~5 400 offsets of 2^35 as in the headline's list, with and without bounds
+    big = np.sort(rng.choice(1 << 35, 6_000_000, replace=False)).astype(np.uint64)
+    run(hits(big, 0), cap=len(big) + 70_000)
+    run(hits(big, 0), cap=len(big) + 70_000, bounded=1)
     # crowded: 300 000 consecutive offsets (a stream made of sync words) next to sparse ones
     off = np.concatenate([np.arange(5_000_000, 5_300_000), rng.choice(1 << 33, 50000, replace=False)]).astype(np.uint64)
     run(hits(np.unique(off), 0), cap=400000)
@@ -530,7 +535,9 @@ def test_scan_ordered_device(lap):
     d_w = bt.DeviceBuffer(buf.nbytes).upload(buf)
     # (capacities around 2^21 and 2^22: the bucket count of the ordering -- one more bit when the caller gives the bounds -- is at
     # its largest there)
-    for cap in (len(want) + 100, len(want) // 3, (1 << 21) - 3, (1 << 21) + 1, (1 << 22) + 5):
+    # (... and beyond 2^22: round 5 lets lists of more than 4 M records have up to 2^24 buckets, sixteen counters per thread in the
+    # scans of the counts)
+    for cap in (len(want) + 100, len(want) // 3, (1 << 21) - 3, (1 << 21) + 1, (1 << 22) + 5, (1 << 23) + 5, (1 << 24) + 3):
         d_h = bt.DeviceBuffer(cap * 16).zero()
         d_c = bt.DeviceBuffer(16).zero()
         sb = lib.btbbx_order_hits_scratch_bytes(cap)
