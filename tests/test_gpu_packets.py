@@ -584,6 +584,23 @@ def test_piconet_decode_entry_equals_the_per_packet_form():
     assert good > 300                                             # the packets built for the entry's clock decode with it
     assert lib.btbbx_decode_hits_piconet_device(d_w.ptr, n_words, n_words, d_h.ptr, None, n, entry.ctypes.data_as(C.c_void_p), 0,
                                                 bt.MAX_SYMBOLS, d_w.ptr, None, None) < 0          # clk_div = 0 is refused
+    # (round 5) a buffer that starts `phase` symbols into a slot: clock = entry.clkn + (offset + phase) / clk_div; the entry's
+    # length field, which the kernel uses to carry the phase, is ignored whatever the caller left in it
+    for clk_div, phase, base in ((625, 0, 77), (625, 1, 77), (625, 624, 77), (4096, 3000, 0x3FFFFF0)):
+        entry["clkn"], entry["flags"], entry["uap"], entry["length"] = base, flags, uap, 12345
+        pin = np.zeros(n, bt.PKTIN_DTYPE)
+        pin["clkn"] = ((base + (hits["offset"] + np.uint64(phase)) // np.uint64(clk_div)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        pin["flags"], pin["uap"] = flags, uap
+        want, _ = bt.run_decode_hits(words, hits, pin)
+        d_out = bt.DeviceBuffer(n * bt.PKTOUT_DTYPE.itemsize).zero()
+        bt.check(lib.btbbx_decode_hits_piconet_phase_device(d_w.ptr, n_words, n_words, d_h.ptr, None, n, entry.ctypes.data_as(C.c_void_p),
+                                                            clk_div, phase, bt.MAX_SYMBOLS, d_out.ptr, None, None), "piconet_phase")
+        bt.check(lib.btbbx_sync(None))
+        got = d_out.download(bt.PKTOUT_DTYPE, n)
+        assert got.tobytes() == want.tobytes(), (clk_div, phase, [i for i in range(n) if got[i].tobytes() != want[i].tobytes()][:5])
+        d_out.free()
+    assert lib.btbbx_decode_hits_piconet_phase_device(d_w.ptr, n_words, n_words, d_h.ptr, None, n, entry.ctypes.data_as(C.c_void_p), 625,
+                                                      625, bt.MAX_SYMBOLS, d_w.ptr, None, None) < 0  # phase >= clk_div is refused
     d_w.free()
     d_h.free()
 
