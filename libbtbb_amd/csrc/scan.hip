@@ -12,10 +12,11 @@
 //      once; a carry-save adder counts mismatches against 0x27 and `count in {0,1,6,7}`
 //      is BARKER_DISTANCE[window] <= 1.  1/8 of the offsets survive.
 //   2. bit-sliced check stream (slide.h): the (64,30) code is cyclic, so ONE sparse parity check slides over the
-//      window; 19 consecutive bits of the check stream at a survivor's offset are its candidate index -- one
-//      funnel shift and ONE read of a 2^19-bit set in LDS per survivor (the set = every index a window the
-//      reference accepts can have: gen_syndrome :147-159 and the map of :161-185 are linear in the same code).
-//      0.30 % pass.
+//      window; 19 consecutive bits of the check stream at a survivor's offset are its candidate index.  A chain of 32
+//      offsets is a pair of shift registers (survivor mask, check bits) moved down to the survivor in hand, so the
+//      index is the low 19 bits: ONE read of a 2^19-bit set in LDS per survivor (the set = every index a window the
+//      reference accepts can have: gen_syndrome :147-159 and the map of :161-185 are linear in the same code; its
+//      words lie bit-reversed, membership is one signed compare).  0.30 % pass.
 //   3. candidates go straight to a per-wave LDS ring and are verified up to 64 at a time with the
 //      exact reference rule: full 34-bit syndrome, open-addressing lookup of the
 //      error pattern, popcount <= max_ac_errors, LAP from the corrected word
@@ -703,9 +704,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 //
 // The kernel of the headline path (promiscuous_packet_search, bluetooth_packet.c:368-420).  Per trip of
 // TILES tiles: the bit-sliced barker filter (barker32) and the check stream (slide32, slide.h) for both
-// halves of the lane's words, then the lock-step survivor loop -- one funnel shift into the check stream and
-// ONE read of the 2^SLIDE_BITS-bit candidate set in LDS per survivor.  A candidate goes straight to the wave's
-// ring in LDS (ballot + mbcnt, no atomics); the exact reference rule (verify_lap_any, syndrome tables read
+// halves of the lane's words, then the lock-step survivor loop -- eight vector instructions and ONE read of the
+// 2^SLIDE_BITS-bit candidate set in LDS per survivor (chains as shift registers, round 5).  A candidate goes straight to
+// the wave's ring in LDS (the membership compare's lane mask + mbcnt, no atomics); the exact reference rule (verify_lap_any, syndrome tables read
 // through L2) runs on ring batches of up to 64.  The ring is the only LDS besides the set, so TWO workgroups
 // fit a CU: 2 x 768 threads = 6 waves per SIMD at <= 80 VGPRs (76 KiB of LDS each).  Measured on one box,
 // 4 GiB, ms per launch (profiles/r03_ab/): one 1024-thread workgroup per CU (4 waves per SIMD) 4.12, 2 x 1024
