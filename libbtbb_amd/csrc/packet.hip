@@ -1047,9 +1047,11 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 	return *(volatile __attribute__((address_space(3))) const uint32_t *)p;
 }
 
+#ifndef TL_THREADS
 #define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
+#endif
 #define TL_PACKETS (TL_THREADS / 16)
-#define TL_WGS_PER_CU 1
+#define TL_WGS_PER_CU (1024 / TL_THREADS)
 #define TL_TRIALS  (TL_PACKETS * 64)
 #define TL_A_BLOCKS 183                     // DM5: 228 bytes = 1824 bits
 #define TL_A_BYTES  232                     // >= 229, multiple of 4
@@ -1068,7 +1070,7 @@ __device__ unsigned long long g_tl_prof[16];
 #define TL_PROF_END do { } while (0)
 #endif
 #define TL_AFAIL(p) lds_now(&a_fail[p])
-__global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
+__global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void trials_linear_kernel(const uint64_t *packets, const btbbx_pkt_in *in,
 							     uint32_t n_packets, btbbx_trial *trials)
 {
 	__shared__ uint64_t pk[TL_PACKETS][BTBBX_PKT_WORDS + 1];
@@ -1084,11 +1086,16 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	__shared__ uint32_t pk_sort[TL_PACKETS];          // per packet: type key | varies with the clock << 4 | rank among its like << 8
 	__shared__ uint32_t type_base[18];                // first trial slot of every type; [17] = packets whose type varies with the clock
 	// per packet
-	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 1];       // decoded 10-bit groups, payload at 122
+	// (a10 is dead behind step 2a, the barrier that follows it separates it from step 2c: its rows are then the packet's p4a and
+	// p4c rows.  93 dwords per row: odd, so the rows of consecutive packets start in different banks.)
+	__shared__ uint16_t a10[TL_PACKETS][TL_A_BLOCKS + 3];       // decoded 10-bit groups, payload at 122
+	static_assert(TL_A_BYTES / 4 + LIN_MAXLEN / 4 <= TL_A_BLOCKS + 3, "p4a and p4c of a packet lie in its a10 row");
 	__shared__ uint16_t b10[TL_PACKETS][TL_B_BLOCKS + 2];       // ... DV data at 202
 	__shared__ uint32_t a_bytes[TL_PACKETS][TL_A_BYTES / 4], b_bytes[TL_PACKETS][TL_B_BYTES / 4];
 	__shared__ uint32_t a_fail[TL_PACKETS], b_fail[TL_PACKETS]; // first undecodable block
-	__shared__ uint16_t p4a[TL_PACKETS][TL_A_BYTES / 4], p4b[TL_PACKETS][TL_B_BYTES / 4], p4c[TL_PACKETS][LIN_MAXLEN / 4];
+	__shared__ uint16_t p4b[TL_PACKETS][TL_B_BYTES / 4];
+	auto p4a = [&](uint32_t p) { return &a10[p][0]; };
+	auto p4c = [&](uint32_t p) { return &a10[p][TL_A_BYTES / 4]; };
 	__shared__ int8_t hv_rv[TL_PACKETS];
 	__shared__ uint16_t chunk_reg[TL_PACKETS][20];
 	const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1194,7 +1201,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 	// fixed-type packet (not whitened, or FEC 1/3 failed: SURVEY Q5) lie together behind them.  One wave ranks the 64 packets;
 	// rounds 2-4 counted every trial into its type with an LDS atomic (sixteen counters, 4096 atomics per batch) and scattered
 	// the trial numbers in a second pass behind a scan of the counters.
-	static_assert(TL_PACKETS == 64, "one wave ranks the packets of a batch");
+	static_assert(TL_PACKETS <= 64, "one wave ranks the packets of a batch");
 	if (tid < 64) {
 		const bool live = tid < mine;
 		uint32_t h = 0;
@@ -1232,7 +1239,8 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			type_base[lane] = 4u * nvar * lane + 64u * (incl - cf);      // (lane 16: the end of the last type)
 		if (lane == 17)
 			type_base[17] = nvar;
-		pk_sort[tid] = key | ((var ? 1u : 0u) << 4) | (rank << 8);
+		if (tid < TL_PACKETS)
+			pk_sort[tid] = key | ((var ? 1u : 0u) << 4) | (rank << 8);
 	}
 	// 2a. FEC 2/3 of both layouts: sixteen threads per packet (one quarter of a wave), sixteen blocks of the
 	// payload layout per round, and no further round once a block of the packet has failed -- nothing behind
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 			continue;
 		uint32_t w8[8];
 		chunk_words(p, layout, j, nwords, w8);
-		uint16_t *dst = layout == 0 ? p4c[p] : layout == 1 ? p4a[p] : p4b[p];
+		uint16_t *dst = layout == 0 ? p4c(p) : layout == 1 ? p4a(p) : p4b[p];
 #pragma unroll
 		for (uint32_t i = 0; i < 8; i++)
 			if (i < nwords) {
@@ -1430,8 +1438,8 @@ __global__ __launch_bounds__(TL_THREADS) void trials_linear_kernel(const uint64_
 		auto data_reg = [&](int layout, uint32_t L) {
 			const uint32_t q = L >> 2, r = L & 3;
 			uint32_t crc, w;
-			if (layout == 0) { crc = p4c[p][q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
-			else if (layout == 1) { crc = p4a[p][q]; w = r ? a_bytes[p][q] : 0; }
+			if (layout == 0) { crc = p4c(p)[q]; w = r ? pk_bits32(pk[p], 122 + 32 * q, 32) : 0; }
+			else if (layout == 1) { crc = p4a(p)[q]; w = r ? a_bytes[p][q] : 0; }
 			else { crc = p4b[p][q]; w = r ? b_bytes[p][q] : 0; }
 			// + the chunk's start register carried to word q
 			const uint32_t start = chunk_reg[p][(layout == 0 ? 0u : layout == 1 ? 11u : 19u) + (q >> 3)], iw = q & 7;

@@ -1031,24 +1031,31 @@ void scan_slide_kernel(ScanArgs a)
 		// a pass then looks at the chains one by one and skips those that are empty wave-wide (the same ballots are the
 		// loop's exit test), instead of paying the full pass for two or three lanes.
 		auto sparse_tail = [&]() {
-			for (;;) {
+			uint64_t live[TILES][2], anyl = 0;
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					live[u][h] = __ballot(m[u][h] != 0);
+					anyl |= live[u][h];
+				}
+			while (anyl) {
 				Stage g;
 				uint64_t cms[TILES][2], anyc = 0;
-				bool any = false;
+				anyl = 0;
 #pragma unroll
 				for (int u = 0; u < TILES; u++)
 #pragma unroll
 					for (int h = 0; h < 2; h++) {
 						cms[u][h] = 0;
-						if (!__ballot(m[u][h] != 0))
+						if (!live[u][h])
 							continue;
-						any = true;
 						step(u, h, g);
 						cms[u][h] = member(u, h, g);
 						anyc |= cms[u][h];
+						live[u][h] = __ballot(m[u][h] != 0);
+						anyl |= live[u][h];
 					}
-				if (!any)
-					break;
 				if (anyc)
 					events(cms);
 			}
