@@ -24,7 +24,6 @@
 #define TABA_FIRST     34                  // the (64,30) code is systematic: window bits 0..33 are their own syndrome,
 #define TABA_BITS      11                  //   only bits 34..56 need tables: 34..44 (tabA) and
 #define TABB_BITS      12                  //   45..56 (tabB, with the class-0 barker / PN constant folded in)
-#define BITMAP_BITS    19                  // projection width of the candidate bitmap
 #define QRING          128                 // per-wave candidate ring (entries; it never holds more than 127)
 #ifndef SCAN_UNROLL
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
@@ -38,11 +37,9 @@
 // probe needs no address adds.
 #define LDS_TABB_WORDS   (1u << TABB_BITS)            // 4096 u32  = 16 KiB
 #define LDS_TABA_WORDS   (1u << TABA_BITS)            // 2048 u32  =  8 KiB
-#define LDS_BITMAP_WORDS (1u << (BITMAP_BITS - 5))    // 16384 u32 = 64 KiB
 #define LDS_OFF_TABB     0u
 #define LDS_OFF_TABA     (LDS_OFF_TABB + 4u * LDS_TABB_WORDS)
-#define LDS_OFF_BITMAP   (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)
-#define LDS_OFF_QUEUE    (LDS_OFF_BITMAP + 4u * LDS_BITMAP_WORDS)             // 16 x QRING candidates
+#define LDS_OFF_QUEUE    (LDS_OFF_TABA + 4u * LDS_TABA_WORDS)                 // 16 x QRING candidates
 #define LDS_OFF_PARK     (LDS_OFF_QUEUE + CAND_BYTES * SCAN_WAVES * QRING)    // 16 x 64 x PARK_SLOTS candidates
 #define LDS_OFF_PROF     (LDS_OFF_PARK + CAND_BYTES * SCAN_WAVES * 64u * PARK_SLOTS)   // -DSCAN_PROFILE: 32 counters per wave
 #ifdef SCAN_PROFILE
@@ -55,13 +52,14 @@
 struct ScanTables {
 	const uint32_t *tabA;      // [2048]   low-32 syndrome of window bits 34..44
 	const uint32_t *tabB;      // [4096]   low-32 syndrome of bits 45..56 ^ class-0 constant
-	const uint32_t *bitmap;    // 2^BITMAP_BITS-bit set: projection of acceptable syndromes
 	const uint32_t *slide_bitmap;  // 2^SLIDE_BITS-bit set over the sliding checks (slide.h), PN constant folded in
 	const uint64_t *hslots;    // open-addressing table of packed (syndrome, positions)
 	uint64_t hmask;            // slots - 1
 	uint64_t kclass[2];        // full syndrome of (corrected barker | pn), class 0 / 1
 	uint32_t kdiff;            // low 32 bits of kclass[0] ^ kclass[1]
 	uint64_t hi_mask[2];       // window bits (0..56) whose syndrome has bit 32 / bit 33 set
+	const uint32_t *slide4_bitmap;  // tables for four errors: 2^SLIDE4_BITS-bit set over the checks SLIDE4_TAPS (LDS, one workgroup per CU) ...
+	const uint32_t *slide4b_bitmap; // ... and the 2^SLIDE4B_BITS-bit set over SLIDE4B_TAPS its members are looked up in (L2), words bit-reversed; else null
 	const uint32_t *bitmap2;   // second-level filter in global memory (tables for >= 3 errors), or null
 	uint32_t bitmap2_shift;    // index = (low32 * golden) >> shift
 };

@@ -268,7 +268,6 @@ static inline uint32_t hslot_hash(uint64_t key)
 
 struct MapBuilder {
 	std::vector<uint64_t> slots;
-	std::vector<uint32_t> bitmap;
 	std::vector<uint32_t> bitmap2;   // empty = not used
 	int shift2 = 0;
 	uint64_t mask;
@@ -284,8 +283,6 @@ struct MapBuilder {
 		while (slots[h] != HSLOT_EMPTY)
 			h = (h + 1) & mask;
 		slots[h] = packed;
-		uint32_t proj = (uint32_t)syndrome & ((1u << BITMAP_BITS) - 1);
-		bitmap[proj >> 5] |= 1u << (proj & 31);
 		if (!bitmap2.empty()) {
 			const uint32_t i2 = ((uint32_t)syndrome * 0x9E3779B1u) >> shift2;
 			bitmap2[i2 >> 5] |= 1u << (i2 & 31);
@@ -311,11 +308,13 @@ struct MapBuilder {
 // the bits 0..56 (the map's patterns reach bit 57, which the checks do not touch), so its index is K ^ the
 // XOR of that many columns.  Host only.  Returns the number of members or a negative error.
 #define SLIDE_WORDS (1u << (SLIDE_BITS - 5))
-static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<uint32_t> &slide_bitmap)
+// the set of values `bits` positions of the check `taps` can take (XOR their value over PN) for a window the reference
+// accepts with tables for max_ac_errors: sums of at most that many columns
+static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<uint32_t> &slide_bitmap,
+			   const int bits = SLIDE_BITS, const uint64_t taps = SLIDE_TAPS)
 {
-	slide_bitmap.assign(SLIDE_WORDS, 0);
-	const uint64_t taps = SLIDE_TAPS;
-	for (int b = 0; b < SLIDE_BITS; b++)           // every check must annihilate every codeword
+	slide_bitmap.assign(1u << (bits - 5), 0);
+	for (int b = 0; b < bits; b++)           // every check must annihilate every codeword
 		for (int r = 0; r < 30; r++) {
 			const uint64_t row = (1ULL << (34 + r)) | t.col[34 + r];
 			if (((taps << b) >> 57) || (__builtin_popcountll(row & (taps << b)) & 1)) {
@@ -324,11 +323,11 @@ static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<u
 			}
 		}
 	uint32_t colv[57], k_pn = 0;
-	for (int b = 0; b < SLIDE_BITS; b++)
+	for (int b = 0; b < bits; b++)
 		k_pn |= (uint32_t)(__builtin_popcountll(SW_PN & (taps << b)) & 1) << b;
 	for (int i = 0; i < 57; i++) {
 		colv[i] = 0;
-		for (int b = 0; b < SLIDE_BITS; b++)
+		for (int b = 0; b < bits; b++)
 			if (i >= b && ((taps >> (i - b)) & 1))
 				colv[i] |= 1u << b;
 	}
@@ -406,10 +405,8 @@ static int upload_tables(int max_ac_errors)
 		bits++;
 	MapBuilder mb;
 	mb.slots.assign(1ULL << bits, HSLOT_EMPTY);
-	mb.bitmap.assign(LDS_BITMAP_WORDS, 0);
 	mb.mask = (1ULL << bits) - 1;
 	mb.shift = 32 - bits;
-	mb.bitmap[0] |= 1u;                     // the zero syndrome (error-free codeword)
 	if (max_ac_errors >= 3) {
 		// With 32 567 (3 errors) .. 5.0 M (5) patterns the 2^19-bit LDS bitmap passes 6 % .. 100 %
 		// of the survivors; a 2^26-bit bitmap over a hash of the low 32 syndrome bits (8 MiB, L2 /
@@ -456,10 +453,44 @@ static int upload_tables(int max_ac_errors)
 		}
 	}
 
-	// one block: tabA | tabB | bitmap | slide bitmap
+	// tables for four errors: the two sets of scan_slide_kernel's two-level form (slide.h)
+	std::vector<uint32_t> slide4, slide4b;
+	if (max_ac_errors == 4) {
+		int rc4 = build_slide_set(t, 4, slide4, SLIDE4_BITS, SLIDE4_TAPS);
+		if (rc4 >= 0)
+			rc4 = build_slide_set(t, 4, slide4b, SLIDE4B_BITS, SLIDE4B_TAPS);
+		if (rc4 < 0)
+			return rc4;
+		// An idle chain of the kernel indexes 0 or 1 (see above), and with four errors the all-zero value of these twenty checks
+		// IS a sum of four columns and PN's -- its complement is not: the kernel for four errors runs on the COMPLEMENTED check
+		// stream (Slide4::INVERT in scan.hip), so member i stands at index ~i here.
+		{
+			std::vector<uint32_t> inv(slide4.size(), 0);
+			const uint32_t full = (1u << SLIDE4_BITS) - 1;
+			for (uint32_t i = 0; i <= full; i++)
+				if ((slide4[i >> 5] >> (i & 31)) & 1)
+					inv[(i ^ full) >> 5] |= 1u << ((i ^ full) & 31);
+			slide4.swap(inv);
+		}
+		if (slide4[0] & 3u) {
+			set_error("btbbx_init: internal: index 0 / 1 of the sliding checks is a member of the candidate set");
+			return BTBBX_E_ARG;
+		}
+		// the second level is read from global memory one word per probe: stored the way the kernel tests it, member bit of
+		// index i at bit 31 - (i & 31) (a left shift by i brings it to the sign)
+		for (uint32_t &w : slide4b) {
+			uint32_t r = 0;
+			for (int k = 0; k < 32; k++)
+				r |= ((w >> k) & 1u) << (31 - k);
+			w = r;
+		}
+	}
+
+	// one block: tabA | tabB | bitmap | slide bitmap | the two sets for four errors
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
-	size_t off_s = off_m + 4 * LDS_BITMAP_WORDS;
-	size_t total = off_s + 4 * SLIDE_WORDS;
+	size_t off_s = off_m;
+	size_t off_s4 = off_s + 4 * SLIDE_WORDS, off_s4b = off_s4 + 4 * slide4.size();
+	size_t total = off_s4b + 4 * slide4b.size();
 	// Build the new set beside the old one and swap only when every copy has succeeded: a failure
 	// leaves the context as it was; the replaced set outlives the swap by one re-build (see below).
 	struct Fresh {
@@ -475,8 +506,11 @@ static int upload_tables(int max_ac_errors)
 	char *base = (char *)fresh.tab;
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(base + off_m, mb.bitmap.data(), 4 * LDS_BITMAP_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_s, slide_bitmap.data(), 4 * SLIDE_WORDS, hipMemcpyHostToDevice));
+	if (!slide4.empty()) {
+		HIP_TRY(hipMemcpy(base + off_s4, slide4.data(), 4 * slide4.size(), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(base + off_s4b, slide4b.data(), 4 * slide4b.size(), hipMemcpyHostToDevice));
+	}
 	HIP_TRY(hipMemcpy(fresh.hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipDeviceSynchronize());                   // scans queued on any stream still read the old tables
 	// The set just replaced is not freed here: a launcher on another thread may have copied `c.scan` (the old
@@ -498,8 +532,9 @@ static int upload_tables(int max_ac_errors)
 	base = (char *)c.d_tab_block;
 	c.scan.tabA = (const uint32_t *)(base + off_a);
 	c.scan.tabB = (const uint32_t *)(base + off_b);
-	c.scan.bitmap = (const uint32_t *)(base + off_m);
 	c.scan.slide_bitmap = (const uint32_t *)(base + off_s);
+	c.scan.slide4_bitmap = slide4.empty() ? nullptr : (const uint32_t *)(base + off_s4);
+	c.scan.slide4b_bitmap = slide4b.empty() ? nullptr : (const uint32_t *)(base + off_s4b);
 	c.scan.hslots = (const uint64_t *)c.d_hslots;
 	c.scan.hmask = mb.mask;
 	c.scan.kclass[0] = kclass[0];

@@ -257,11 +257,6 @@ __device__ __forceinline__ Probe probe_addr(uint32_t e0, uint32_t e1, uint32_t e
 	return r;
 }
 
-__device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
-{
-	return (proj >> 3) & ((LDS_BITMAP_WORDS - 1) << 2);
-}
-
 // Wave priorities (s_setprio) by phase of a trip.  The four waves of a SIMD otherwise run in step -- all in the
 // VALU-dense pre-filter, then all waiting on LDS round trips in the survivor loop -- and compete for the same unit.
 // With the pre-filter lowest, the loop above it and the candidate handling (the longest latencies: LDS batches,
@@ -274,20 +269,22 @@ __device__ __forceinline__ uint32_t bitmap_off(uint32_t proj)
 #define PRIO_CAND 3
 #endif
 struct SlideTapList { int n; int k[32]; };
+template <uint64_t TAPS>
 constexpr SlideTapList slide_tap_list()
 {
 	SlideTapList l = {0, {0}};
 	for (int k = 0; k < 64; k++)
-		if ((SLIDE_TAPS >> k) & 1)
+		if ((TAPS >> k) & 1)
 			l.k[l.n++] = k;
 	return l;
 }
 // 32 positions of the sliding check stream (slide.h): bit b = parity of the stream bits b + k over the taps k,
 // stream bit i = bit i of e2:e1:e0.  Taps and shifts are compile-time constants (a funnel shift by a
 // run-time amount costs more, see 3.2 of NOTEBOOK.md).
+template <uint64_t TAPS>
 __device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e2)
 {
-	constexpr SlideTapList taps = slide_tap_list();
+	constexpr SlideTapList taps = slide_tap_list<TAPS>();
 	uint32_t plane[32];
 #pragma unroll
 	for (int i = 0; i < taps.n; i++) {
@@ -312,9 +309,10 @@ __device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e
 
 // the low bits (b <= 63 - highest tap) of the same for wave-uniform dwords, written with 64-bit shifts so that it
 // stays on the SALU
+template <uint64_t TAPS>
 __device__ __forceinline__ uint32_t slide32_low_uniform(uint32_t e0, uint32_t e1)
 {
-	constexpr SlideTapList taps = slide_tap_list();
+	constexpr SlideTapList taps = slide_tap_list<TAPS>();
 	const uint64_t w = ((uint64_t)e1 << 32) | e0;
 	uint32_t acc = 0;
 #pragma unroll
@@ -323,7 +321,6 @@ __device__ __forceinline__ uint32_t slide32_low_uniform(uint32_t e0, uint32_t e1
 	return acc;
 }
 
-template <int VARIANT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 {
 	extern __shared__ uint32_t lds[];
@@ -357,13 +354,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		char *ldsb = reinterpret_cast<char *>(lds);
 		const uint4 *srcA = reinterpret_cast<const uint4 *>(a.t.tabA);
 		const uint4 *srcB = reinterpret_cast<const uint4 *>(a.t.tabB);
-		const uint4 *srcM = reinterpret_cast<const uint4 *>(a.t.bitmap);
 		uint4 *dA = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABA);
 		uint4 *dB = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_TABB);
-		uint4 *dM = reinterpret_cast<uint4 *>(ldsb + LDS_OFF_BITMAP);
 		for (uint32_t i = tid; i < LDS_TABA_WORDS / 4; i += SCAN_THREADS) dA[i] = srcA[i];
 		for (uint32_t i = tid; i < LDS_TABB_WORDS / 4; i += SCAN_THREADS) dB[i] = srcB[i];
-		for (uint32_t i = tid; i < LDS_BITMAP_WORDS / 4; i += SCAN_THREADS) dM[i] = srcM[i];
 	}
 	__syncthreads();
 #ifdef SCAN_PROFILE
@@ -630,16 +624,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
-					if (VARIANT == 8) {
-						// tables for >= 5 errors: the LDS bitmap passes every survivor, so probe the
-						// 2^26-bit bitmap in L2 / Infinity Cache right here instead
-						i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
-						bw[u][h] = 0;
-						if (m[u][h])
-							bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
-					} else {
-						bw[u][h] = lds_ld(LDS_OFF_BITMAP + bitmap_off(proj[u][h]));
-					}
+					// tables for five errors: every value of any set that fits the LDS is a sum of five columns, so each
+					// survivor probes the 2^26-bit bitmap in L2 / Infinity Cache right here
+					i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
+					bw[u][h] = 0;
+					if (m[u][h])
+						bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
 				}
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
@@ -647,15 +637,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 				for (int h = 0; h < 2; h++) {
 					// only bit 0 counts: (bitmap word >> index) & (m >> p), p = ~0 for m == 0: 0 >> 31
 					live[u][h] = m[u][h] >> p[u][h];
-					bit[u][h] = bw[u][h] >> ((VARIANT == 8 ? i2[u][h] : proj[u][h]) & 31);
-					if (VARIANT == 9) {
-						bit[u][h] &= live[u][h];
-						if (bit[u][h] & 1) {
-							// tables for 4 errors: 58 % pass the LDS bitmap; those lanes alone go on to the L2 bitmap
-							const uint32_t j2 = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
-							bit[u][h] = (a.t.bitmap2[j2 >> 5] >> (j2 & 31)) & 1;
-						}
-					}
+					bit[u][h] = bw[u][h] >> (i2[u][h] & 31);
 					anybit = BITOP3(bit[u][h], live[u][h], anybit, 0xea);   // anybit |= bit & live, one instruction
 					m[u][h] &= m[u][h] - 1;
 				}
@@ -716,18 +698,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // words: tests/test_gpu_scan.py adversarial cases).
 // Geometry and tuning (every A/B behind these values is in profiles/: r03_ab, r05_scan).
 #define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
+#define SLIDE4_TILES 3                     // ... of the two-level form (tables for four errors)
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
 #define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
-#define SLIDE_WAVES_PER_EU (SLIDE_WGS * SLIDE_THREADS / 256)
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
-#define SLIDE_SET_WORDS  (1u << (SLIDE_BITS - 5))
-#define SLIDE_SET_BYTES  (4u * SLIDE_SET_WORDS)
-template <int WGS> struct SlideGeom {
-	static constexpr uint32_t RING = WGS == 2 ? 64 : 128;               // ring entries per wave
-	static constexpr uint32_t RING_END = SLIDE_SET_BYTES + CAND_BYTES * (SLIDE_THREADS / 64) * RING;
+// The kernel's two cuts.  SlideStd: tables for <= 3 errors, two workgroups per CU around a 2^19-bit set.  Slide4: tables for four
+// errors (slide.h), ONE workgroup per CU around a 2^20-bit set (the whole LDS: 128 KiB + 2 KiB of ring per wave), its members
+// looked up in a second set in L2 before they count as candidates.
+struct SlideStd {
+	static constexpr int BITS = SLIDE_BITS, THREADS = SLIDE_THREADS, WGS = SLIDE_WGS;
+	static constexpr uint64_t TAPS = SLIDE_TAPS, TAPS_B = 0;
+	static constexpr bool LEVEL2 = false, INVERT = false;
+};
+struct Slide4 {
+	static constexpr int BITS = SLIDE4_BITS, THREADS = 1024, WGS = 1;
+	static constexpr uint64_t TAPS = SLIDE4_TAPS, TAPS_B = SLIDE4B_TAPS;
+	// INVERT: the chains run on the complemented check stream -- an idle chain indexes 0 or 1, which are members of the set for
+	// four errors while their complements are not (context.cpp stores the set accordingly)
+	static constexpr bool LEVEL2 = true, INVERT = true;
+};
+template <class CFG> struct SlideGeom {
+	static constexpr uint32_t SET_WORDS = 1u << (CFG::BITS - 5), SET_BYTES = 4u * SET_WORDS;
+	static constexpr uint32_t WAVES_PER_EU = CFG::WGS * CFG::THREADS / 256;
+	static constexpr uint32_t RING = CFG::WGS == 2 ? 64 : 128;               // ring entries per wave
+	static constexpr uint32_t RING_END = SET_BYTES + CAND_BYTES * (CFG::THREADS / 64) * RING;
 #ifdef SCAN_PROFILE
-	static constexpr uint32_t LDS_BYTES = RING_END + 128u * (SLIDE_THREADS / 64);     // 32 phase counters per wave
+	static constexpr uint32_t LDS_BYTES = RING_END + 128u * (CFG::THREADS / 64);     // 32 phase counters per wave
 #else
 	static constexpr uint32_t LDS_BYTES = RING_END;
 #endif
@@ -739,17 +736,18 @@ template <int WGS> struct SlideGeom {
 // in-place path costs the dense case a factor of three).
 // MSB: the words hold their symbols MSB first in every byte (BTBBX_FMT_PACKED_MSB); a template flag, not a run-time branch: the
 // branch alone cost the LSB path 1 % here and 7 % in scan_known_lap_kernel (the words' registers become merge points)
-template <int TILES, int WGS, bool DENSE, bool MSB>
-__global__ __launch_bounds__(SLIDE_THREADS) __attribute__((amdgpu_waves_per_eu(SLIDE_WAVES_PER_EU, SLIDE_WAVES_PER_EU)))
+template <class CFG, int TILES, bool DENSE, bool MSB>
+__global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(SlideGeom<CFG>::WAVES_PER_EU, SlideGeom<CFG>::WAVES_PER_EU)))
 void scan_slide_kernel(ScanArgs a)
 {
 	extern __shared__ uint32_t lds[];
-	constexpr uint32_t RING = SlideGeom<WGS>::RING;
+	constexpr uint32_t RING = SlideGeom<CFG>::RING;
+	constexpr uint32_t THREADS = CFG::THREADS, SET_WORDS = SlideGeom<CFG>::SET_WORDS, SET_BYTES = SlideGeom<CFG>::SET_BYTES;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: ring addresses stay on the SALU
-	const uint32_t ring_off = SLIDE_SET_BYTES + CAND_BYTES * wave * RING;
+	const uint32_t ring_off = SET_BYTES + CAND_BYTES * wave * RING;
 
 	// tile order: one contiguous eighth of the tiles per XCD, its workgroups interleaved (see scan_lap_any_kernel)
 	uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, n_mine;
@@ -766,9 +764,9 @@ void scan_slide_kernel(ScanArgs a)
 	{	// candidate set -> LDS byte 0, 16 bytes per lane per step, every word bit-reversed: the member bit of index i is bit
 		// 31 - (i & 31), so that a LEFT shift by i brings it to the sign bit -- "member" is then one signed compare, whose
 		// result (a lane mask in scalar registers) is also the ballot the candidate path needs
-		const uint4 *src = reinterpret_cast<const uint4 *>(a.t.slide_bitmap);
+		const uint4 *src = reinterpret_cast<const uint4 *>(CFG::LEVEL2 ? a.t.slide4_bitmap : a.t.slide_bitmap);
 		uint4 *dst = reinterpret_cast<uint4 *>(lds);
-		for (uint32_t i = tid; i < SLIDE_SET_WORDS / 4; i += SLIDE_THREADS) {
+		for (uint32_t i = tid; i < SET_WORDS / 4; i += THREADS) {
 			const uint4 v = src[i];
 			dst[i] = make_uint4(__brev(v.x), __brev(v.y), __brev(v.z), __brev(v.w));
 		}
@@ -778,7 +776,7 @@ void scan_slide_kernel(ScanArgs a)
 #ifdef SCAN_PROFILE
 	// phases: 0 = tile loads + barker filter + check stream, 1 .. 13 = survivor pass k, 16 = loop exit, 18 = ring drain,
 	// 19 = hand-over to the next trip
-	const uint32_t prof_off = SlideGeom<WGS>::RING_END + 128u * wave;
+	const uint32_t prof_off = SlideGeom<CFG>::RING_END + 128u * wave;
 	if (lane < 32)
 		lds_st(prof_off + 4u * lane, 0u);
 	uint64_t prof_t;
@@ -794,7 +792,7 @@ void scan_slide_kernel(ScanArgs a)
 			stream = tile / (uint32_t)a.tiles_per_stream;
 			t = tile - stream * (uint32_t)a.tiles_per_stream;
 		}
-		return (uint64_t)t * SLIDE_THREADS + wave * 64 + ((code >> 6) & 63);
+		return (uint64_t)t * THREADS + wave * 64 + ((code >> 6) & 63);
 	};
 	// hits: up to 64 pending records per wave in registers, written 1 KiB at a time behind one counter atomic
 	uint32_t pend = 0;                            // wave-uniform
@@ -881,12 +879,12 @@ void scan_slide_kernel(ScanArgs a)
 		lo = hi = 0;
 		if (c.stream >= a.n_streams)
 			return;
-		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SLIDE_THREADS;   // uniform
+		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * THREADS;   // uniform
 		if (tile_full(c.t)) {
 			lo = stream_ld(tp + tid);
 			hi = stream_ld(tp + tid + 1);
 		} else {
-			const uint64_t w = (uint64_t)c.t * SLIDE_THREADS + tid;
+			const uint64_t w = (uint64_t)c.t * THREADS + tid;
 			lo = w < a.n_words ? stream_ld(tp + tid) : 0;
 			hi = w + 1 < a.n_words ? stream_ld(tp + tid + 1) : 0;
 		}
@@ -904,6 +902,7 @@ void scan_slide_kernel(ScanArgs a)
 	for (uint32_t it = 0; tc[0].stream < a.n_streams; it += TILES) {
 		__builtin_amdgcn_s_setprio(PRIO_FILTER);
 		uint32_t d[TILES][4], m[TILES][2], c[TILES][3];
+		uint32_t c2[TILES][CFG::LEVEL2 ? 3 : 1];                 // (two-level form) the second check stream, positions as c
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
@@ -917,7 +916,7 @@ void scan_slide_kernel(ScanArgs a)
 			if (tc[u].stream >= a.n_streams) {
 				validA = validB = 0;
 			} else if (!tile_full(tc[u].t)) {
-				const uint64_t first_off = ((uint64_t)tc[u].t * SLIDE_THREADS + tid) * 64;
+				const uint64_t first_off = ((uint64_t)tc[u].t * THREADS + tid) * 64;
 				const uint64_t valid = first_off >= a.search_bits ? 0ULL
 					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
 				validA = (uint32_t)valid;
@@ -926,13 +925,25 @@ void scan_slide_kernel(ScanArgs a)
 			uint32_t cls_unused;
 			barker32(d[u][1], d[u][2], validA, m[u][0], cls_unused);    // offsets 0..31: window bits 57.. in d1:d2
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls_unused);    // offsets 32..63
-			c[u][0] = slide32(d[u][0], d[u][1], d[u][2]);
-			c[u][1] = slide32(d[u][1], d[u][2], d[u][3]);
+			c[u][0] = slide32<CFG::TAPS>(d[u][0], d[u][1], d[u][2]);
+			c[u][1] = slide32<CFG::TAPS>(d[u][1], d[u][2], d[u][3]);
 			// positions 64..95 = the first check dword of the next lane's word; lane 63's from the scalar unit
 			const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
-			const uint32_t last = slide32_low_uniform(s2, s3);
+			uint32_t last = slide32_low_uniform<CFG::TAPS>(s2, s3);
+			if constexpr (CFG::INVERT) {
+				c[u][0] = ~c[u][0];
+				c[u][1] = ~c[u][1];
+				last = ~last;
+			}
 			const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
 			c[u][2] = lane == 63 ? last : next;
+			if constexpr (CFG::LEVEL2) {
+				c2[u][0] = slide32<CFG::TAPS_B>(d[u][0], d[u][1], d[u][2]);
+				c2[u][1] = slide32<CFG::TAPS_B>(d[u][1], d[u][2], d[u][3]);
+				const uint32_t last2 = slide32_low_uniform<CFG::TAPS_B>(s2, s3);
+				const uint32_t next2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c2[u][0]);
+				c2[u][2] = lane == 63 ? last2 : next2;
+			}
 		}
 
 		// A chain (32 offsets) as a pair of shift registers: its survivor mask and the 50 check bits its indices are cut from,
@@ -952,6 +963,7 @@ void scan_slide_kernel(ScanArgs a)
 				any |= m[u][0] | m[u][1];
 			return __ballot(any != 0) != 0;
 		};
+		uint32_t pos2[TILES][2];                     // (two-level form) where the chains stood when their pending look-ups were sent
 		auto events = [&](const uint64_t (&cms)[TILES][2]) {   // append the wave's candidates of one pass to its ring
 #pragma unroll
 			for (int u = 0; u < TILES; u++)
@@ -970,7 +982,10 @@ void scan_slide_kernel(ScanArgs a)
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
 						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
 						uint32_t pos;
-						asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
+						if constexpr (CFG::LEVEL2)
+							pos = pos2[u][h];
+						else
+							asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
 						// the record carries the three stream dwords the window lies in; the drain cuts it out (for sixty
 						// candidates at once) instead of this branch (for one)
 						const uint32_t code = pos | lane6 | (((it + u) << 12) | (h << 5));
@@ -1003,11 +1018,47 @@ void scan_slide_kernel(ScanArgs a)
 			m[u][h] >>= p & 31;
 			C[u][h] >>= p & 63;
 			g.v[u][h] = (uint32_t)C[u][h];
-			g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SLIDE_SET_WORDS - 1) << 2));
+			g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SET_WORDS - 1) << 2));
 			m[u][h] &= ~1u;
 		};
 		auto member = [&](int u, int h, const Stage &g) {   // lanes whose index is in the set (the compare's own mask: no ballot)
 			return __ballot((int32_t)(g.bw[u][h] << (g.v[u][h] & 31)) < 0);
+		};
+		// Two-level form: a third of the survivors are members of the LDS set; they alone (exec mask) look their SLIDE4B_BITS
+		// positions of the second check stream up in the set in L2 -- one dword each, the four chains' loads in flight together.
+		// The position comes from the chain's marker, as in a candidate event.  The look-ups of a pass are sent at its end and
+		// looked at in the NEXT pass, behind that pass's own steps (level2_take): the L2's answer has a pass to arrive in.
+		uint32_t v2[TILES][2], w2[TILES][2];
+		uint64_t sent[TILES][2], any_sent = 0;               // lanes with a look-up in flight, per chain
+		auto level2_send = [&](const uint64_t (&cms)[TILES][2]) {
+			any_sent = 0;
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					sent[u][h] = cms[u][h];
+					any_sent |= cms[u][h];
+					asm("v_ffbh_u32 %0, %1" : "=v"(pos2[u][h]) : "v"((uint32_t)(C[u][h] >> 32)));
+					v2[u][h] = alignbit(c2[u][h + 1], c2[u][h], pos2[u][h]);
+					w2[u][h] = 0;
+					if (__builtin_amdgcn_inverse_ballot_w64(cms[u][h]))
+						w2[u][h] = a.t.slide4b_bitmap[(v2[u][h] >> 5) & ((1u << (SLIDE4B_BITS - 5)) - 1)];
+				}
+		};
+		auto level2_take = [&]() {
+			if (!any_sent)
+				return;
+			uint64_t cms[TILES][2], any = 0;
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					cms[u][h] = sent[u][h] & __ballot((int32_t)(w2[u][h] << (v2[u][h] & 31)) < 0);
+					any |= cms[u][h];
+				}
+			any_sent = 0;
+			if (any)
+				events(cms);
 		};
 		auto pass = [&]() {
 			Stage g;
@@ -1024,8 +1075,13 @@ void scan_slide_kernel(ScanArgs a)
 					cms[u][h] = member(u, h, g);
 					any |= cms[u][h];
 				}
-			if (any)                                     // some lane of the wave holds a candidate (half of the passes)
+			if constexpr (CFG::LEVEL2) {
+				level2_take();                           // the previous pass's look-ups, then this pass's are sent
+				if (any)
+					level2_send(cms);
+			} else if (any) {                            // some lane of the wave holds a candidate (half of the passes)
 				events(cms);
+			}
 		};
 		// Behind the fixed passes a handful of the wave's 2 * TILES * 64 chains still hold survivors (0.8 % have seven or more):
 		// a pass then looks at the chains one by one and skips those that are empty wave-wide (the same ballots are the
@@ -1098,6 +1154,8 @@ void scan_slide_kernel(ScanArgs a)
 					PROF_MARK(pass_no < 13 ? pass_no : 13);
 					pass_no++;
 				}
+				if constexpr (CFG::LEVEL2)
+					level2_take();                       // (the look-ups of the last pass)
 				__builtin_amdgcn_s_setprio(PRIO_CAND);
 				PROF_MARK(16);
 				if (more || q_tail - q_head >= 32u)
@@ -1642,13 +1700,14 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 	ctx_scan_snapshot(&a.t, &table_errors);
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
-		// tables built for 4 / 5 errors fill 58 % / 100 % of the LDS bitmap: their kernels consult the
-		// 2^26-bit bitmap in L2 inside the survivor loops (after / instead of the LDS one); everything else
-		// runs the sliding-check kernel
+		// tables for <= 3 errors: the sliding-check kernel (1); for four: its two-level form (4: a 2^20-bit set in LDS, its members
+		// looked up in a second set in L2, slide.h); for five every survivor probes a 2^26-bit bitmap in L2 (8: scan_lap_any_kernel)
 		int run_variant = 1;
-		if (a.t.bitmap2 && table_errors >= 4)
-			run_variant = table_errors == 4 ? 9 : 8;
-		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : SCAN_THREADS;      // one word per thread
+		if (table_errors == 4 && a.t.slide4_bitmap)
+			run_variant = 4;
+		else if (a.t.bitmap2 && table_errors >= 4)
+			run_variant = 8;
+		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : run_variant == 4 ? Slide4::THREADS : SCAN_THREADS;      // one word per thread
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
 		{	// tile t is full iff (t + 1) * tile_words + 1 <= n_words and (t + 1) * tile_words * 64 <= search_bits
@@ -1663,26 +1722,35 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			set_error("btbbx_scan: launch too large for the candidate encoding (split the stream)");
 			return BTBBX_E_ARG;
 		}
-#define LAUNCH_VARIANT(V) do { \
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel<V>), \
-					    hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES)); \
-		hipLaunchKernelGGL(scan_lap_any_kernel<V>, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a); } while (0)
 #ifdef SCAN_PROFILE
 		static unsigned long long zero_prof[32];
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), zero_prof, sizeof(zero_prof)));
 #endif
 		switch (run_variant) {
-		case 8: LAUNCH_VARIANT(8); break;
-		case 9: LAUNCH_VARIANT(9); break;
+		case 8:
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES));
+			hipLaunchKernelGGL(scan_lap_any_kernel, dim3((uint32_t)grid), dim3(SCAN_THREADS), SCAN_LDS_BYTES, stream, a);
+			break;
+		case 4: {
+			a.ring_margin = 24u;
+			constexpr uint32_t lds_bytes = SlideGeom<Slide4>::LDS_BYTES;
+#define LAUNCH_SLIDE4(MSB_) do { \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<Slide4, SLIDE4_TILES, true, MSB_>), \
+						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+			hipLaunchKernelGGL((scan_slide_kernel<Slide4, SLIDE4_TILES, true, MSB_>), dim3((uint32_t)grid), dim3(Slide4::THREADS), lds_bytes, stream, a); } while (0)
+			if (msb) LAUNCH_SLIDE4(true); else LAUNCH_SLIDE4(false);
+#undef LAUNCH_SLIDE4
+			break;
+		}
 		case 1: {
 			a.ring_margin = 24u;
-			constexpr uint32_t lds_bytes = SlideGeom<SLIDE_WGS>::LDS_BYTES;
+			constexpr uint32_t lds_bytes = SlideGeom<SlideStd>::LDS_BYTES;
 			// (tables for 4 errors through this kernel -- one tile per trip, a drain after practically every pass: 58 % of the
 			// survivors are candidates there -- ran 6.26 ms per GiB against 3.27 for scan_lap_any_kernel<9>, round 3; removed)
 #define LAUNCH_SLIDE(DENSE_, MSB_) do { \
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, DENSE_, MSB_>), \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, DENSE_, MSB_>), \
 						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-			hipLaunchKernelGGL((scan_slide_kernel<SLIDE_TILES, SLIDE_WGS, DENSE_, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
+			hipLaunchKernelGGL((scan_slide_kernel<SlideStd, SLIDE_TILES, DENSE_, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
 			if (table_errors >= 3) {
 				if (msb) LAUNCH_SLIDE(true, true); else LAUNCH_SLIDE(true, false);
 			} else {

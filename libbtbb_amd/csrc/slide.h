@@ -63,15 +63,15 @@ constexpr uint64_t clmul(uint64_t a, uint64_t b)
 	return r;
 }
 
-// the lightest multiple of h~ with degree <= SLIDE_SPAN (first one found among equals)
-constexpr uint64_t lightest_check(uint64_t g)
+// the lightest multiple of h~ with degree <= span (first one found among equals)
+constexpr uint64_t lightest_check(uint64_t g, int span)
 {
 	uint64_t rem = 0;
 	const uint64_t hr = reversed(cofactor(g, &rem));
 	uint64_t best = hr;
-	for (uint64_t a = 1; a < (2ULL << (SLIDE_SPAN - degree(hr))); a += 2) {
+	for (uint64_t a = 1; a < (2ULL << (span - degree(hr))); a += 2) {
 		const uint64_t q = clmul(hr, a);
-		if (degree(q) <= SLIDE_SPAN && weight(q) < weight(best))
+		if (degree(q) <= span && weight(q) < weight(best))
 			best = q;
 	}
 	return best;
@@ -88,7 +88,21 @@ constexpr uint64_t remainder_of(uint64_t g)
 
 // taps of the check stream: bit k set = stream[x + k] takes part in c(x)  (q shifted by one: check 0 of a
 // codeword of length 64 does not hold, checks 1 .. 33 do)
-constexpr uint64_t SLIDE_TAPS = slide::lightest_check(0260534236651ULL) << 1;
+constexpr uint64_t SLIDE_TAPS = slide::lightest_check(0260534236651ULL, SLIDE_SPAN) << 1;
+
+// Tables for FOUR errors (scan_slide4 in scan.hip).  263 247 of the 2^19 values of the nineteen checks above are sums of at
+// most four columns -- half of all survivors would pass -- and no set that fits the LDS can do much better (397 k patterns against
+// 2^20 .. 2^21 bits).  So the kernel for four errors runs one workgroup per CU with a 2^20-bit set over TWENTY checks (the
+// lightest multiple of degree <= 36: 31.8 % pass) and sends those through a second level in L2: twenty-four positions of a
+// second, independent check stream (the lightest multiple of degree <= 32), a 2^24-bit set (2 MiB) that 2.9 % of them pass.
+// The two streams together have the full rank (27) of the checks that lie inside bits 1 .. 56; the exact rule still decides.
+#define SLIDE4_BITS 20
+#define SLIDE4B_BITS 24
+constexpr uint64_t SLIDE4_TAPS = slide::lightest_check(0260534236651ULL, 56 - SLIDE4_BITS) << 1;
+constexpr uint64_t SLIDE4B_TAPS = slide::lightest_check(0260534236651ULL, 56 - SLIDE4B_BITS) << 1;
+static_assert(slide::degree(SLIDE4_TAPS) + SLIDE4_BITS - 1 <= 56 && slide::degree(SLIDE4B_TAPS) + SLIDE4B_BITS - 1 <= 56,
+	      "the checks must stay below the barker bits");
+static_assert(SLIDE4_TAPS != SLIDE4B_TAPS, "the second level must be a different check");
 
 static_assert(slide::remainder_of(0260534236651ULL) == 0, "the generator must divide x^63 + 1");
 static_assert(slide::degree(SLIDE_TAPS) + SLIDE_BITS - 1 <= 56, "the checks must stay below the barker bits");

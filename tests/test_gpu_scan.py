@@ -210,11 +210,12 @@ def test_init_semantics_first_nonzero_wins():
 def test_large_error_tables(n_init):
     """btbb_init(3): 32 567 error patterns, 6 % of the barker survivors are candidates -- the DENSE form of
     scan_slide_kernel, whose pass loop is left for ring drains (a stream long enough for every wave to do so).
-    btbb_init(4) / btbb_init(5): 457 k / 5.0 M patterns; the LDS bitmap saturates and nearly every survivor takes
-    the exact path (scan_lap_any_kernel<9> / <8>) -- slow but bit-exact."""
+    btbb_init(4): 457 k patterns -- the two-level form of the same kernel (a third of the survivors are members of its 2^20-bit
+    set in LDS and look a second check stream up in a set in L2; more in test_four_error_tables_two_level_kernel).
+    btbb_init(5): 5.0 M patterns; every survivor probes a bitmap in L2 (scan_lap_any_kernel) -- slow but bit-exact."""
     lib = bt.lib()
     orc = _libs.oracle()
-    words, inj = synth.make_stream(108, (1 << 15) + 77 if n_init == 3 else 1 << 11, stride=512, err_cycle=7)     # 0..5 (+6) bit errors
+    words, inj = synth.make_stream(108, (1 << 15) + 77 if n_init <= 4 else 1 << 11, stride=512, err_cycle=7)     # 0..5 (+6) bit errors
     sym = np.ascontiguousarray(synth.unpack_bits(words))
     n = len(sym) - 63
     try:
@@ -226,6 +227,70 @@ def test_large_error_tables(n_init):
             got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, me))
             assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, me), (n_init, me)
         assert len(got) > 150
+    finally:
+        lib.btbbx_shutdown()
+        orc.orc_reset_syndrome_map()
+        bt.init(2)
+        orc.orc_init(2)
+
+
+def test_four_error_tables_two_level_kernel():
+    """btbb_init(4) runs scan_slide_kernel in its two-level form (one 1024-thread workgroup per CU, complemented check stream, the
+    set's members looked up in L2 a pass later).  Against the oracle with the same tables: several streams with a pitch, LSB- and
+    MSB-first words, search lengths around word and tile boundaries (tiles of 1024 words here), every max_ac_errors the tables
+    serve; then a stream made of sync words only (every candidate ring overflows into the in-place check) and one of sync words
+    with exactly four errors each."""
+    lib = bt.lib()
+    orc = _libs.oracle()
+    n_streams, nwords, pitch = 3, 3 * 1024 + 131, 3 * 1024 + 140
+    try:
+        lib.btbbx_shutdown()
+        orc.orc_reset_syndrome_map()
+        assert lib.btbb_init(4) == 0 and orc.orc_init(4) == 0
+        lsb_rows, msb_rows, syms = [], [], []
+        for ch in range(n_streams):
+            words, inj = synth.make_stream(470 + ch, nwords, stride=512, err_cycle=7)
+            sym = np.ascontiguousarray(synth.unpack_bits(words))
+            msb = np.packbits(sym, bitorder="big").view(np.uint64)
+            lsb_rows.append(np.concatenate([words, np.zeros(pitch - nwords, np.uint64)]))
+            msb_rows.append(np.concatenate([msb, np.zeros(pitch - nwords, np.uint64)]))
+            syms.append(sym)
+        d_l = bt.DeviceBuffer(pitch * n_streams * 8).upload(np.concatenate(lsb_rows))
+        d_m = bt.DeviceBuffer(pitch * n_streams * 8).upload(np.concatenate(msb_rows))
+        cap = 1 << 16
+        d_h = bt.DeviceBuffer(cap * 16)
+        d_c = bt.DeviceBuffer(16)
+
+        def run(d_w, fmt, bits, me):
+            d_c.zero()
+            bt.check(lib.btbbx_scan_device_fmt(d_w.ptr, nwords, pitch, n_streams, bits, bt.LAP_ANY, me, fmt, d_h.ptr, cap, d_c.ptr, None), "scan_fmt")
+            bt.check(lib.btbbx_sync(None))
+            cnt = int(d_c.download(np.uint32, 4)[0])
+            return sorted((int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt])
+
+        total = 0
+        for bits, mes in ((nwords * 64 - 63, (0, 2, 3, 4, 6)), (nwords * 64 - 63 - 29, (4,)), (1024 * 64, (4,)), (1024 * 64 + 1, (4,)),
+                          (1024 * 64 - 1, (4,)), (2048 * 64 + 33, (3, 4)), (65, (4,)), (1, (4,))):
+            for me in mes:
+                want = sorted((ch, o, l, e) for ch in range(n_streams) for (o, l, e) in _libs.orc_find_all(syms[ch], bits, _libs.LAP_ANY, me))
+                assert run(d_l, 0, bits, me) == want, (bits, me)
+                assert run(d_m, 2, bits, me) == want, (bits, me, "msb")
+                total += len(want)
+        assert total > 1500
+        for b in (d_l, d_m, d_h, d_c):
+            b.free()
+        rng = np.random.default_rng(_libs.seed(44))
+        laps = rng.integers(0, 1 << 24, 4096)
+        clean = [synth.syncword(int(l)) for l in laps]
+        hurt = [w ^ sum(1 << int(b) for b in rng.choice(57, 4, replace=False)) for w in clean]      # four errors below the barker bits
+        for body in (clean, hurt):
+            words = np.array(body + [0], dtype=np.uint64)
+            sym = np.ascontiguousarray(synth.unpack_bits(words))
+            n = len(sym) - 63
+            for me in (3, 4):
+                got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, me))
+                assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, me)
+            assert len(got) >= 4096
     finally:
         lib.btbbx_shutdown()
         orc.orc_reset_syndrome_map()
