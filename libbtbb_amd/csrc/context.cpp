@@ -453,12 +453,12 @@ static int upload_tables(int max_ac_errors)
 		}
 	}
 
-	// tables for four errors: the two sets of scan_slide_kernel's two-level form (slide.h)
+	// tables for three and four errors: the two sets of scan_slide_kernel's two-level form (slide.h)
 	std::vector<uint32_t> slide4, slide4b;
-	if (max_ac_errors == 4) {
-		int rc4 = build_slide_set(t, 4, slide4, SLIDE4_BITS, SLIDE4_TAPS);
+	if (max_ac_errors == 3 || max_ac_errors == 4) {
+		int rc4 = build_slide_set(t, max_ac_errors, slide4, SLIDE4_BITS, SLIDE4_TAPS);
 		if (rc4 >= 0)
-			rc4 = build_slide_set(t, 4, slide4b, SLIDE4B_BITS, SLIDE4B_TAPS);
+			rc4 = build_slide_set(t, max_ac_errors, slide4b, SLIDE4B_BITS, SLIDE4B_TAPS);
 		if (rc4 < 0)
 			return rc4;
 		// An idle chain of the kernel indexes 0 or 1 (see above), and with four errors the all-zero value of these twenty checks

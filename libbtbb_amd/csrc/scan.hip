@@ -698,7 +698,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // words: tests/test_gpu_scan.py adversarial cases).
 // Geometry and tuning (every A/B behind these values is in profiles/: r03_ab, r05_scan).
 #define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
-#define SLIDE4_TILES 3                     // ... of the two-level form (tables for four errors)
+#ifndef SLIDE4_TILES
+#define SLIDE4_TILES 3                     // ... of the two-level form (tables for three and four errors; 2: +2.5 %, 4: +20 %)
+#endif
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
 #define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
@@ -1028,6 +1030,8 @@ void scan_slide_kernel(ScanArgs a)
 		// positions of the second check stream up in the set in L2 -- one dword each, the four chains' loads in flight together.
 		// The position comes from the chain's marker, as in a candidate event.  The look-ups of a pass are sent at its end and
 		// looked at in the NEXT pass, behind that pass's own steps (level2_take): the L2's answer has a pass to arrive in.
+		// (No "this chain has no member in any lane" shortcut: a branch per chain makes the compiler wait for the loads at
+		// every merge -- 1.9 against 1.43 ms per GiB with tables for three errors, where a third of the chain-passes could skip.)
 		uint32_t v2[TILES][2], w2[TILES][2];
 		uint64_t sent[TILES][2], any_sent = 0;               // lanes with a look-up in flight, per chain
 		auto level2_send = [&](const uint64_t (&cms)[TILES][2]) {
@@ -1703,7 +1707,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		// tables for <= 3 errors: the sliding-check kernel (1); for four: its two-level form (4: a 2^20-bit set in LDS, its members
 		// looked up in a second set in L2, slide.h); for five every survivor probes a 2^26-bit bitmap in L2 (8: scan_lap_any_kernel)
 		int run_variant = 1;
-		if (table_errors == 4 && a.t.slide4_bitmap)
+		if ((table_errors == 3 || table_errors == 4) && a.t.slide4_bitmap)
 			run_variant = 4;
 		else if (a.t.bitmap2 && table_errors >= 4)
 			run_variant = 8;

@@ -208,10 +208,9 @@ def test_init_semantics_first_nonzero_wins():
 
 @pytest.mark.parametrize("n_init", [3, 4, 5])
 def test_large_error_tables(n_init):
-    """btbb_init(3): 32 567 error patterns, 6 % of the barker survivors are candidates -- the DENSE form of
-    scan_slide_kernel, whose pass loop is left for ring drains (a stream long enough for every wave to do so).
-    btbb_init(4): 457 k patterns -- the two-level form of the same kernel (a third of the survivors are members of its 2^20-bit
-    set in LDS and look a second check stream up in a set in L2; more in test_four_error_tables_two_level_kernel).
+    """btbb_init(3) / btbb_init(4): 32 567 / 457 k error patterns -- the two-level form of scan_slide_kernel (3 % / 32 % of the
+    survivors are members of its 2^20-bit set in LDS and look a second check stream up in a set in L2; more in
+    test_three_and_four_error_tables_two_level_kernel), on a stream long enough for every wave to drain its ring.
     btbb_init(5): 5.0 M patterns; every survivor probes a bitmap in L2 (scan_lap_any_kernel) -- slow but bit-exact."""
     lib = bt.lib()
     orc = _libs.oracle()
@@ -234,19 +233,20 @@ def test_large_error_tables(n_init):
         orc.orc_init(2)
 
 
-def test_four_error_tables_two_level_kernel():
-    """btbb_init(4) runs scan_slide_kernel in its two-level form (one 1024-thread workgroup per CU, complemented check stream, the
+@pytest.mark.parametrize("n_init", [3, 4])
+def test_three_and_four_error_tables_two_level_kernel(n_init):
+    """btbb_init(3) and btbb_init(4) run scan_slide_kernel in its two-level form (one 1024-thread workgroup per CU, complemented check stream, the
     set's members looked up in L2 a pass later).  Against the oracle with the same tables: several streams with a pitch, LSB- and
     MSB-first words, search lengths around word and tile boundaries (tiles of 1024 words here), every max_ac_errors the tables
     serve; then a stream made of sync words only (every candidate ring overflows into the in-place check) and one of sync words
-    with exactly four errors each."""
+    with exactly n_init errors each."""
     lib = bt.lib()
     orc = _libs.oracle()
     n_streams, nwords, pitch = 3, 3 * 1024 + 131, 3 * 1024 + 140
     try:
         lib.btbbx_shutdown()
         orc.orc_reset_syndrome_map()
-        assert lib.btbb_init(4) == 0 and orc.orc_init(4) == 0
+        assert lib.btbb_init(n_init) == 0 and orc.orc_init(n_init) == 0
         lsb_rows, msb_rows, syms = [], [], []
         for ch in range(n_streams):
             words, inj = synth.make_stream(470 + ch, nwords, stride=512, err_cycle=7)
@@ -269,8 +269,8 @@ def test_four_error_tables_two_level_kernel():
             return sorted((int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt])
 
         total = 0
-        for bits, mes in ((nwords * 64 - 63, (0, 2, 3, 4, 6)), (nwords * 64 - 63 - 29, (4,)), (1024 * 64, (4,)), (1024 * 64 + 1, (4,)),
-                          (1024 * 64 - 1, (4,)), (2048 * 64 + 33, (3, 4)), (65, (4,)), (1, (4,))):
+        for bits, mes in ((nwords * 64 - 63, (0, 2, 3, 4, 6)), (nwords * 64 - 63 - 29, (n_init,)), (1024 * 64, (n_init,)), (1024 * 64 + 1, (n_init,)),
+                          (1024 * 64 - 1, (n_init,)), (2048 * 64 + 33, (3, 4)), (65, (n_init,)), (1, (n_init,))):
             for me in mes:
                 want = sorted((ch, o, l, e) for ch in range(n_streams) for (o, l, e) in _libs.orc_find_all(syms[ch], bits, _libs.LAP_ANY, me))
                 assert run(d_l, 0, bits, me) == want, (bits, me)
@@ -282,12 +282,12 @@ def test_four_error_tables_two_level_kernel():
         rng = np.random.default_rng(_libs.seed(44))
         laps = rng.integers(0, 1 << 24, 4096)
         clean = [synth.syncword(int(l)) for l in laps]
-        hurt = [w ^ sum(1 << int(b) for b in rng.choice(57, 4, replace=False)) for w in clean]      # four errors below the barker bits
+        hurt = [w ^ sum(1 << int(b) for b in rng.choice(57, n_init, replace=False)) for w in clean]  # n_init errors below the barker bits
         for body in (clean, hurt):
             words = np.array(body + [0], dtype=np.uint64)
             sym = np.ascontiguousarray(synth.unpack_bits(words))
             n = len(sym) - 63
-            for me in (3, 4):
+            for me in (n_init - 1, n_init):
                 got = as_tuples(bt.scan_words(words, n, bt.LAP_ANY, me))
                 assert got == _libs.orc_find_all(sym, n, _libs.LAP_ANY, me)
             assert len(got) >= 4096
