@@ -33,7 +33,7 @@
 #endif
 #define CAND_BYTES     16                  // a parked candidate: position code + its 64-bit window + pad (one ds_*_b128)
 
-// LDS layout (bytes).  All three table bases fit the 16-bit DS offset immediate, so a
+// LDS layout of scan_lap_any_kernel (bytes).  Both table bases fit the 16-bit DS offset immediate, so a
 // probe needs no address adds.
 #define LDS_TABB_WORDS   (1u << TABB_BITS)            // 4096 u32  = 16 KiB
 #define LDS_TABA_WORDS   (1u << TABA_BITS)            // 2048 u32  =  8 KiB
@@ -45,7 +45,7 @@
 #ifdef SCAN_PROFILE
 #define SCAN_LDS_BYTES   (LDS_OFF_PROF + 128u * SCAN_WAVES)
 #else
-#define SCAN_LDS_BYTES   LDS_OFF_PROF                                                   // = 152 KiB
+#define SCAN_LDS_BYTES   LDS_OFF_PROF                                                   // = 88 KiB
 #endif
 
 // ---- device-side table bundle -----------------------------------------------------

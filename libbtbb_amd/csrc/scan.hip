@@ -5,8 +5,9 @@
 // btbb_find_ac() (:444-464).  Input is the PACKED stream (1 bit per symbol); one
 // lane owns the 64 bit-offsets that start in one 64-bit word.
 //
-// LAP_ANY, per lane and word (scan_slide_kernel; tables built for 4 / 5 errors: scan_lap_any_kernel<9> / <8>, which
-// probe two syndrome tables + a bitmap per survivor instead of step 2):
+// LAP_ANY, per lane and word (scan_slide_kernel; tables built for three and four errors: the same kernel in its two-level
+// form, see SlideStd / Slide4 below; for five errors: scan_lap_any_kernel, which computes the syndrome from two tables in LDS
+// and probes a bitmap in L2 per survivor instead of step 2):
 //   1. bit-sliced barker pre-filter: seven funnel-shifted copies of the stream give the
 //      7-bit window (LAP MSB + 6 barker bits, :378-385) of all 32 offsets of a dword at
 //      once; a carry-save adder counts mismatches against 0x27 and `count in {0,1,6,7}`
@@ -232,10 +233,10 @@ __device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t vali
 	cls = ~(twos | fours);
 }
 
-// One survivor costs about 17 VALU + 3 DS instructions:
+// (scan_lap_any_kernel, tables for five errors)  One survivor costs about 17 VALU + 2 DS instructions:
 //   syndrome_low32 = w[31:0] ^ tabA[w[44:34]] ^ tabB[w[56:45]] ^ (class ? kdiff : 0)
-// for the window w at offset p of the dword triple (e0,e1,e2), then a probe of the candidate
-// bitmap with its low 19 bits.  The stages are separate functions so that the survivor loop
+// for the window w at offset p of the dword triple (e0,e1,e2), then a probe of the second-level
+// bitmap in L2 with a hash of it.  The stages are separate functions so that the survivor loop
 // can issue the LDS reads of its two chains back to back, each under the exec mask of the
 // lanes that really have a survivor: the DS pipe (shared by the 16 waves of the CU) then
 // only pays bank conflicts for useful lanes.
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_t) : : "memory");
 #endif
 
-	// Candidate = passed the bitmap (0.3 % of survivors).  Three stages keep it cheap:
+	// Candidate = passed the bitmap in L2 (a quarter of the survivors with tables for five errors).  Three stages:
 	//  1. park: one DS write into a private slot of the lane -- no atomics and no ballots in
 	//     the survivor loop (a lane with all slots full verifies in place: adversarial input);
 	//  2. compact: at a tile end, once enough lanes hold one, the parked codes are packed
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		// a lane that has a survivor -- masks their bitmap bit afterwards.  Switching them off in the
 		// exec mask instead (a v_cmp, an s_and_saveexec, a skip branch and an s_or per group of reads)
 		// was 3 % slower: the loop is bound by instruction issue, not by LDS bank conflicts
-		// (profiles/r02_cut).  The global bitmap of the >= 4-error variants is still read under exec.
+		// (profiles/r02_cut).  The bitmap in L2 is still read under exec.
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			PROF_PIN(m[u][0]);
@@ -705,20 +706,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
-// The kernel's two cuts.  SlideStd: tables for <= 3 errors, two workgroups per CU around a 2^19-bit set.  Slide4: tables for four
-// errors (slide.h), ONE workgroup per CU around a 2^20-bit set (the whole LDS: 128 KiB + 2 KiB of ring per wave), its members
-// looked up in a second set in L2 before they count as candidates.
+// The kernel's two cuts.
+// SlideStd: tables for <= 2 errors (0.3 % of the survivors are members of the set).  Two workgroups per CU around a 2^19-bit set; six
+//   passes run blind, a candidate the ring has no room for is checked in place.
+// Slide4: tables for three and four errors (slide.h), where 3 % / 32 % of the survivors are members of any set the LDS can hold.  ONE
+//   workgroup per CU around a 2^20-bit set (the whole LDS: 128 KiB + 2 KiB of ring per wave); its members look a second check
+//   stream up in a set in L2 before they count as candidates (LEVEL2); the pass loop watches the ring's room and is left for
+//   drains (DENSE: the room test in every pass costs the sparse case 4 %, the in-place path costs a dense case a factor of three).
+//   INVERT: the chains run on the complemented check stream -- an idle chain indexes 0 or 1, which are members of the set for four
+//   errors while their complements are not (context.cpp stores the set accordingly).
+// Measured, ms per GiB (tools/init_sweep.py, profiles/r05_init4): three errors 1.72-1.75 (SlideStd in a dense form, rounds 3-4) ->
+// 1.42-1.44; four errors 2.78-2.84 (a probe kernel: three table reads per survivor, 58 % of them to L2) -> 2.09-2.13.
 struct SlideStd {
 	static constexpr int BITS = SLIDE_BITS, THREADS = SLIDE_THREADS, WGS = SLIDE_WGS;
 	static constexpr uint64_t TAPS = SLIDE_TAPS, TAPS_B = 0;
-	static constexpr bool LEVEL2 = false, INVERT = false;
+	static constexpr bool LEVEL2 = false, INVERT = false, DENSE = false;
 };
 struct Slide4 {
 	static constexpr int BITS = SLIDE4_BITS, THREADS = 1024, WGS = 1;
 	static constexpr uint64_t TAPS = SLIDE4_TAPS, TAPS_B = SLIDE4B_TAPS;
-	// INVERT: the chains run on the complemented check stream -- an idle chain indexes 0 or 1, which are members of the set for
-	// four errors while their complements are not (context.cpp stores the set accordingly)
-	static constexpr bool LEVEL2 = true, INVERT = true;
+	static constexpr bool LEVEL2 = true, INVERT = true, DENSE = true;
 };
 template <class CFG> struct SlideGeom {
 	static constexpr uint32_t SET_WORDS = 1u << (CFG::BITS - 5), SET_BYTES = 4u * SET_WORDS;
@@ -732,13 +739,9 @@ template <class CFG> struct SlideGeom {
 #endif
 };
 
-// DENSE: tables for 3 errors, where 6 % of the survivors are candidates (0.3 % for <= 2 errors) and a trip fills the ring --
-// the pass loop then watches the ring's room and is left for a drain; the sparse form runs six passes blind and checks in
-// place the few candidates a full ring turns away (measured: the room test in every pass costs the sparse case 4 %, the
-// in-place path costs the dense case a factor of three).
 // MSB: the words hold their symbols MSB first in every byte (BTBBX_FMT_PACKED_MSB); a template flag, not a run-time branch: the
 // branch alone cost the LSB path 1 % here and 7 % in scan_known_lap_kernel (the words' registers become merge points)
-template <class CFG, int TILES, bool DENSE, bool MSB>
+template <class CFG, int TILES, bool MSB>
 __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(SlideGeom<CFG>::WAVES_PER_EU, SlideGeom<CFG>::WAVES_PER_EU)))
 void scan_slide_kernel(ScanArgs a)
 {
@@ -1128,7 +1131,7 @@ void scan_slide_kernel(ScanArgs a)
 #endif
 		PROF_MARK(0);
 		uint32_t pass_no = 1;
-		if (!DENSE) {
+		if constexpr (!CFG::DENSE) {
 			__builtin_amdgcn_s_setprio(PRIO_LOOP);
 #pragma unroll 1
 			for (int k = 0; k < SLIDE_FIXED; k++) { // practically every trip needs these (TILES * 128 chains of ~4 survivors)
@@ -1739,9 +1742,9 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<Slide4>::LDS_BYTES;
 #define LAUNCH_SLIDE4(MSB_) do { \
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<Slide4, SLIDE4_TILES, true, MSB_>), \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<Slide4, SLIDE4_TILES, MSB_>), \
 						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-			hipLaunchKernelGGL((scan_slide_kernel<Slide4, SLIDE4_TILES, true, MSB_>), dim3((uint32_t)grid), dim3(Slide4::THREADS), lds_bytes, stream, a); } while (0)
+			hipLaunchKernelGGL((scan_slide_kernel<Slide4, SLIDE4_TILES, MSB_>), dim3((uint32_t)grid), dim3(Slide4::THREADS), lds_bytes, stream, a); } while (0)
 			if (msb) LAUNCH_SLIDE4(true); else LAUNCH_SLIDE4(false);
 #undef LAUNCH_SLIDE4
 			break;
@@ -1751,15 +1754,15 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			constexpr uint32_t lds_bytes = SlideGeom<SlideStd>::LDS_BYTES;
 			// (tables for 4 errors through this kernel -- one tile per trip, a drain after practically every pass: 58 % of the
 			// survivors are candidates there -- ran 6.26 ms per GiB against 3.27 for scan_lap_any_kernel<9>, round 3; removed)
-#define LAUNCH_SLIDE(DENSE_, MSB_) do { \
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, DENSE_, MSB_>), \
+#define LAUNCH_SLIDE(MSB_) do { \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_>), \
 						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-			hipLaunchKernelGGL((scan_slide_kernel<SlideStd, SLIDE_TILES, DENSE_, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
+			hipLaunchKernelGGL((scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
 			if (table_errors >= 3) {
-				if (msb) LAUNCH_SLIDE(true, true); else LAUNCH_SLIDE(true, false);
-			} else {
-				if (msb) LAUNCH_SLIDE(false, true); else LAUNCH_SLIDE(false, false);
+				set_error("btbbx_scan: internal: the tables for %d errors lack their second-level set", table_errors);
+				return BTBBX_E_ARG;
 			}
+			if (msb) LAUNCH_SLIDE(true); else LAUNCH_SLIDE(false);
 #undef LAUNCH_SLIDE
 			break;
 		}
