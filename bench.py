@@ -731,6 +731,56 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
     }
 
 
+def four_error_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t, cap):
+    """The headline stream with tables for FOUR errors (btbb_init(4): 457 k error patterns) at max_ac_errors 4 -- scan_slide_kernel
+    in its two-level form (a 2^20-bit set in LDS, its members looked up in a second set in L2).  Checked in the run: with the same
+    tables and max_ac_errors 2 the list is the headline's own list (the tables only add patterns of more errors), and the list at 4
+    contains it."""
+    two = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:int(cnt_t.item())].copy()
+    full = ["offset", "lap", "ac_errors", "stream"]
+    cap = 2 * cap                                       # (a third more hits than with two errors)
+    hits_t = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+    try:
+        lib.btbbx_shutdown()
+        bt.init(4)
+
+        def step(me):
+            cnt_t.zero_()
+            bt.check(lib.btbbx_scan_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, me, hits_t.data_ptr(), cap,
+                                           cnt_t.data_ptr(), hs))
+        step(2)
+        torch.cuda.synchronize()
+        n2 = int(cnt_t.item())
+        got2 = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:min(n2, cap)].copy()
+        same = n2 == len(two) and bool(np.array_equal(np.sort(got2, order="offset")[full], np.sort(two, order="offset")[full]))
+        step(4)
+        torch.cuda.synchronize()
+        reps = 5
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+        for _ in range(reps):
+            step(4)
+        b.record(cur)
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        n4 = int(cnt_t.item())
+        fits = n4 <= cap
+        got4 = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:min(n4, cap)]
+        contains = fits and bool(np.isin(two["offset"], got4["offset"][got4["ac_errors"] <= 2]).all())
+    finally:
+        lib.btbbx_shutdown()
+        bt.init(2)
+    alg = nbits / 8 + 16 * n4
+    return {
+        "config": "BASELINE configs[1]'s stream with btbb_init(4) tables, max_ac_errors 4 (scan_slide_kernel, two-level form)",
+        "value": round(nbits / (ms * 1e-3) / 1e9, 2), "unit": "Gbit/s", "ms_per_step": round(ms, 4), "hits": n4, "hits_at_2": n2,
+        "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
+                     "kernel": "scan_slide_kernel<Slide4>", "kernel_ms": round(ms, 4), "traffic": None},
+        "parity": bool(same and contains), "list_at_2_equals_headline": same, "list_at_4_contains_headline": contains,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -742,7 +792,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 block")
     ap.add_argument("--only-secondary", default=None, metavar="NAME", help="run one line of the secondary block only (with the input it "
-                    "needs): lap_any_4gib_ordered, known_lap_79ch_chain_full_payloads, known_lap_79ch_chain, clk6_bruteforce, clk6_bruteforce_all_types")
+                    "needs): lap_any_4gib_ordered, lap_any_4gib_init4, known_lap_79ch_chain_full_payloads, known_lap_79ch_chain, clk6_bruteforce, clk6_bruteforce_all_types")
     ap.add_argument("--layout", default="single", choices=["single", "channels79"],
                     help="single: one stream of --gib GiB per GPU (weak scaling, BASELINE configs[1], the default line); "
                          "channels79: BASELINE configs[3] as written -- 79 channel streams, --gib GiB IN TOTAL (default 64), every "
@@ -904,15 +954,24 @@ def main():
         else:
             result["cpu_baseline"] = None
         if world == 1 and not args.no_secondary:
-            ordered = None
+            ordered = four = None
+            if args.only_secondary in (None, "lap_any_4gib_init4"):
+                four = four_error_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t, cap)
             if args.only_secondary in (None, "lap_any_4gib_ordered"):
+                if four is not None:                    # (the headline's own list back into hits_t)
+                    cnt_t.zero_()
+                    bt.check(lib.btbbx_scan_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2, hits_t.data_ptr(), cap,
+                                                   cnt_t.data_ptr(), hs))
+                    torch.cuda.synchronize()
                 ordered = ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t, cap, kern_ms)
             del stream, hits_t
             torch.cuda.empty_cache()
-            result["secondary"] = {} if args.only_secondary == "lap_any_4gib_ordered" else \
+            result["secondary"] = {} if args.only_secondary in ("lap_any_4gib_ordered", "lap_any_4gib_init4") else \
                 secondary(bt, lib, dev, cur, hs, cpu, not args.no_cpu, args.only_secondary)
             if ordered is not None:
                 result["secondary"]["lap_any_4gib_ordered"] = ordered
+            if four is not None:
+                result["secondary"]["lap_any_4gib_init4"] = four
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

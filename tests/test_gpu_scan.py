@@ -279,6 +279,17 @@ def test_three_and_four_error_tables_two_level_kernel(n_init):
         assert total > 1500
         for b in (d_l, d_m, d_h, d_c):
             b.free()
+        # the drop-in entry (first match only: the kernel's atomicMin mode) with these tables
+        sym, off, found, pkt = syms[0], 0, 0, C.c_void_p(None)
+        while found < 12:
+            n = len(sym) - 63 - off
+            lo, eo = C.c_uint32(0), C.c_uint8(0)
+            want = orc.orc_find_ac(C.c_void_p(sym.ctypes.data + off), n, _libs.LAP_ANY, n_init, C.byref(lo), C.byref(eo))
+            got = lib.btbb_find_ac(C.c_void_p(sym.ctypes.data + off), n, bt.LAP_ANY, n_init, C.byref(pkt))
+            assert (got if got >= 0 else -1) == want and want >= 0
+            assert lib.btbb_packet_get_lap(pkt) == lo.value and lib.btbb_packet_get_ac_errors(pkt) == eo.value
+            found += 1
+            off += want + 1
         rng = np.random.default_rng(_libs.seed(44))
         laps = rng.integers(0, 1 << 24, 4096)
         clean = [synth.syncword(int(l)) for l in laps]

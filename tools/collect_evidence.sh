@@ -21,7 +21,7 @@ timeout 300 python tools/pmc_collect.py --out $out/pmc --kernel scan_ --groups F
   SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
   -- python bench.py --steps 4 --warmup 1 --no-cpu --no-secondary > $out/pmc_scan.json 2> $out/pmc.err
 rm -rf $out/pmc
-for line in lap_any_4gib_ordered known_lap_79ch_chain_full_payloads known_lap_79ch_chain clk6_bruteforce clk6_bruteforce_all_types; do
+for line in lap_any_4gib_ordered lap_any_4gib_init4 known_lap_79ch_chain_full_payloads known_lap_79ch_chain clk6_bruteforce clk6_bruteforce_all_types; do
   timeout 300 python tools/pmc_collect.py --out $out/pmc2 --kernel "" --groups FETCH_SIZE WRITE_SIZE \
     SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_WAVE_CYCLES SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_ANY \
     -- python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary $line > $out/pmc_sec_$line.json 2> $out/pmc2.err

@@ -21,6 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = [("headline", ["--steps", "10", "--warmup", "2", "--no-cpu", "--no-secondary"], 2),
          ("lap_any_4gib_ordered", ["--steps", "2", "--warmup", "1", "--no-cpu", "--only-secondary", "lap_any_4gib_ordered"], 1),
+         ("lap_any_4gib_init4", ["--steps", "2", "--warmup", "1", "--no-cpu", "--only-secondary", "lap_any_4gib_init4"], 1),
          ("known_lap_79ch_chain_full_payloads", ["--steps", "2", "--warmup", "1", "--no-cpu", "--only-secondary", "known_lap_79ch_chain_full_payloads"], 1),
          ("known_lap_79ch_chain", ["--steps", "2", "--warmup", "1", "--no-cpu", "--only-secondary", "known_lap_79ch_chain"], 1),
          ("clk6_bruteforce", ["--steps", "2", "--warmup", "1", "--no-cpu", "--only-secondary", "clk6_bruteforce"], 1),

@@ -46,7 +46,7 @@ out = {"csrc_sha16": fp, "source": "%s/pmc_sec_<line>.json: rocprofv3 --pmc FETC
        "`python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary <line>` (one line of the block at a time: a kernel's mean "
        "per launch then belongs to one workload); (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
 CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel")
-for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_")), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
+for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_")), ("lap_any_4gib_init4", ("Slide4",)), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
                    ("clk6_bruteforce", ("trials_linear_kernel", "trials_wave_kernel")),
                    ("clk6_bruteforce_all_types", ("trials_linear_kernel", "trials_wave_kernel"))):
     path = os.path.join(d, "pmc_sec_%s.json" % line)
