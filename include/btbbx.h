@@ -109,6 +109,12 @@ int btbbx_table_errors(void);          /* the max_ac_errors the tables were buil
  * 16384 words.  *taps (may be NULL) receives the check's tap pattern: check b of a window w is the parity of
  * w & (taps << b), b = 0..18.  Returns the number of members or a negative BTBBX_E_*. */
 int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64_t *taps);
+/* The same for tables built for THREE or FOUR errors (max_ac_errors = 3 or 4), whose scan tests a survivor in two
+ * levels, as the kernel reads them: first_words = a 2^20-bit set (32768 words) over twenty positions of the check
+ * taps[0], indexed by the COMPLEMENT of the checks' value (index i, bit i & 31 of word i >> 5); second_words = a
+ * 2^24-bit set (524288 words) over twenty-four positions of the check taps[1], index i at bit 31 - (i & 31) of word
+ * i >> 5.  A window within max_ac_errors of a sync word is a member of both.  Returns 0 or a negative BTBBX_E_*. */
+int btbbx_slide_sets_two_level(int max_ac_errors, uint32_t *first_words, uint32_t *second_words, uint64_t *taps);
 
 /* ---- device memory helpers (so C callers need not link HIP themselves) -------- */
 void *btbbx_malloc(size_t bytes);

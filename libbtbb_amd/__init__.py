@@ -89,6 +89,7 @@ SIGNATURES = {
     "btbbx_device_count": (C.c_int, []),
     "btbbx_table_errors": (C.c_int, []),
     "btbbx_slide_set": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "btbbx_slide_sets_two_level": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "btbbx_malloc": (_vp, [C.c_size_t]),
     "btbbx_free": (None, [_vp]),
     "btbbx_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),

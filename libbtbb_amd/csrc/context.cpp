@@ -357,6 +357,57 @@ static int build_slide_set(const HostTables &t, int max_ac_errors, std::vector<u
 	return members;
 }
 
+// The two sets of scan_slide_kernel's two-level form (tables for three and four errors; slide.h), laid out as the kernel reads
+// them.  first: 2^SLIDE4_BITS bits over SLIDE4_TAPS for the LDS.  An idle chain of the kernel indexes 0 or 1, and with four
+// errors the all-zero value of these twenty checks IS a sum of four columns and PN's -- its complement is not: the kernel runs
+// on the COMPLEMENTED check stream (Slide4::INVERT in scan.hip), so member i stands at index ~i here.  second: 2^SLIDE4B_BITS
+// bits over SLIDE4B_TAPS, read from L2 one word per look-up: member bit of index i at bit 31 - (i & 31) of word i >> 5 (a left
+// shift by i brings it to the sign).
+static int build_two_level_sets(const HostTables &t, int max_ac_errors, std::vector<uint32_t> &first, std::vector<uint32_t> &second)
+{
+	int rc = build_slide_set(t, max_ac_errors, first, SLIDE4_BITS, SLIDE4_TAPS);
+	if (rc >= 0)
+		rc = build_slide_set(t, max_ac_errors, second, SLIDE4B_BITS, SLIDE4B_TAPS);
+	if (rc < 0)
+		return rc;
+	std::vector<uint32_t> inv(first.size(), 0);
+	const uint32_t full = (1u << SLIDE4_BITS) - 1;
+	for (uint32_t i = 0; i <= full; i++)
+		if ((first[i >> 5] >> (i & 31)) & 1)
+			inv[(i ^ full) >> 5] |= 1u << ((i ^ full) & 31);
+	first.swap(inv);
+	if (first[0] & 3u) {
+		set_error("btbbx_init: internal: index 0 / 1 of the sliding checks is a member of the candidate set");
+		return BTBBX_E_ARG;
+	}
+	for (uint32_t &w : second) {
+		uint32_t r = 0;
+		for (int k = 0; k < 32; k++)
+			r |= ((w >> k) & 1u) << (31 - k);
+		w = r;
+	}
+	return BTBBX_OK;
+}
+
+extern "C" int btbbx_slide_sets_two_level(int max_ac_errors, uint32_t *first_words, uint32_t *second_words, uint64_t *taps)
+{
+	if ((max_ac_errors != 3 && max_ac_errors != 4) || !first_words || !second_words) {
+		set_error("btbbx_slide_sets_two_level: bad argument (tables for three or four errors have these sets)");
+		return BTBBX_E_ARG;
+	}
+	std::vector<uint32_t> first, second;
+	const int rc = build_two_level_sets(host_tables(), max_ac_errors, first, second);
+	if (rc < 0)
+		return rc;
+	memcpy(first_words, first.data(), first.size() * sizeof(uint32_t));
+	memcpy(second_words, second.data(), second.size() * sizeof(uint32_t));
+	if (taps) {
+		taps[0] = SLIDE4_TAPS;
+		taps[1] = SLIDE4B_TAPS;
+	}
+	return BTBBX_OK;
+}
+
 extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64_t *taps)
 {
 	if (max_ac_errors < 0 || !bitmap_words) {
@@ -456,37 +507,12 @@ static int upload_tables(int max_ac_errors)
 	// tables for three and four errors: the two sets of scan_slide_kernel's two-level form (slide.h)
 	std::vector<uint32_t> slide4, slide4b;
 	if (max_ac_errors == 3 || max_ac_errors == 4) {
-		int rc4 = build_slide_set(t, max_ac_errors, slide4, SLIDE4_BITS, SLIDE4_TAPS);
-		if (rc4 >= 0)
-			rc4 = build_slide_set(t, max_ac_errors, slide4b, SLIDE4B_BITS, SLIDE4B_TAPS);
+		const int rc4 = build_two_level_sets(t, max_ac_errors, slide4, slide4b);
 		if (rc4 < 0)
 			return rc4;
-		// An idle chain of the kernel indexes 0 or 1 (see above), and with four errors the all-zero value of these twenty checks
-		// IS a sum of four columns and PN's -- its complement is not: the kernel for four errors runs on the COMPLEMENTED check
-		// stream (Slide4::INVERT in scan.hip), so member i stands at index ~i here.
-		{
-			std::vector<uint32_t> inv(slide4.size(), 0);
-			const uint32_t full = (1u << SLIDE4_BITS) - 1;
-			for (uint32_t i = 0; i <= full; i++)
-				if ((slide4[i >> 5] >> (i & 31)) & 1)
-					inv[(i ^ full) >> 5] |= 1u << ((i ^ full) & 31);
-			slide4.swap(inv);
-		}
-		if (slide4[0] & 3u) {
-			set_error("btbbx_init: internal: index 0 / 1 of the sliding checks is a member of the candidate set");
-			return BTBBX_E_ARG;
-		}
-		// the second level is read from global memory one word per probe: stored the way the kernel tests it, member bit of
-		// index i at bit 31 - (i & 31) (a left shift by i brings it to the sign)
-		for (uint32_t &w : slide4b) {
-			uint32_t r = 0;
-			for (int k = 0; k < 32; k++)
-				r |= ((w >> k) & 1u) << (31 - k);
-			w = r;
-		}
 	}
 
-	// one block: tabA | tabB | bitmap | slide bitmap | the two sets for four errors
+	// one block: tabA | tabB | slide set | the two sets of the two-level form
 	size_t off_a = 0, off_b = off_a + 4 * LDS_TABA_WORDS, off_m = off_b + 4 * LDS_TABB_WORDS;
 	size_t off_s = off_m;
 	size_t off_s4 = off_s + 4 * SLIDE_WORDS, off_s4b = off_s4 + 4 * slide4.size();

@@ -92,3 +92,75 @@ def test_product_candidate_set_contains_every_acceptable_window(tmp_path):
     col = [sum((((taps_c >> (i - b)) & 1) if i >= b else 0) << b for b in range(bits)) for i in range(57)]
     distinct = {0} | set(col) | {col[i] ^ col[j] for i in range(57) for j in range(i)}
     assert lib.btbbx_slide_set(2, words, None) == len(distinct)
+
+
+def _two_level_constants(tmp_path):
+    src = tmp_path / "slide4_print.cpp"
+    src.write_text('#include <stdio.h>\n#include "%s"\n'
+                   'int main() { printf("%%llx %%d %%llx %%d\\n", (unsigned long long)SLIDE4_TAPS, SLIDE4_BITS, '
+                   '(unsigned long long)SLIDE4B_TAPS, SLIDE4B_BITS); return 0; }\n'
+                   % os.path.join(ROOT, "libbtbb_amd", "csrc", "slide.h"))
+    exe = tmp_path / "slide4_print"
+    subprocess.run(["g++", "-std=c++17", "-O1", str(src), "-o", str(exe)], check=True)
+    t1, b1, t2, b2 = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    return int(t1, 16), int(b1), int(t2, 16), int(b2)
+
+
+def test_two_level_checks_vanish_on_every_sync_word_and_span_the_checks_below_the_barker_bits(tmp_path):
+    """The two check streams of the kernel for three and four errors (slide.h: SLIDE4_TAPS, SLIDE4B_TAPS): every position of both
+    has even parity on every (sync word ^ PN) and stays inside bits 1 .. 56; together they have rank 27 -- all there is: the
+    26 .. 27 independent checks of the code that avoid bit 0 and the seven bits the barker correction replaces."""
+    t1, b1, t2, b2 = _two_level_constants(tmp_path)
+    assert (b1, b2) == (20, 24) and t1 != t2
+    orc = oracle()
+    rng = np.random.default_rng(seed(4110))
+    for taps, bits in ((t1, b1), (t2, b2)):
+        assert taps & 1 == 0 and (taps << (bits - 1)) >> 57 == 0
+        for lap in [0, 0xFFFFFF, 0x9E8B33] + [int(x) for x in rng.integers(0, 1 << 24, 1500)]:
+            cw = orc.orc_gen_syncword(lap) ^ PN
+            assert all(bin(cw & (taps << b)).count("1") % 2 == 0 for b in range(bits)), hex(lap)
+    rows = [t1 << b for b in range(b1)] + [t2 << b for b in range(b2)]
+    basis = []
+    for v in rows:
+        for x in basis:
+            v = min(v, v ^ x)
+        if v:
+            basis.append(v)
+    assert len(basis) == 27
+
+
+def test_two_level_sets_contain_every_acceptable_window_and_no_idle_chain(tmp_path):
+    """btbbx_slide_sets_two_level hands out the sets as the kernel reads them (first: indexed by the complemented checks, plain bit
+    order; second: bit-reversed words).  Every window within n errors of a sync word (anything in the barker bits) is a member of
+    both; index 0 and 1 of the first -- what an idle chain of the kernel reads -- are not; and the sets are as selective as
+    DESIGN 3.1 says (a third / 3 % of all values for four / three errors in the first, a few per cent in the second)."""
+    import ctypes as C
+
+    import libbtbb_amd as bt
+
+    lib = bt.lib()
+    t1, b1, t2, b2 = _two_level_constants(tmp_path)
+    orc = oracle()
+    rng = np.random.default_rng(seed(4111))
+    first = (C.c_uint32 * (1 << (b1 - 5)))()
+    second = (C.c_uint32 * (1 << (b2 - 5)))()
+    taps = (C.c_uint64 * 2)()
+    assert lib.btbbx_slide_sets_two_level(2, first, second, taps) < 0
+    for n, lo1, hi1, hi2 in ((3, 0.02, 0.04, 0.003), (4, 0.28, 0.34, 0.03)):
+        assert lib.btbbx_slide_sets_two_level(n, first, second, taps) == 0
+        assert (taps[0], taps[1]) == (t1, t2)
+        f = np.frombuffer(first, dtype=np.uint32)
+        s = np.frombuffer(second, dtype=np.uint32)
+        assert (int(f[0]) & 3) == 0
+        d1 = np.unpackbits(f.view(np.uint8)).mean()
+        d2 = np.unpackbits(s.view(np.uint8)).mean()
+        assert lo1 < d1 < hi1 and 0 < d2 < hi2, (n, d1, d2)
+        for _ in range(1500):
+            window = orc.orc_gen_syncword(int(rng.integers(0, 1 << 24)))
+            for e in rng.choice(57, size=int(rng.integers(0, n + 1)), replace=False):
+                window ^= 1 << int(e)
+            window ^= int(rng.integers(0, 128)) << 57
+            i1 = sum((bin(window & (t1 << b)).count("1") & 1) << b for b in range(b1)) ^ ((1 << b1) - 1)
+            i2 = sum((bin(window & (t2 << b)).count("1") & 1) << b for b in range(b2))
+            assert (int(f[i1 >> 5]) >> (i1 & 31)) & 1, (n, hex(window))
+            assert (int(s[i2 >> 5]) >> (31 - (i2 & 31))) & 1, (n, hex(window))
