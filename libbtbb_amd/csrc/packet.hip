@@ -1047,9 +1047,8 @@ __device__ __forceinline__ uint32_t lds_now(const uint32_t *p)
 	return *(volatile __attribute__((address_space(3))) const uint32_t *)p;
 }
 
-#ifndef TL_THREADS
-#define TL_THREADS 1024                 // one workgroup per CU: 64 packets per batch, 144 KiB of LDS
-#endif
+#define TL_THREADS 512                  // two workgroups per CU, 32 packets per batch, 74 KiB of LDS each (one 1024-thread workgroup,
+                                        // 64 packets, 126 KiB: 0.930 against 0.921-0.926 ms per 2^20 packets, profiles/r05_trials)
 #define TL_PACKETS (TL_THREADS / 16)
 #define TL_WGS_PER_CU (1024 / TL_THREADS)
 #define TL_TRIALS  (TL_PACKETS * 64)
@@ -1198,7 +1197,7 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 	// whitening of exactly four clocks: a packet whose type varies with the clock (whitened, header FEC 1/3 decodable) puts
 	// exactly FOUR trials into EVERY type.  So type t starts at slot 4 nvar t + 64 x (packets of fixed type < t), the trial of
 	// varying packet number r and clock c is slot base[type] + 4 r + (rank of c among its four), and the 64 trials of a
-	// fixed-type packet (not whitened, or FEC 1/3 failed: SURVEY Q5) lie together behind them.  One wave ranks the 64 packets;
+	// fixed-type packet (not whitened, or FEC 1/3 failed: SURVEY Q5) lie together behind them.  One wave ranks the packets of a batch;
 	// rounds 2-4 counted every trial into its type with an LDS atomic (sixteen counters, 4096 atomics per batch) and scattered
 	// the trial numbers in a second pass behind a scan of the counters.
 	static_assert(TL_PACKETS <= 64, "one wave ranks the packets of a batch");

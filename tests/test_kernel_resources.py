@@ -105,9 +105,10 @@ def test_decoders_and_trials_keep_their_state_in_registers(kernels):
                 r"replay_kernel"):
         k = _one(kernels, pat)
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (pat, k)
-    k = _one(kernels, r"trials_linear_kernel")              # one 1024-thread workgroup per CU at the 128-register ceiling;
-    assert k["vgpr_count"] <= 128, k                        # round 4: nothing in scratch any more (index arithmetic not hoisted)
-    assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["group_segment_fixed_size"] <= LDS_PER_CU, k
+    k = _one(kernels, r"trials_linear_kernel")              # two 512-thread workgroups per CU (round 5): four waves per SIMD at
+    assert k["vgpr_count"] <= 128, k                        # the 128-register ceiling, nothing in scratch, half the LDS each
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and 2 * k["group_segment_fixed_size"] <= LDS_PER_CU, k
+    assert k["max_flat_workgroup_size"] == 512, k
 
 
 def test_order_kernels_have_no_scratch(kernels):
