@@ -731,6 +731,11 @@ template <class CFG> struct SlideGeom {
 	static constexpr uint32_t SET_WORDS = 1u << (CFG::BITS - 5), SET_BYTES = 4u * SET_WORDS;
 	static constexpr uint32_t WAVES_PER_EU = CFG::WGS * CFG::THREADS / 256;
 	static constexpr uint32_t RING = CFG::WGS == 2 ? 64 : 128;               // ring entries per wave
+#ifndef SLIDE_LANE_WORDS
+#define SLIDE_LANE_WORDS 63
+#endif
+	static constexpr uint32_t LANE_WORDS = SLIDE_LANE_WORDS;                // words of a tile a wave owns (see the kernel)
+	static constexpr uint32_t TILE_WORDS = CFG::THREADS / 64 * LANE_WORDS;
 	static constexpr uint32_t RING_END = SET_BYTES + CAND_BYTES * (CFG::THREADS / 64) * RING;
 #ifdef SCAN_PROFILE
 	static constexpr uint32_t LDS_BYTES = RING_END + 128u * (CFG::THREADS / 64);     // 32 phase counters per wave
@@ -752,6 +757,14 @@ void scan_slide_kernel(ScanArgs a)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: ring addresses stay on the SALU
+	// A wave owns LANE_WORDS = 63 consecutive words of a tile; its lane 63 works on the NEXT wave's first word, only so that
+	// lane 62 gets the check bits behind its own word (positions 64 .. 95) from a neighbour like every other lane.  (With 64
+	// words per wave those eighteen bits of lane 63 came from the scalar unit: two readlanes and 22 scalar shifts / XORs per
+	// tile and check stream -- 5 % of the instructions a wave issues per trip, for one lane; a lane in 64 idles instead.)
+	constexpr uint32_t LANE_WORDS = SlideGeom<CFG>::LANE_WORDS, TILE_WORDS = SlideGeom<CFG>::TILE_WORDS;
+	const uint32_t wid = wave * LANE_WORDS + lane;                       // this lane's word in a tile
+	uint32_t live = LANE_WORDS == 64 || lane != 63 ? 0xffffffffu : 0u;  // offsets of the lane's word that are its own
+	asm volatile("" : "+v"(live));
 	const uint32_t ring_off = SET_BYTES + CAND_BYTES * wave * RING;
 
 	// tile order: one contiguous eighth of the tiles per XCD, its workgroups interleaved (see scan_lap_any_kernel)
@@ -797,7 +810,7 @@ void scan_slide_kernel(ScanArgs a)
 			stream = tile / (uint32_t)a.tiles_per_stream;
 			t = tile - stream * (uint32_t)a.tiles_per_stream;
 		}
-		return (uint64_t)t * THREADS + wave * 64 + ((code >> 6) & 63);
+		return (uint64_t)t * TILE_WORDS + wave * LANE_WORDS + ((code >> 6) & 63);
 	};
 	// hits: up to 64 pending records per wave in registers, written 1 KiB at a time behind one counter atomic
 	uint32_t pend = 0;                            // wave-uniform
@@ -860,38 +873,51 @@ void scan_slide_kernel(ScanArgs a)
 		q_head += n;
 	};
 
-	struct Cursor { uint32_t stream; uint32_t t; };
+	// The tile cursor carries its tile's address along (one 64-bit scalar add per tile; the products stream x pitch and tile x
+	// words are formed again only when it crosses into the next stream), and a lane's word is that address + a byte offset
+	// it computes once: `global_load ... v_off, s[base]` -- no 64-bit vector address arithmetic per load (round 5: the scalar
+	// unit's instructions are not free, they take about two issue cycles each from the same wave).
+	struct Cursor { uint32_t stream; uint32_t t; const uint64_t *tp; };
 	const uint32_t tiles_per_stream = (uint32_t)a.tiles_per_stream;
-	Cursor cur = {a.n_streams, 0};               // stream == n_streams: nothing (left) to do
+	Cursor cur = {a.n_streams, 0, a.words};      // stream == n_streams: nothing (left) to do
 	uint32_t handed = 0;
+	auto tile_address = [&](const Cursor &c) { return a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * TILE_WORDS; };
 	if (n_mine) {
 		cur.stream = a.n_streams > 1 ? first_tile / tiles_per_stream : 0;
 		cur.t = first_tile - cur.stream * tiles_per_stream;
+		cur.tp = tile_address(cur);
 	}
+	const uint64_t step_words = (uint64_t)tile_step * TILE_WORDS;
 	auto advance = [&](Cursor &c) {
 		if (++handed >= n_mine) {
 			c.stream = a.n_streams;
 			return;
 		}
 		c.t += tile_step;
-		while (c.t >= tiles_per_stream && c.stream < a.n_streams) {
-			c.t -= tiles_per_stream;
-			c.stream++;
+		c.tp += step_words;
+		if (c.t >= tiles_per_stream) {
+			while (c.t >= tiles_per_stream && c.stream < a.n_streams) {
+				c.t -= tiles_per_stream;
+				c.stream++;
+			}
+			c.tp = tile_address(c);
 		}
 	};
 	auto tile_full = [&](uint32_t tt) { return tt < a.full_tiles; };
+	uint32_t voff = wid * 8u;                                            // this lane's word in a tile, in bytes
+	asm volatile("" : "+v"(voff));
 	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
 		lo = hi = 0;
 		if (c.stream >= a.n_streams)
 			return;
-		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * THREADS;   // uniform
+		const uint64_t *p = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(c.tp) + voff);
 		if (tile_full(c.t)) {
-			lo = stream_ld(tp + tid);
-			hi = stream_ld(tp + tid + 1);
+			lo = stream_ld(p);
+			hi = stream_ld(p + 1);
 		} else {
-			const uint64_t w = (uint64_t)c.t * THREADS + tid;
-			lo = w < a.n_words ? stream_ld(tp + tid) : 0;
-			hi = w + 1 < a.n_words ? stream_ld(tp + tid + 1) : 0;
+			const uint64_t w = (uint64_t)c.t * TILE_WORDS + wid;
+			lo = w < a.n_words ? stream_ld(p) : 0;
+			hi = w + 1 < a.n_words ? stream_ld(p + 1) : 0;
 		}
 	};
 
@@ -917,37 +943,42 @@ void scan_slide_kernel(ScanArgs a)
 				for (int k = 0; k < 4; k++)
 					d[u][k] = msb_dword(d[u][k]);
 			}
-			uint32_t validA = 0xffffffffu, validB = 0xffffffffu;
+			uint32_t validA = live, validB = live;
 			if (tc[u].stream >= a.n_streams) {
 				validA = validB = 0;
 			} else if (!tile_full(tc[u].t)) {
-				const uint64_t first_off = ((uint64_t)tc[u].t * THREADS + tid) * 64;
+				const uint64_t first_off = ((uint64_t)tc[u].t * TILE_WORDS + wid) * 64;
 				const uint64_t valid = first_off >= a.search_bits ? 0ULL
 					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-				validA = (uint32_t)valid;
-				validB = (uint32_t)(valid >> 32);
+				validA = (uint32_t)valid & live;
+				validB = (uint32_t)(valid >> 32) & live;
 			}
 			uint32_t cls_unused;
 			barker32(d[u][1], d[u][2], validA, m[u][0], cls_unused);    // offsets 0..31: window bits 57.. in d1:d2
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls_unused);    // offsets 32..63
 			c[u][0] = slide32<CFG::TAPS>(d[u][0], d[u][1], d[u][2]);
 			c[u][1] = slide32<CFG::TAPS>(d[u][1], d[u][2], d[u][3]);
-			// positions 64..95 = the first check dword of the next lane's word; lane 63's from the scalar unit
-			const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
-			uint32_t last = slide32_low_uniform<CFG::TAPS>(s2, s3);
 			if constexpr (CFG::INVERT) {
 				c[u][0] = ~c[u][0];
 				c[u][1] = ~c[u][1];
-				last = ~last;
 			}
-			const uint32_t next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
-			c[u][2] = lane == 63 ? last : next;
+			// positions 64..95 = the first check dword of the next lane's word (lane 63 has no offsets of its own, see above)
+			c[u][2] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c[u][0]);
 			if constexpr (CFG::LEVEL2) {
 				c2[u][0] = slide32<CFG::TAPS_B>(d[u][0], d[u][1], d[u][2]);
 				c2[u][1] = slide32<CFG::TAPS_B>(d[u][1], d[u][2], d[u][3]);
-				const uint32_t last2 = slide32_low_uniform<CFG::TAPS_B>(s2, s3);
-				const uint32_t next2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c2[u][0]);
-				c2[u][2] = lane == 63 ? last2 : next2;
+				c2[u][2] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c2[u][0]);
+			}
+			if constexpr (LANE_WORDS == 64) {                        // (the scalar unit's eighteen bits for lane 63)
+				const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
+				const uint32_t last = slide32_low_uniform<CFG::TAPS>(s2, s3);
+				if (lane == 63)
+					c[u][2] = CFG::INVERT ? ~last : last;
+				if constexpr (CFG::LEVEL2) {
+					const uint32_t last2 = slide32_low_uniform<CFG::TAPS_B>(s2, s3);
+					if (lane == 63)
+						c2[u][2] = last2;
+				}
 			}
 		}
 
@@ -1714,11 +1745,12 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			run_variant = 4;
 		else if (a.t.bitmap2 && table_errors >= 4)
 			run_variant = 8;
-		const uint32_t tile_words = run_variant == 1 ? SLIDE_THREADS : run_variant == 4 ? Slide4::THREADS : SCAN_THREADS;      // one word per thread
+		const uint32_t tile_words = run_variant == 1 ? SlideGeom<SlideStd>::TILE_WORDS : run_variant == 4 ? SlideGeom<Slide4>::TILE_WORDS : SCAN_THREADS;
+		const uint32_t halo_words = run_variant == 8 || SLIDE_LANE_WORDS == 64 ? 1 : 2;   // words behind a tile its last lane reads
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
-		{	// tile t is full iff (t + 1) * tile_words + 1 <= n_words and (t + 1) * tile_words * 64 <= search_bits
-			const uint64_t by_words = n_words ? (n_words - 1) / tile_words : 0, by_bits = search_bits / (tile_words * 64ull);
+		{	// tile t is full iff (t + 1) * tile_words + halo_words <= n_words and (t + 1) * tile_words * 64 <= search_bits
+			const uint64_t by_words = n_words >= halo_words ? (n_words - halo_words) / tile_words : 0, by_bits = search_bits / (tile_words * 64ull);
 			const uint64_t full = by_words < by_bits ? by_words : by_bits;
 			a.full_tiles = full > 0xffffffffull ? 0xffffffffu : (uint32_t)full;
 		}

@@ -108,6 +108,19 @@ KERNEL(k_lshr_sdwa, OP8_SDWA("v_lshrrev_b32_sdwa"))
 KERNEL(k_and_sdwa, OP8_SDWA("v_and_b32_sdwa"))
 
 
+// compares: to vcc (VOP2-sized encoding) and to an SGPR pair (VOP3 encoding) -- the pass of scan_slide_kernel ends in one per chain
+#define CMP8(dst) asm volatile("v_cmp_gt_i32 " dst ", 0, %0\n v_cmp_gt_i32 " dst ", 0, %1\n v_cmp_gt_i32 " dst ", 0, %2\n v_cmp_gt_i32 " dst ", 0, %3\n" \
+	"v_cmp_gt_i32 " dst ", 0, %4\n v_cmp_gt_i32 " dst ", 0, %5\n v_cmp_gt_i32 " dst ", 0, %6\n v_cmp_gt_i32 " dst ", 0, %7\n" \
+	: : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h) : "vcc", "s20", "s21");
+KERNEL(k_cmp_vcc, CMP8("vcc"))
+KERNEL(k_cmp_sgpr, CMP8("s[20:21]"))
+// (the same with the lane mask consumed by the scalar unit, as the pass does)
+KERNEL(k_cmp_vcc_sor, asm volatile("v_cmp_gt_i32 vcc, 0, %0\n s_or_b64 s[22:23], s[22:23], vcc\n v_cmp_gt_i32 vcc, 0, %1\n s_or_b64 s[22:23], s[22:23], vcc\n"
+	"v_cmp_gt_i32 vcc, 0, %2\n s_or_b64 s[22:23], s[22:23], vcc\n v_cmp_gt_i32 vcc, 0, %3\n s_or_b64 s[22:23], s[22:23], vcc\n"
+	"v_cmp_gt_i32 vcc, 0, %4\n s_or_b64 s[22:23], s[22:23], vcc\n v_cmp_gt_i32 vcc, 0, %5\n s_or_b64 s[22:23], s[22:23], vcc\n"
+	"v_cmp_gt_i32 vcc, 0, %6\n s_or_b64 s[22:23], s[22:23], vcc\n v_cmp_gt_i32 vcc, 0, %7\n s_or_b64 s[22:23], s[22:23], vcc\n"
+	: : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h) : "vcc", "scc", "s22", "s23");)
+
 // ---- source-operand VGPR banks (round 5): does it matter whether two or three sources of one instruction sit in the
 // same register bank (register number mod 4)?  Eight independent instructions per body on fixed registers: sources
 // v8..v19, destinations v20..v27, no dependence between them, so the figure is pure issue rate.
@@ -225,6 +238,9 @@ int main()
 		run("v_mbcnt_lo", k_mbcnt, d_out, w);
 		run("v_bfm_b32", k_bfm, d_out, w);
 		run("v_mov_dpp", k_movdpp, d_out, w);
+		run("v_cmp -> vcc", k_cmp_vcc, d_out, w);
+		run("v_cmp -> sgpr pair", k_cmp_sgpr, d_out, w);
+		run("v_cmp -> vcc + s_or", k_cmp_vcc_sor, d_out, w);
 		run("bitop3 banks 0,1,2", k_bitop3_b012, d_out, w);
 		run("bitop3 banks 0,0,1", k_bitop3_b001, d_out, w);
 		run("bitop3 banks 0,0,0", k_bitop3_b000, d_out, w);
