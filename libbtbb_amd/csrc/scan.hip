@@ -1012,7 +1012,9 @@ void scan_slide_kernel(ScanArgs a)
 					// ring entries left for this chain; candidates ranked beyond them (a stream made of
 					// sync words: tests/test_gpu_scan.py adversarial cases) go through the exact rule in place
 					const uint32_t room = RING - (q_tail - q_head);
-					const uint32_t n = min((uint32_t)__popcll(cm), room);
+					uint32_t in_wave;                       // (asm: the compiler turns `popcount == 1` into a 64-bit VECTOR compare)
+					asm("s_bcnt1_i32_b64 %0, %1" : "=s"(in_wave) : "s"(cm) : "scc");
+					const uint32_t n = min(in_wave, room);
 					if (cand) {
 						uint32_t lane6 = lane << 6;
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
@@ -1026,7 +1028,7 @@ void scan_slide_kernel(ScanArgs a)
 						// candidates at once) instead of this branch (for one)
 						const uint32_t code = pos | lane6 | (((it + u) << 12) | (h << 5));
 						const u32x4 rec = {code, d[u][h], d[u][h + 1], d[u][h + 2]};
-						if ((cm & (cm - 1)) == 0 && room) {
+						if (in_wave == 1 && room) {
 							// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
 							lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
 						} else {
