@@ -237,7 +237,7 @@ def test_large_error_tables(n_init):
 def test_three_and_four_error_tables_two_level_kernel(n_init):
     """btbb_init(3) and btbb_init(4) run scan_slide_kernel in its two-level form (one 1024-thread workgroup per CU, complemented check stream, the
     set's members looked up in L2 a pass later).  Against the oracle with the same tables: several streams with a pitch, LSB- and
-    MSB-first words, search lengths around word and tile boundaries (tiles of 1024 words here), every max_ac_errors the tables
+    MSB-first words, search lengths around word and tile boundaries (tiles of 1008 words here), every max_ac_errors the tables
     serve; then a stream made of sync words only (every candidate ring overflows into the in-place check) and one of sync words
     with exactly n_init errors each."""
     lib = bt.lib()
@@ -269,8 +269,9 @@ def test_three_and_four_error_tables_two_level_kernel(n_init):
             return sorted((int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt])
 
         total = 0
-        for bits, mes in ((nwords * 64 - 63, (0, 2, 3, 4, 6)), (nwords * 64 - 63 - 29, (n_init,)), (1024 * 64, (n_init,)), (1024 * 64 + 1, (n_init,)),
-                          (1024 * 64 - 1, (n_init,)), (2048 * 64 + 33, (3, 4)), (65, (n_init,)), (1, (n_init,))):
+        # (a tile of this form of the kernel is 16 waves x 63 words = 1008 words)
+        for bits, mes in ((nwords * 64 - 63, (0, 2, 3, 4, 6)), (nwords * 64 - 63 - 29, (n_init,)), (1024 * 64, (n_init,)), (1008 * 64 + 1, (n_init,)),
+                          (1008 * 64 - 1, (n_init,)), (1008 * 64, (n_init,)), (2016 * 64 + 33, (3, 4)), (63 * 64 + 7, (n_init,)), (65, (n_init,)), (1, (n_init,))):
             for me in mes:
                 want = sorted((ch, o, l, e) for ch in range(n_streams) for (o, l, e) in _libs.orc_find_all(syms[ch], bits, _libs.LAP_ANY, me))
                 assert run(d_l, 0, bits, me) == want, (bits, me)
@@ -677,7 +678,9 @@ def test_msb_first_capture_scanned_as_it_is(lap):
         return [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt]]
 
     total = 0
-    for bits in (nwords * 64 - 63, nwords * 64 - 63 - 29, 768 * 64, 768 * 64 + 1, 768 * 64 - 1, 64 * 700 + 33, 65, 1):
+    # (a tile of the LAP_ANY kernel is 12 waves x 63 words = 756 words, of the known-LAP kernel 512)
+    for bits in (nwords * 64 - 63, nwords * 64 - 63 - 29, 768 * 64, 768 * 64 + 1, 768 * 64 - 1, 756 * 64, 756 * 64 + 1, 756 * 64 - 1,
+                 2 * 756 * 64 - 63, 63 * 64 + 5, 64 * 700 + 33, 65, 1):
         want = sorted((ch, o, l, e) for ch in range(n_streams) for (o, l, e) in _libs.orc_find_all(syms[ch], bits, olap, 2))
         got_m = plain(d_m, 2, bits)
         assert got_m == plain(d_l, 0, bits) == want, (lap, bits, len(got_m), len(want))
