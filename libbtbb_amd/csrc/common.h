@@ -25,12 +25,8 @@
 #define TABA_BITS      11                  //   only bits 34..56 need tables: 34..44 (tabA) and
 #define TABB_BITS      12                  //   45..56 (tabB, with the class-0 barker / PN constant folded in)
 #define QRING          128                 // per-wave candidate ring (entries; it never holds more than 127)
-#ifndef SCAN_UNROLL
 #define SCAN_UNROLL    2                   // tiles a wave works on per loop trip (independent LDS chains)
-#endif
-#ifndef PARK_SLOTS
 #define PARK_SLOTS     2                   // private candidate slots per lane
-#endif
 #define CAND_BYTES     16                  // a parked candidate: position code + its 64-bit window + pad (one ds_*_b128)
 
 // LDS layout of scan_lap_any_kernel (bytes).  Both table bases fit the 16-bit DS offset immediate, so a

@@ -425,15 +425,9 @@ extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64
 }
 
 // size of the second-level bitmap by the error count the tables are built for (2^bits bits; 26 = 8 MiB, rounds 1-3)
-#ifndef BITMAP2_BITS_3
 #define BITMAP2_BITS_3 26
-#endif
-#ifndef BITMAP2_BITS_4
 #define BITMAP2_BITS_4 24          // 2 MiB: stays in every XCD's 4 MiB L2 beside the stream (2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51)
-#endif
-#ifndef BITMAP2_BITS_5
 #define BITMAP2_BITS_5 26
-#endif
 static int upload_tables(int max_ac_errors)
 {
 	const HostTables &t = host_tables();

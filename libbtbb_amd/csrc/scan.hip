@@ -26,7 +26,7 @@
 // max_ac_errors = 2), the survivors get the full popcount(window ^ syncword) of :433.
 //
 // scan_slide_kernel: two persistent 768-thread workgroups per CU (6 waves per SIMD; 64 KiB set + 12 KiB rings of LDS
-// each) stride over tiles of 768 words; scan_known_lap_kernel: 256-thread workgroups, tiles of 512 words.  Pure integer
+// each) stride over tiles of 756 words (63 per wave); scan_known_lap_kernel: 256-thread workgroups, tiles of 512 words.  Pure integer
 // work, no MFMA; bound by VALU issue, not by HBM (DESIGN.md 3.1 and 6 say what it is bound by).
 #include <stdlib.h>
 #include <string.h>
@@ -305,20 +305,6 @@ __device__ __forceinline__ uint32_t slide32(uint32_t e0, uint32_t e1, uint32_t e
 		acc = xor3(acc, plane[i], plane[i + 1]);
 	if ((taps.n & 1) == 0)
 		acc ^= plane[taps.n - 1];
-	return acc;
-}
-
-// the low bits (b <= 63 - highest tap) of the same for wave-uniform dwords, written with 64-bit shifts so that it
-// stays on the SALU
-template <uint64_t TAPS>
-__device__ __forceinline__ uint32_t slide32_low_uniform(uint32_t e0, uint32_t e1)
-{
-	constexpr SlideTapList taps = slide_tap_list<TAPS>();
-	const uint64_t w = ((uint64_t)e1 << 32) | e0;
-	uint32_t acc = 0;
-#pragma unroll
-	for (int i = 0; i < taps.n; i++)
-		acc ^= (uint32_t)(w >> taps.k[i]);
 	return acc;
 }
 
@@ -699,9 +685,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // words: tests/test_gpu_scan.py adversarial cases).
 // Geometry and tuning (every A/B behind these values is in profiles/: r03_ab, r05_scan).
 #define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
-#ifndef SLIDE4_TILES
 #define SLIDE4_TILES 3                     // ... of the two-level form (tables for three and four errors; 2: +2.5 %, 4: +20 %)
-#endif
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
 #define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
@@ -731,10 +715,7 @@ template <class CFG> struct SlideGeom {
 	static constexpr uint32_t SET_WORDS = 1u << (CFG::BITS - 5), SET_BYTES = 4u * SET_WORDS;
 	static constexpr uint32_t WAVES_PER_EU = CFG::WGS * CFG::THREADS / 256;
 	static constexpr uint32_t RING = CFG::WGS == 2 ? 64 : 128;               // ring entries per wave
-#ifndef SLIDE_LANE_WORDS
-#define SLIDE_LANE_WORDS 63
-#endif
-	static constexpr uint32_t LANE_WORDS = SLIDE_LANE_WORDS;                // words of a tile a wave owns (see the kernel)
+	static constexpr uint32_t LANE_WORDS = 63;                              // words of a tile a wave owns (see the kernel)
 	static constexpr uint32_t TILE_WORDS = CFG::THREADS / 64 * LANE_WORDS;
 	static constexpr uint32_t RING_END = SET_BYTES + CAND_BYTES * (CFG::THREADS / 64) * RING;
 #ifdef SCAN_PROFILE
@@ -763,7 +744,7 @@ void scan_slide_kernel(ScanArgs a)
 	// tile and check stream -- 5 % of the instructions a wave issues per trip, for one lane; a lane in 64 idles instead.)
 	constexpr uint32_t LANE_WORDS = SlideGeom<CFG>::LANE_WORDS, TILE_WORDS = SlideGeom<CFG>::TILE_WORDS;
 	const uint32_t wid = wave * LANE_WORDS + lane;                       // this lane's word in a tile
-	uint32_t live = LANE_WORDS == 64 || lane != 63 ? 0xffffffffu : 0u;  // offsets of the lane's word that are its own
+	uint32_t live = lane != 63 ? 0xffffffffu : 0u;                       // offsets of the lane's word that are its own
 	asm volatile("" : "+v"(live));
 	const uint32_t ring_off = SET_BYTES + CAND_BYTES * wave * RING;
 
@@ -968,17 +949,6 @@ void scan_slide_kernel(ScanArgs a)
 				c2[u][0] = slide32<CFG::TAPS_B>(d[u][0], d[u][1], d[u][2]);
 				c2[u][1] = slide32<CFG::TAPS_B>(d[u][1], d[u][2], d[u][3]);
 				c2[u][2] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1) << 2), (int)c2[u][0]);
-			}
-			if constexpr (LANE_WORDS == 64) {                        // (the scalar unit's eighteen bits for lane 63)
-				const uint32_t s2 = __builtin_amdgcn_readlane(d[u][2], 63), s3 = __builtin_amdgcn_readlane(d[u][3], 63);
-				const uint32_t last = slide32_low_uniform<CFG::TAPS>(s2, s3);
-				if (lane == 63)
-					c[u][2] = CFG::INVERT ? ~last : last;
-				if constexpr (CFG::LEVEL2) {
-					const uint32_t last2 = slide32_low_uniform<CFG::TAPS_B>(s2, s3);
-					if (lane == 63)
-						c2[u][2] = last2;
-				}
 			}
 		}
 
@@ -1748,7 +1718,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		else if (a.t.bitmap2 && table_errors >= 4)
 			run_variant = 8;
 		const uint32_t tile_words = run_variant == 1 ? SlideGeom<SlideStd>::TILE_WORDS : run_variant == 4 ? SlideGeom<Slide4>::TILE_WORDS : SCAN_THREADS;
-		const uint32_t halo_words = run_variant == 8 || SLIDE_LANE_WORDS == 64 ? 1 : 2;   // words behind a tile its last lane reads
+		const uint32_t halo_words = run_variant == 8 ? 1 : 2;   // words behind a tile its last lane reads
 		a.tiles_per_stream = (search_words + tile_words - 1) / tile_words;
 		a.n_tiles = a.tiles_per_stream * n_streams;
 		{	// tile t is full iff (t + 1) * tile_words + halo_words <= n_words and (t + 1) * tile_words * 64 <= search_bits

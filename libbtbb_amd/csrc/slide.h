@@ -21,9 +21,7 @@
 #pragma once
 #include <stdint.h>
 
-#ifndef SLIDE_BITS
-#define SLIDE_BITS 19                         // 20 = 128 KiB set (half the false candidates), one workgroup per CU only
-#endif
+#define SLIDE_BITS 19                         // (tables for three and four errors use SLIDE4_BITS = 20 below: one workgroup per CU)
 #define SLIDE_SPAN (56 - SLIDE_BITS)          // highest tap of q: checks 1 .. SLIDE_BITS stay inside bits 1 .. 56
 
 namespace slide {

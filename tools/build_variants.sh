@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build A/B variants of the library for the GPU box: libbtbb_amd/variants/<name>.so = the normal build with the
 # listed sources recompiled under extra -D flags (the other objects are taken from csrc/build, so `make` first).
-#   tools/build_variants.sh "scan.hip context.cpp" u3 "-DSCAN_UNROLL=3" prof "-DSCAN_PROFILE"
+#   tools/build_variants.sh "scan.hip context.cpp" prof "-DSCAN_PROFILE" x "-DSOME_SWITCH_UNDER_TEST"
 #   tools/build_variants.sh "packet.hip" tlp "-DTL_PROFILE"
 # Then, on the box (LIBBTBB_AMD_SO selects the library the Python view loads):
 #   tools/ab_test.sh libbtbb_amd/variants/u3.so      scan tests against one variant
