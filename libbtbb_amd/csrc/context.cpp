@@ -453,9 +453,9 @@ static int upload_tables(int max_ac_errors)
 	mb.mask = (1ULL << bits) - 1;
 	mb.shift = 32 - bits;
 	if (max_ac_errors >= 3) {
-		// With 32 567 (3 errors) .. 5.0 M (5) patterns the 2^19-bit LDS bitmap passes 6 % .. 100 %
-		// of the survivors; a 2^26-bit bitmap over a hash of the low 32 syndrome bits (8 MiB, L2 /
-		// Infinity Cache resident) prunes them before the pattern table is probed.
+		// With 32 567 (3 errors) .. 5.0 M (5) patterns a bitmap over a hash of the low 32 syndrome bits (2^24 .. 2^26 bits,
+		// L2 / Infinity Cache resident) prunes the candidates before the pattern table is probed (the exact check's first
+		// look; for five errors also what every survivor of scan_lap_any_kernel probes).
 		const int bits2 = max_ac_errors == 3 ? BITMAP2_BITS_3 : max_ac_errors == 4 ? BITMAP2_BITS_4 : BITMAP2_BITS_5;
 		mb.shift2 = 32 - bits2;
 		mb.bitmap2.assign(1u << (bits2 - 5), 0);

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 }
 
 
-// ---- LAP_ANY, sliding checks (tables for <= 3 errors) ----------------------------------------------
+// ---- LAP_ANY, sliding checks (tables for <= 4 errors; two cuts of one kernel: SlideStd / Slide4 below) ----
 //
 // The kernel of the headline path (promiscuous_packet_search, bluetooth_packet.c:368-420).  Per trip of
 // TILES tiles: the bit-sliced barker filter (barker32) and the check stream (slide32, slide.h) for both
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // 2^SLIDE_BITS-bit candidate set in LDS per survivor (chains as shift registers, round 5).  A candidate goes straight to
 // the wave's ring in LDS (the membership compare's lane mask + mbcnt, no atomics); the exact reference rule (verify_lap_any, syndrome tables read
 // through L2) runs on ring batches of up to 64.  The ring is the only LDS besides the set, so TWO workgroups
-// fit a CU: 2 x 768 threads = 6 waves per SIMD at <= 80 VGPRs (76 KiB of LDS each).  Measured on one box,
+// fit a CU: 2 x 768 threads = 6 waves per SIMD at <= 80 VGPRs (76 KiB of LDS each; a wave owns 63 words of a tile of 756).  Measured on one box,
 // 4 GiB, ms per launch (profiles/r03_ab/): one 1024-thread workgroup per CU (4 waves per SIMD) 4.12, 2 x 1024
 // (8 waves, 64 VGPRs, spills outside the loop) 3.82-3.90, 2 x 768 3.59, 2 x 896 / 832 / 704 / 640 (waves that do
 // not divide evenly over the four SIMDs) 4.4-5.6; the 2^20-bit set (128 KiB, one workgroup per CU only) 3.81.
@@ -1710,7 +1710,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 	ctx_scan_snapshot(&a.t, &table_errors);
 	const uint64_t search_words = (search_bits + 63) / 64;
 	if (lap == BTBBX_LAP_ANY) {
-		// tables for <= 3 errors: the sliding-check kernel (1); for four: its two-level form (4: a 2^20-bit set in LDS, its members
+		// tables for <= 2 errors: the sliding-check kernel (1); for three and four: its two-level form (4: a 2^20-bit set in LDS, its members
 		// looked up in a second set in L2, slide.h); for five every survivor probes a 2^26-bit bitmap in L2 (8: scan_lap_any_kernel)
 		int run_variant = 1;
 		if ((table_errors == 3 || table_errors == 4) && a.t.slide4_bitmap)
@@ -1756,8 +1756,6 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		case 1: {
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SlideStd>::LDS_BYTES;
-			// (tables for 4 errors through this kernel -- one tile per trip, a drain after practically every pass: 58 % of the
-			// survivors are candidates there -- ran 6.26 ms per GiB against 3.27 for scan_lap_any_kernel<9>, round 3; removed)
 #define LAUNCH_SLIDE(MSB_) do { \
 			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_>), \
 						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
