@@ -218,9 +218,13 @@ def cpu_baseline(words_host, first_word, gpu_hits, cpu):
     parity = (len(sel) == len(off) and bool(np.array_equal(sel["offset"].astype(np.uint64) - np.uint64(lo_bit), off))
               and bool(np.array_equal(sel["lap"].astype(np.uint32), laps))
               and bool(np.array_equal(sel["ac_errors"].astype(np.uint8), errs)))
+    # "cores" = the CPUs this container may use: what its cgroup grants when it has a quota (16 of the host's 256 threads on the
+    # gpurun boxes), else the logical CPUs it is allowed on; "threads" = the workers of the placement whose rate is quoted
+    # (more runnable threads than granted CPUs are throttled, not added)
+    cores_granted = int(quota) if quota is not None and 1 <= int(quota) < len(allowed) else len(allowed)
     return {
-        "value": best["Gbit_s"], "unit": "Gbit/s", "cores": best["threads"], "kind": "reference",
-        "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"],
+        "value": best["Gbit_s"], "unit": "Gbit/s", "cores": cores_granted, "threads": best["threads"], "kind": "reference",
+        "cpu_model": cpu["model"], "physical_cores": cpu["physical_cores"], "host_logical_cpus": len(allowed),
         "per_thread_Msym_s": best["per_thread_Msym_s"]["mean"], "solo_thread_Msym_s": round(solo, 2),
         "all_logical_cpus": every, "one_thread_per_core": phys, "one_thread_per_granted_cpu": granted,
         "cgroup_cpu_quota": quota,
@@ -273,6 +277,41 @@ class Timer:
         return a.elapsed_time(b) / reps
 
 
+_TSEC = None
+
+
+def secondary_traffic(name):
+    """(bytes per step, source, VALU block) of one secondary line from profiles/traffic_secondary.json -- the last rocprofv3 --pmc
+    passes over `bench.py --only-secondary <line>` (tools/collect_evidence.sh), NOT measured in this run; null when the build
+    this run loads differs from the sources that were measured."""
+    global _TSEC
+    if _TSEC is None:
+        try:
+            _TSEC = json.load(open(os.path.join(ROOT, "profiles", "traffic_secondary.json")))
+        except (OSError, ValueError):
+            _TSEC = {}
+    e = _TSEC.get(name)
+    if not e:
+        return None, None, None
+    if _TSEC.get("csrc_sha16") != csrc_fingerprint():
+        return None, "null: profiles/traffic_secondary.json was measured on sources %s, this build is %s" % (
+            _TSEC.get("csrc_sha16"), csrc_fingerprint()), None
+    return (int(e["bytes_per_step"]), "profiles/traffic_secondary.json (%s); not re-measured in this run" % _TSEC.get("source", "rocprofv3 --pmc"),
+            e.get("valu"))
+
+
+def valu_block(v, kernel_ms):
+    """roofline.valu of a line: the vector-issue time of its dominant kernel = wave-instructions per launch (PMC run) x cycles per
+    instruction (the kernel's static mix priced with tools/valu_rate.hip) / (SIMDs x clock), as a fraction of the kernel's time."""
+    if not v or not v.get("insts_per_launch"):
+        return None
+    busy_s = v["insts_per_launch"] * v["cycles_per_inst"] / (v["simds"] * v["clock_ghz"] * 1e9)
+    return {"kernel": v.get("kernel"), "insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
+            "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kernel_ms * 1e-3), 4),
+            "salu_per_valu": round((v.get("salu_insts_per_launch") or 0) / v["insts_per_launch"], 3),
+            "wait_any_frac": v.get("wait_any_frac")}
+
+
 def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
     """BASELINE configs 3 and 5, driver-timed: see the module docstring.  only: run just the named line (and what it needs
     as input) -- for the PMC passes of tools/collect_evidence.sh, whose per-kernel means must not mix two workloads."""
@@ -280,21 +319,7 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
     from libbtbb_amd import synth
     tm = Timer(cur)
     out = {}
-    # HBM traffic per step of the two secondary workloads: NOT measured in this run -- the last rocprofv3 --pmc
-    # passes over this command, kept with their derivation in profiles/traffic_secondary.json
-    try:
-        tsec = json.load(open(os.path.join(ROOT, "profiles", "traffic_secondary.json")))
-    except (OSError, ValueError):
-        tsec = {}
-
-    def traffic_of(name):
-        e = tsec.get(name)
-        if not e:
-            return None, None
-        if tsec.get("csrc_sha16") != csrc_fingerprint():
-            return None, "null: profiles/traffic_secondary.json was measured on sources %s, this build is %s" % (
-                tsec.get("csrc_sha16"), csrc_fingerprint())
-        return int(e["bytes_per_step"]), "profiles/traffic_secondary.json (%s); not re-measured in this run" % tsec.get("source", "rocprofv3 --pmc")
+    traffic_of = secondary_traffic
     ref = _libs.ref() if with_cpu else None
     if ref is not None:
         ref.btbb_init(2)
@@ -400,7 +425,8 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
                          "kernel_frac": round(scan_alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "decode_hits_kernel_ms": round(decode_ms, 4),
                          "decode_hits_kernel_frac": round((n3 * (391 + 32 + 40) + 2 * pay_bytes) / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": traffic_of(name)[0], "traffic_source": traffic_of(name)[1]},
+                         "traffic": traffic_of(name)[0], "traffic_source": traffic_of(name)[1],
+                         "valu": valu_block(traffic_of(name)[2], scan_ms)},
             "host_build_s": round(t_build, 2),
         }
         if ref is not None:
@@ -491,7 +517,8 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
         "roofline": {"bound": "hbm", "achieved": round(alg5 / (t_tr * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(alg5 / (t_tr * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_step": alg5, "kernel": "trials_linear_kernel", "kernel_ms": round(t_tr, 4),
-                     "traffic": traffic_of("clk6_bruteforce")[0], "traffic_source": traffic_of("clk6_bruteforce")[1]},
+                     "traffic": traffic_of("clk6_bruteforce")[0], "traffic_source": traffic_of("clk6_bruteforce")[1],
+                     "valu": valu_block(traffic_of("clk6_bruteforce")[2], t_tr)},
         "hec_only_table": {"value": round(npk / (t_u * 1e-3)), "unit": "packets/s", "ms_per_step": round(t_u, 4),
                            "kernel": "uap_table_kernel",
                            "frac": round(npk * (8 + 128) / (t_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -559,7 +586,8 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
         "roofline": {"bound": "hbm", "achieved": round(alg5 / (t_all * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg5 / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": alg5,
                      "kernel": "trials_linear_kernel", "kernel_ms": round(t_all, 4),
-                     "traffic": traffic_of("clk6_bruteforce_all_types")[0], "traffic_source": traffic_of("clk6_bruteforce_all_types")[1]},
+                     "traffic": traffic_of("clk6_bruteforce_all_types")[0], "traffic_source": traffic_of("clk6_bruteforce_all_types")[1],
+                     "valu": valu_block(traffic_of("clk6_bruteforce_all_types")[2], t_all)},
     }
     if ref is not None:
         m = 128
@@ -630,7 +658,9 @@ def channels79(args, bt, lib, shard, dev, rank, world, red_dev):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_ms = sum(step_ms) / args.steps
+    kern_median, kern_min = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]), step_ms[0]
     nhits = int(cnt_t.item())
     assert nhits <= cap, "hit buffer overflow"
     if args.dump_hits:
@@ -696,7 +726,7 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
     scratch; scan of the counts, scatter, rank: sort.hip).  Checked in the run: strictly increasing offsets, and the same set
     of records as the unordered list of the timed headline loop."""
     unordered = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:int(cnt_t.item())].copy()
-    order_bytes = lib.btbbx_order_hits_scratch_bytes(cap)
+    order_bytes = lib.btbbx_scan_ordered_scratch_bytes(nbits, 1, bt.LAP_ANY, cap)     # (with the segment slots: 32 B per 4032 offsets)
     scratch = torch.empty(order_bytes, dtype=torch.uint8, device=dev)
 
     def step():
@@ -717,16 +747,19 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
     increasing = bool(np.all(got["offset"][1:] > got["offset"][:-1]))
     full = ["offset", "lap", "ac_errors", "stream"]
     same = n == len(unordered) and bool(np.array_equal(got[full], np.sort(unordered, order="offset")[full]))
-    alg = nbits / 8 + 16 * n + 32 * n                  # the stream once, every record written, read and written again by the ordering
+    alg = nbits / 8 + 16 * n + 32 * n                  # the stream once, every record written (slot), read and written again (compaction)
     del scratch
     return {
         "config": "BASELINE configs[1] with the list in offset order: btbbx_scan_ordered_device on the headline stream "
-                  "(scan + bucket counts, scan of the counts, scatter, ranks of shared buckets), one stream, no host round trip",
+                  "(round 6: the scan leaves its hits, ranked, in slots of their 4032-offset segment; counts -> prefix -> one "
+                  "coalesced copy), one stream, no host round trip",
+        "scratch_bytes": int(order_bytes),
         "value": round(nbits / (ms * 1e-3) / 1e9, 2), "unit": "Gbit/s", "ms_per_step": round(ms, 4), "hits": n,
         "ordering_ms": round(ms - unordered_ms, 4), "unordered_kernel_ms": round(unordered_ms, 4),
         "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
-                     "kernel": "scan_slide_kernel + order_*", "traffic": None},
+                     "kernel": "scan_slide_kernel<ORD> + slot_*", "traffic": secondary_traffic("lap_any_4gib_ordered")[0],
+                     "traffic_source": secondary_traffic("lap_any_4gib_ordered")[1]},
         "parity": bool(increasing and same), "strictly_increasing": increasing, "equals_sorted_unordered_list": same,
     }
 
@@ -776,7 +809,9 @@ def four_error_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cn
         "value": round(nbits / (ms * 1e-3) / 1e9, 2), "unit": "Gbit/s", "ms_per_step": round(ms, 4), "hits": n4, "hits_at_2": n2,
         "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
-                     "kernel": "scan_slide_kernel<Slide4>", "kernel_ms": round(ms, 4), "traffic": None},
+                     "kernel": "scan_slide_kernel<Slide4>", "kernel_ms": round(ms, 4), "traffic": secondary_traffic("lap_any_4gib_init4")[0],
+                     "traffic_source": secondary_traffic("lap_any_4gib_init4")[1],
+                     "valu": valu_block(secondary_traffic("lap_any_4gib_init4")[2], ms)},
         "parity": bool(same and contains), "list_at_2_equals_headline": same, "list_at_4_contains_headline": contains,
     }
 
@@ -873,7 +908,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_ms = sum(step_ms) / args.steps
+    kern_median, kern_min = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]), step_ms[0]
     nhits = int(cnt_t.item())
     assert nhits <= cap, "hit buffer overflow"
     if args.dump_hits:
@@ -935,6 +972,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan_slide_kernel", "kernel_ms": round(kern_ms, 4),
+                         "kernel_ms_median": round(kern_median, 4), "kernel_ms_min": round(kern_min, 4), "kernel_ms_max": round(step_ms[-1], 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "valu": valu},
             "csrc_sha16": fp,
         }

@@ -107,6 +107,7 @@ SIGNATURES = {
     "btbbx_sort_hits": (None, [_vp, C.c_size_t]),
     "btbbx_sort_hits_device": (C.c_int, [_vp, _u32, _vp]),
     "btbbx_order_hits_scratch_bytes": (C.c_size_t, [_u32]),
+    "btbbx_scan_ordered_scratch_bytes": (C.c_size_t, [_u64, _u32, _u32, _u32]),
     "btbbx_order_hits_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _vp]),
     "btbbx_order_scan_hits_device": (C.c_int, [_vp, _vp, _u32, _u32, _u64, _vp, C.c_size_t, _vp]),
     "btbbx_scan_ordered_device": (C.c_int, [_vp, _u64, _u64, _u32, _u64, _u32, C.c_int, _vp, _u32, _vp, _vp, C.c_size_t, _vp]),

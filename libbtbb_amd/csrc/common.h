@@ -60,6 +60,19 @@ struct ScanTables {
 	uint32_t bitmap2_shift;    // index = (low32 * golden) >> shift
 };
 
+// Segment slots of the ordered LAP_ANY scan (scan.hip scan_slide_kernel<..., ORD> fills them, sort.hip lays them out and compacts them)
+struct ScanSlots {
+	btbbx_hit *slots;          // [segments][slot_n]
+	uint16_t *cnt;             // [segments] hits per segment, zeroed before the scan
+	uint32_t slot_n;
+	uint32_t segs_per_stream;
+	btbbx_hit *ovf_recs;       // hits ranked beyond a segment's slots ...
+	void *ovf_meta;            // ... with their (segment, rank) as uint2
+	uint32_t ovf_cap;
+	uint32_t *ovf_count;
+	uint32_t *irregular;
+};
+
 // packed hash slot: bits 0..33 syndrome, then five 6-bit error positions (63 = unused),
 // ascending.  Empty slot = all ones.
 #define HSLOT_EMPTY 0xffffffffffffffffULL

@@ -484,15 +484,17 @@ static int upload_tables(int max_ac_errors)
 		tabB[v] = (uint32_t)s;
 	}
 
-	std::vector<uint32_t> slide_bitmap;
-	{
+	// The 2^SLIDE_BITS-bit set is read by the one-level form of scan_slide_kernel only (tables for <= 2 errors; three and four run the
+	// two-level form on their own sets, five the probe kernel): for larger tables it stays empty -- launch_scan refuses the one-level
+	// kernel with them -- and its C(57, n) sums are not enumerated for nothing.
+	std::vector<uint32_t> slide_bitmap(SLIDE_WORDS, 0u);
+	if (max_ac_errors <= 2) {
 		const int rc_slide = build_slide_set(t, max_ac_errors, slide_bitmap);
 		if (rc_slide < 0)
 			return rc_slide;
 		// scan_slide_kernel lets a chain that has run out of survivors shift itself out: its index is then 0 or 1.  Those two
-		// must not be members, or a lane without a survivor would look like a candidate (true for every table set of this code;
-		// the tables for >= 4 errors run the probe kernels, which do not rely on it).
-		if (max_ac_errors <= 3 && (slide_bitmap[0] & 3u)) {
+		// must not be members, or a lane without a survivor would look like a candidate (true for the table sets of this code).
+		if (slide_bitmap[0] & 3u) {
 			set_error("btbbx_init: internal: index 0 / 1 of the sliding checks is a member of the candidate set");
 			return BTBBX_E_ARG;
 		}

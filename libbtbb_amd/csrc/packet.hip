@@ -1234,8 +1234,8 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 			if (lane >= (uint32_t)dd)
 				incl += up;
 		}
-		if (lane < 17)
-			type_base[lane] = 4u * nvar * lane + 64u * (incl - cf);      // (lane 16: the end of the last type)
+		if (lane < 16)
+			type_base[lane] = 4u * nvar * lane + 64u * (incl - cf);
 		if (lane == 17)
 			type_base[17] = nvar;
 		if (tid < TL_PACKETS)

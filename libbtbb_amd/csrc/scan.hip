@@ -58,6 +58,21 @@ struct ScanArgs {
 	uint32_t *bucket_cnt;
 	uint64_t bucket_mul;
 	uint32_t bucket_shift;
+	// btbbx_scan_ordered_device, LAP_ANY with tables for <= 2 errors (scan_slide_kernel<..., ORD>; the ordering itself: sort.hip
+	// "segment slots"): a SEGMENT = the 63 words of a tile one wave owns.  All hits of a segment come out of ONE drain of ONE wave,
+	// which ranks them by offset among themselves and stores each in the segment's own slots -- plain stores, no counter, no
+	// atomic; hits ranked beyond the slots go to an overflow list with (segment, rank).  null = off.
+	btbbx_hit *seg_slots;        // [segments][seg_slot_n]
+	uint16_t *seg_cnt;           // hits of the segment (all of them, also those in the overflow list); zeroed by the caller
+	uint32_t seg_slot_n;
+	uint32_t segs_per_stream;    // tiles_per_stream x waves per tile
+	btbbx_hit *ovf_recs;         // overflow list: records ...
+	uint2 *ovf_meta;             // ... and their (segment, rank)
+	uint32_t ovf_cap;
+	uint32_t *ovf_count;
+	uint32_t *irregular;         // set when a hit left outside a drain (a ring without room: a stream of sync words) or the overflow list is full:
+	                             // the caller falls back to the general ordering
+	const uint32_t *gate;        // the fallback launch itself: returns at once unless *gate != 0
 	ScanTables t;
 };
 
@@ -687,9 +702,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 #define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
 #define SLIDE4_TILES 3                     // ... of the two-level form (tables for three and four errors; 2: +2.5 %, 4: +20 %)
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
-#define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
-#define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
-#define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
+#ifndef SLIDE_THREADS
+#define SLIDE_THREADS 768
+#endif
+//                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 %
+#ifndef SLIDE_HITREG
+#define SLIDE_HITREG 0                     // 1: the fixed passes keep their membership results in a hit register per chain (no compare, scalar OR or branch per pass)
+#endif
+#ifndef SLIDE_HITREG_UNROLL
+#define SLIDE_HITREG_UNROLL 1
+#endif
+#ifndef SLIDE_DIRECT
+#define SLIDE_DIRECT 0                     // 1: a drain writes its hits straight behind one counter atomic (no pending records in registers)
+#endif
+#ifndef SLIDE_FIXED
+#define SLIDE_FIXED 6
+#endif
+//                                         // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
+#ifndef SLIDE_DRAIN_AT
+#define SLIDE_DRAIN_AT 60u
+#endif
+#define SLIDE_DRAIN_AT_ORD 40u
+//                                        // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms)
 // The kernel's two cuts.
 // SlideStd: tables for <= 2 errors (0.3 % of the survivors are members of the set).  Two workgroups per CU around a 2^19-bit set; six
 //   passes run blind, a candidate the ring has no room for is checked in place.
@@ -714,7 +748,11 @@ struct Slide4 {
 template <class CFG> struct SlideGeom {
 	static constexpr uint32_t SET_WORDS = 1u << (CFG::BITS - 5), SET_BYTES = 4u * SET_WORDS;
 	static constexpr uint32_t WAVES_PER_EU = CFG::WGS * CFG::THREADS / 256;
+#ifdef SCAN_PROFILE
+	static constexpr uint32_t RING = 64;                                    // (the phase counters need 2 KiB of the two-level form's full LDS)
+#else
 	static constexpr uint32_t RING = CFG::WGS == 2 ? 64 : 128;               // ring entries per wave
+#endif
 	static constexpr uint32_t LANE_WORDS = 63;                              // words of a tile a wave owns (see the kernel)
 	static constexpr uint32_t TILE_WORDS = CFG::THREADS / 64 * LANE_WORDS;
 	static constexpr uint32_t RING_END = SET_BYTES + CAND_BYTES * (CFG::THREADS / 64) * RING;
@@ -723,17 +761,23 @@ template <class CFG> struct SlideGeom {
 #else
 	static constexpr uint32_t LDS_BYTES = RING_END;
 #endif
+	static_assert((uint64_t)LDS_BYTES * CFG::WGS <= 160u * 1024u, "the workgroups a CU is cut for must fit its 160 KiB of LDS");
 };
 
 // MSB: the words hold their symbols MSB first in every byte (BTBBX_FMT_PACKED_MSB); a template flag, not a run-time branch: the
 // branch alone cost the LSB path 1 % here and 7 % in scan_known_lap_kernel (the words' registers become merge points)
-template <class CFG, int TILES, bool MSB>
+// ORD: hits leave through the segment slots (ScanArgs::seg_slots) instead of the appended list
+template <class CFG, int TILES, bool MSB, bool ORD = false>
 __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(SlideGeom<CFG>::WAVES_PER_EU, SlideGeom<CFG>::WAVES_PER_EU)))
 void scan_slide_kernel(ScanArgs a)
 {
 	extern __shared__ uint32_t lds[];
+	if (a.gate && *a.gate == 0)
+		return;
 	constexpr uint32_t RING = SlideGeom<CFG>::RING;
 	constexpr uint32_t THREADS = CFG::THREADS, SET_WORDS = SlideGeom<CFG>::SET_WORDS, SET_BYTES = SlideGeom<CFG>::SET_BYTES;
+	constexpr bool HITREG = SLIDE_HITREG && !CFG::DENSE;
+	constexpr int HR_UNROLL = SLIDE_HITREG_UNROLL;
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
@@ -783,6 +827,7 @@ void scan_slide_kernel(ScanArgs a)
 #endif
 	uint32_t q_head = 0, q_tail = 0;          // wave-uniform ring cursors (free running)
 	// code = (tile iteration << 12) | (lane that owns the word << 6) | offset in the word
+	uint32_t code_tile = 0;                       // (set by code_word: the tile's number inside its stream)
 	auto code_word = [&](uint32_t code, uint32_t &stream) {
 		const uint32_t tile = first_tile + (code >> 12) * tile_step;
 		uint32_t t = tile;
@@ -791,6 +836,7 @@ void scan_slide_kernel(ScanArgs a)
 			stream = tile / (uint32_t)a.tiles_per_stream;
 			t = tile - stream * (uint32_t)a.tiles_per_stream;
 		}
+		code_tile = t;
 		return (uint64_t)t * TILE_WORDS + wave * LANE_WORDS + ((code >> 6) & 63);
 	};
 	// hits: up to 64 pending records per wave in registers, written 1 KiB at a time behind one counter atomic
@@ -825,6 +871,24 @@ void scan_slide_kernel(ScanArgs a)
 		if (!m)
 			return;
 		const uint32_t c = (uint32_t)__popcll(m);
+		if constexpr (SLIDE_DIRECT) {
+			// the drain's hits (a third of its sixty candidates on the benchmark stream) go out behind one counter atomic
+			uint32_t base = 0;
+			if (lane == 0)
+				base = atomicAdd(a.hit_count, c);
+			base = __builtin_amdgcn_readfirstlane(base);
+			const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+			if (hit && idx < a.hit_cap) {
+				uint4 rec;
+				rec.x = (uint32_t)offset;
+				rec.y = (uint32_t)(offset >> 32);
+				rec.z = lap;
+				rec.w = nerr | (stream << 16);
+				reinterpret_cast<uint4 *>(a.hits)[idx] = rec;
+				count_bucket(a, stream, offset);
+			}
+			return;
+		}
 		if (pend + c > 64)
 			flush_hits();
 		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -839,18 +903,117 @@ void scan_slide_kernel(ScanArgs a)
 		}
 		pend += c;
 	};
+	// Hit-register form (HITREG): a candidate's record says WHICH survivor of its chain it was (ordinal k, not the offset: the
+	// pass loop keeps no positions).  The drain -- sixty candidates at once -- rebuilds the chain's survivor mask from the two
+	// stream dwords of the record that held the barker bits (the same barker32 under the same validity mask as the filter) and
+	// takes its k-th set bit.
+	auto ordinal_to_pos = [&](uint32_t code, uint64_t word, uint32_t dm, uint32_t dh) {
+		const uint64_t first_off = word * 64 + (code & 32);
+		const uint32_t valid = first_off >= a.search_bits ? 0u
+			: (a.search_bits - first_off >= 32 ? 0xffffffffu : ((1u << (uint32_t)(a.search_bits - first_off)) - 1));
+		uint32_t m0, cls_unused;
+		barker32(dm, dh, valid, m0, cls_unused);
+		// coded ordinal e: a fixed pass k = 0 .. SLIDE_FIXED - 1 leaves e = 32 - SLIDE_FIXED + k (v_ffbh of its flag in the hit
+		// register), tail pass j leaves e = j for the ordinal SLIDE_FIXED + j
+		for (uint32_t k = (code + SLIDE_FIXED) & 31; k; k--)         // (a divergent loop: as many trips as the batch's largest ordinal)
+			m0 &= m0 - 1;
+		return lowest_bit(m0) & 31;
+	};
 	auto drain = [&](uint32_t n) {               // the n <= 64 oldest ring entries through the exact rule
 		bool hit = false;
 		uint32_t stream = 0, lap = 0, nerr = 0;
 		uint64_t offset = 0;
+		u32x4 rec = {0u, 0u, 0u, 0u};
+		if (lane < n)
+			rec = lds_ld4(ring_off + CAND_BYTES * ((q_head + lane) & (RING - 1)));
+		uint32_t code = rec.x;
+		const uint64_t word = code_word(code, stream);
+		if constexpr (HITREG)
+			code = (code & ~31u) | ordinal_to_pos(code, word, rec.z, rec.w);
 		if (lane < n) {
-			const u32x4 rec = lds_ld4(ring_off + CAND_BYTES * ((q_head + lane) & (RING - 1)));
-			const uint32_t code = rec.x;
 			const uint64_t w = ((uint64_t)alignbit(rec.w, rec.z, code) << 32) | alignbit(rec.z, rec.y, code);   // (shift = the low five bits)
-			offset = code_word(code, stream) * 64 + (code & 63);
+			offset = word * 64 + (code & 63);
 			hit = verify_lap_any<false>(a, w, lap, nerr);
 		}
-		push_hits(hit, stream, offset, lap, nerr);
+		if constexpr (ORD) {
+			// A drain takes whole trips, so every hit of a segment (tile iteration code >> 12 of this wave) is in this batch: its
+			// rank = the hits of the same tile with a smaller code (lane, offset) -- one scalar trip per hit of the batch --, its
+			// place = slot `rank` of the segment.  The hit with the highest rank stores the segment's count.
+			const uint64_t hm = __ballot(hit);
+			if (hm) {
+				uint32_t rank = 0, count = 0;
+				// The ring is empty now (its records sit in registers) and lends its kilobyte: a hit counter per tile iteration of the
+				// batch -- ring entries are in trip order, so the iterations run from the oldest entry's (even) one to the newest's -- and
+				// room for four 12-bit codes per tile.  A hit's count = its tile's counter, its rank = the codes of its tile below its own.
+				// (One scalar trip per hit of the batch over all lanes instead -- 300 instructions per drain -- cost the launch 8 %.)
+				// A batch that spans 64 iterations or more (a sparse stream: few hits) or a tile with more than four hits: that loop.
+				const uint32_t it_mine = code >> 12;
+				const uint32_t it_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)it_mine) & ~1u;
+				const uint32_t it_hi = (uint32_t)__builtin_amdgcn_readlane((int)it_mine, (int)(n - 1)) | 1u;
+				bool fast = it_hi - it_lo < 64u;
+				if (fast) {
+					const uint32_t key = (it_mine - it_lo) & 63u;
+					lds_st(ring_off + 4u * lane, 0u);
+					uint32_t idx = 0;
+					if (hit) {
+						idx = __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t *>(ring_off + 4u * key), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (idx < 4u)
+							*reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(ring_off + 256u + 8u * key + 2u * idx) = (uint16_t)(code & 0xfffu);
+					}
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					if (hit)
+						count = lds_ld(ring_off + 4u * key);
+					if (__ballot(count > 4u)) {
+						fast = false;
+					} else if (hit) {
+						const uint32_t lo2 = lds_ld(ring_off + 256u + 8u * key), hi2 = lds_ld(ring_off + 260u + 8u * key);
+						const uint32_t mine = code & 0xfffu;
+						rank = ((lo2 & 0xffffu) < mine ? 1u : 0u);                      // (entry 0 always exists; the own entry is not below itself)
+						rank += count > 1u && (lo2 >> 16) < mine ? 1u : 0u;
+						rank += count > 2u && (hi2 & 0xffffu) < mine ? 1u : 0u;
+						rank += count > 3u && (hi2 >> 16) < mine ? 1u : 0u;
+					}
+				}
+				if (!fast) {
+					rank = count = 0;
+					for (uint64_t r = hm; r; r &= r - 1) {
+						const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)__builtin_ctzll(r));
+						const bool same = (code ^ cj) < 4096u;
+						count += same ? 1u : 0u;
+						rank += same && cj < code ? 1u : 0u;
+					}
+				}
+				const uint32_t seg = stream * a.segs_per_stream + code_tile * (THREADS / 64) + wave;
+				uint4 out;
+				out.x = (uint32_t)offset;
+				out.y = (uint32_t)(offset >> 32);
+				out.z = lap;
+				out.w = nerr | (stream << 16);
+				const bool spill = hit && rank >= a.seg_slot_n;
+				if (hit && !spill)
+					reinterpret_cast<uint4 *>(a.seg_slots)[(uint64_t)seg * a.seg_slot_n + rank] = out;
+				if (hit && rank + 1 == count)
+					a.seg_cnt[seg] = (uint16_t)count;            // (<= 4032 offsets per segment)
+				const uint64_t om = __ballot(spill);
+				if (om) {                                            // more hits in 4032 offsets than a segment has slots: rare
+					uint32_t base = 0;
+					if (lane == 0)
+						base = atomicAdd(a.ovf_count, (uint32_t)__popcll(om));
+					base = __builtin_amdgcn_readfirstlane(base);
+					const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
+					if (spill) {
+						if (idx < a.ovf_cap) {
+							reinterpret_cast<uint4 *>(a.ovf_recs)[idx] = out;
+							a.ovf_meta[idx] = make_uint2(seg, rank);
+						} else {
+							*a.irregular = 1u;
+						}
+					}
+				}
+			}
+		} else {
+			push_hits(hit, stream, offset, lap, nerr);
+		}
 		q_head += n;
 	};
 
@@ -970,7 +1133,8 @@ void scan_slide_kernel(ScanArgs a)
 			return __ballot(any != 0) != 0;
 		};
 		uint32_t pos2[TILES][2];                     // (two-level form) where the chains stood when their pending look-ups were sent
-		auto events = [&](const uint64_t (&cms)[TILES][2]) {   // append the wave's candidates of one pass to its ring
+		const uint32_t no_ordinal[TILES][2] = {};
+		auto events = [&](const uint64_t (&cms)[TILES][2], const uint32_t (&ordinal)[TILES][2]) {   // append the wave's candidates of one pass to its ring
 #pragma unroll
 			for (int u = 0; u < TILES; u++)
 #pragma unroll
@@ -990,7 +1154,9 @@ void scan_slide_kernel(ScanArgs a)
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
 						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
 						uint32_t pos;
-						if constexpr (CFG::LEVEL2)
+						if constexpr (HITREG)
+							pos = ordinal[u][h];                    // (the survivor's ordinal in its chain, coded; the drain turns it into the offset)
+						else if constexpr (CFG::LEVEL2)
 							pos = pos2[u][h];
 						else
 							asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
@@ -1010,9 +1176,17 @@ void scan_slide_kernel(ScanArgs a)
 								uint32_t stream, lap, nerr, cold = code;
 								asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
 								const uint64_t word = code_word(cold, stream);
+								if constexpr (HITREG) {
+									pos = ordinal_to_pos(cold, word, rec.z, rec.w);
+									cold = (cold & ~31u) | pos;
+								}
 								const uint32_t wlo = alignbit(rec.z, rec.y, pos), whi = alignbit(rec.w, rec.z, pos);
-								if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr))
-									emit_hit(a, stream, word * 64 + (code & 63), lap, nerr);
+								if (verify_lap_any<false>(a, ((uint64_t)whi << 32) | wlo, lap, nerr)) {
+									if constexpr (ORD)
+										*a.irregular = 1u;          // a hit outside the drains: its segment cannot be ranked here
+									else
+										emit_hit(a, stream, word * 64 + (cold & 63), lap, nerr);
+								}
 							}
 						}
 					}
@@ -1068,7 +1242,7 @@ void scan_slide_kernel(ScanArgs a)
 				}
 			any_sent = 0;
 			if (any)
-				events(cms);
+				events(cms, no_ordinal);
 		};
 		auto pass = [&]() {
 			Stage g;
@@ -1090,7 +1264,7 @@ void scan_slide_kernel(ScanArgs a)
 				if (any)
 					level2_send(cms);
 			} else if (any) {                            // some lane of the wave holds a candidate (half of the passes)
-				events(cms);
+				events(cms, no_ordinal);
 			}
 		};
 		// Behind the fixed passes a handful of the wave's 2 * TILES * 64 chains still hold survivors (0.8 % have seven or more):
@@ -1098,6 +1272,10 @@ void scan_slide_kernel(ScanArgs a)
 		// loop's exit test), instead of paying the full pass for two or three lanes.
 		auto sparse_tail = [&]() {
 			uint64_t live[TILES][2], anyl = 0;
+			uint32_t tail_ord[TILES][2];                 // HITREG: ordinals SLIDE_FIXED, SLIDE_FIXED + 1, ... coded as 0, 1, ... (see hit_events)
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+				tail_ord[u][0] = tail_ord[u][1] = 0;
 #pragma unroll
 			for (int u = 0; u < TILES; u++)
 #pragma unroll
@@ -1123,7 +1301,12 @@ void scan_slide_kernel(ScanArgs a)
 						anyl |= live[u][h];
 					}
 				if (anyc)
-					events(cms);
+					events(cms, tail_ord);
+				if constexpr (HITREG) {
+#pragma unroll
+					for (int u = 0; u < TILES; u++)
+						tail_ord[u][0] = tail_ord[u][1] = tail_ord[u][0] + 1;
+				}
 			}
 		};
 #ifdef SCAN_PROFILE
@@ -1134,7 +1317,65 @@ void scan_slide_kernel(ScanArgs a)
 #endif
 		PROF_MARK(0);
 		uint32_t pass_no = 1;
-		if constexpr (!CFG::DENSE) {
+		if constexpr (HITREG) {
+			// The fixed passes without a compare, a scalar OR or a branch: the sign bit of (set word << index) -- "member" -- is
+			// shifted into the chain's hit register; ONE look at the registers behind the last pass finds the trip's candidates
+			// (4.5 per trip) and their records say which survivor of the chain it was.
+			__builtin_amdgcn_s_setprio(PRIO_LOOP);
+			uint32_t acc[TILES][2];
+#pragma unroll
+			for (int u = 0; u < TILES; u++)
+				acc[u][0] = acc[u][1] = 0;
+#pragma unroll HR_UNROLL
+			for (int k = 0; k < SLIDE_FIXED; k++) {
+				Stage g;
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						step(u, h, g);
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						acc[u][h] = alignbit(acc[u][h], g.bw[u][h] << (g.v[u][h] & 31), 31);
+				PROF_MARK(pass_no < 13 ? pass_no : 13);
+				pass_no++;
+			}
+			for (;;) {                                   // (a second trip only when some chain holds two candidates)
+				uint64_t cms[TILES][2], any = 0;
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						cms[u][h] = __ballot(acc[u][h] != 0);
+						any |= cms[u][h];
+					}
+				if (!any)
+					break;
+				uint32_t fb[TILES][2];
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						asm("v_ffbh_u32 %0, %1" : "=v"(fb[u][h]) : "v"(acc[u][h]));
+				events(cms, fb);
+#ifdef SLIDE_HITREG_ONCE        // timing only: chains with two candidates lose one
+				break;
+#endif
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						acc[u][h] &= ~(0x80000000u >> (fb[u][h] & 31));      // (an empty register: fb = ~0, bit 0 of nothing)
+			}
+			sparse_tail();
+			PROF_MARK(pass_no < 13 ? pass_no : 13);
+			__builtin_amdgcn_s_setprio(PRIO_CAND);
+			PROF_MARK(16);
+			if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
+				drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
+		} else if constexpr (!CFG::DENSE) {
 			__builtin_amdgcn_s_setprio(PRIO_LOOP);
 #pragma unroll 1
 			for (int k = 0; k < SLIDE_FIXED; k++) { // practically every trip needs these (TILES * 128 chains of ~4 survivors)
@@ -1146,7 +1387,9 @@ void scan_slide_kernel(ScanArgs a)
 			PROF_MARK(pass_no < 13 ? pass_no : 13);
 			__builtin_amdgcn_s_setprio(PRIO_CAND);
 			PROF_MARK(16);
-			if (q_tail - q_head >= (RING == 64 ? SLIDE_DRAIN_AT : 64u))
+			// (ORD: drained at 40, which costs nothing measurable -- profiles/r06_scan -- and leaves every trip room for 24 candidates
+			// where it has 4.5: a hit verified in place, outside the drains, then only happens to streams made of sync words)
+			if (q_tail - q_head >= (RING == 64 ? (ORD ? SLIDE_DRAIN_AT_ORD : SLIDE_DRAIN_AT) : 64u))
 				drain(q_tail - q_head > 64 ? 64 : q_tail - q_head);
 		} else {
 			// The pass loop is left when the ring gets short of room (a.ring_margin entries: what a pass may add), drained at
@@ -1668,11 +1911,30 @@ static int check_scan_args(uint64_t n_words, uint64_t pitch_words, uint32_t n_st
 	return BTBBX_OK;
 }
 
+// geometry of the segment slots for a scan of these streams (sort.hip sizes its scratch from it); false: this scan has no slot form
+// (known LAP, or tables for more than two errors)
+bool scan_slot_geometry(uint64_t search_bits, uint32_t n_streams, uint32_t lap, uint32_t *segs_per_stream, uint64_t *n_segs)
+{
+	int table_errors = 0;
+	ScanTables t;
+	ctx_scan_snapshot(&t, &table_errors);
+	if (lap != BTBBX_LAP_ANY || table_errors > 2 || !t.slide_bitmap)
+		return false;
+	const uint64_t search_words = (search_bits + 63) / 64;
+	const uint64_t tiles = (search_words + SlideGeom<SlideStd>::TILE_WORDS - 1) / SlideGeom<SlideStd>::TILE_WORDS;
+	const uint64_t per_stream = tiles * (SlideStd::THREADS / 64), total = per_stream * n_streams;
+	if (total >= (1ull << 31))
+		return false;
+	*segs_per_stream = (uint32_t)per_stream;
+	*n_segs = total;
+	return true;
+}
+
 int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		uint32_t n_streams, uint64_t search_bits, uint32_t lap, int max_ac_errors,
 		btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
 		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt = nullptr, uint64_t bucket_mul = 0,
-		uint32_t bucket_shift = 0, bool msb = false)
+		uint32_t bucket_shift = 0, bool msb = false, const ScanSlots *slots = nullptr, const uint32_t *gate = nullptr)
 {
 	int rc = ctx_require();
 	if (rc)
@@ -1704,6 +1966,27 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 	a.bucket_cnt = bucket_cnt;
 	a.bucket_mul = bucket_mul;
 	a.bucket_shift = bucket_shift;
+	a.seg_slots = nullptr;
+	a.seg_cnt = nullptr;
+	a.seg_slot_n = 0;
+	a.segs_per_stream = 0;
+	a.ovf_recs = nullptr;
+	a.ovf_meta = nullptr;
+	a.ovf_cap = 0;
+	a.ovf_count = nullptr;
+	a.irregular = nullptr;
+	a.gate = gate;
+	if (slots) {
+		a.seg_slots = slots->slots;
+		a.seg_cnt = slots->cnt;
+		a.seg_slot_n = slots->slot_n;
+		a.segs_per_stream = slots->segs_per_stream;
+		a.ovf_recs = slots->ovf_recs;
+		a.ovf_meta = reinterpret_cast<uint2 *>(slots->ovf_meta);
+		a.ovf_cap = slots->ovf_cap;
+		a.ovf_count = slots->ovf_count;
+		a.irregular = slots->irregular;
+	}
 	a.xcd_tiles = 0;
 	a.ring_margin = 4;
 	int table_errors = 0;
@@ -1737,6 +2020,10 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		static unsigned long long zero_prof[32];
 		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), zero_prof, sizeof(zero_prof)));
 #endif
+		if (slots && run_variant != 1) {
+			set_error("btbbx_scan: internal: segment slots with a kernel that has none");
+			return BTBBX_E_ARG;
+		}
 		switch (run_variant) {
 		case 8:
 			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_lap_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES));
@@ -1756,15 +2043,23 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		case 1: {
 			a.ring_margin = 24u;
 			constexpr uint32_t lds_bytes = SlideGeom<SlideStd>::LDS_BYTES;
-#define LAUNCH_SLIDE(MSB_) do { \
-			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_>), \
+#define LAUNCH_SLIDE(MSB_, ORD_) do { \
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_, ORD_>), \
 						    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-			hipLaunchKernelGGL((scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
+			hipLaunchKernelGGL((scan_slide_kernel<SlideStd, SLIDE_TILES, MSB_, ORD_>), dim3((uint32_t)grid), dim3(SLIDE_THREADS), lds_bytes, stream, a); } while (0)
 			if (table_errors >= 3) {
 				set_error("btbbx_scan: internal: the tables for %d errors lack their second-level set", table_errors);
 				return BTBBX_E_ARG;
 			}
-			if (msb) LAUNCH_SLIDE(true); else LAUNCH_SLIDE(false);
+			if (slots) {
+				if (a.segs_per_stream != a.tiles_per_stream * (SLIDE_THREADS / 64) || d_first) {
+					set_error("btbbx_scan: internal: segment slots laid out for another geometry");
+					return BTBBX_E_ARG;
+				}
+				if (msb) LAUNCH_SLIDE(true, true); else LAUNCH_SLIDE(false, true);
+			} else {
+				if (msb) LAUNCH_SLIDE(true, false); else LAUNCH_SLIDE(false, false);
+			}
 #undef LAUNCH_SLIDE
 			break;
 		}
@@ -1977,7 +2272,7 @@ static int64_t scan_resident(const uint64_t *d_words, uint64_t n_words, uint64_t
 		// scan in (stream, offset) order on the call's private stream -- nothing shared with other callers, no lock, no
 		// allocation in steady state (round 3 ordered through btbbx_sort_hits_device's per-device scratch and its mutex)
 		const size_t rec_bytes = ((size_t)dev_cap * sizeof(btbbx_hit) + 255) & ~(size_t)255;
-		const size_t order_bytes = dev_cap >= 2 ? btbbx_order_hits_scratch_bytes(dev_cap) : 0;
+		const size_t order_bytes = dev_cap >= 2 ? btbbx_scan_ordered_scratch_bytes(search_bits, 1, lap, dev_cap) : 0;   // (segment slots where the scan has them)
 		char *block = (char *)scope_hits(256 + rec_bytes + order_bytes);
 		if (!block)
 			return BTBBX_E_NOMEM;

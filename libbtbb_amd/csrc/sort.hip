@@ -163,9 +163,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 template <int ORDER_SCAN_ITEMS>
 __global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *cnt, uint32_t nb, uint32_t *block_sums, OrderParams *p,
 							       const uint32_t *d_count, uint32_t n_imm, uint32_t cap, uint32_t nb_log2,
-							       uint32_t bounds_streams, unsigned long long max_offset)
+							       uint32_t bounds_streams, unsigned long long max_offset, const uint32_t *gate)
 {
 	__shared__ uint32_t lds_wave[16];
+	if (gate && !*gate)
+		return;
 	if (bounds_streams && blockIdx.x == 0 && threadIdx.x == 0) {
 		const unsigned long long mul = max_offset + 1;
 		p->mul = mul;
@@ -195,10 +197,12 @@ __global__ __launch_bounds__(1024) void order_scan_sums_kernel(const uint32_t *c
 // every workgroup adds up the sums of the workgroups before it itself (at most 1024 numbers from L2: cheaper than a
 // launch for a one-workgroup scan in between)
 template <int ORDER_SCAN_ITEMS>
-__global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, uint32_t nb, const uint32_t *block_sums)
+__global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, uint32_t nb, const uint32_t *block_sums, const uint32_t *gate)
 {
 	__shared__ uint32_t lds_wave[16];
 	__shared__ uint32_t my_base;
+	if (gate && !*gate)
+		return;
 	{
 		const uint32_t v = threadIdx.x < blockIdx.x ? block_sums[threadIdx.x] : 0;      // gridDim.x <= 1024
 		uint32_t before;
@@ -233,8 +237,10 @@ __global__ __launch_bounds__(1024) void order_scan_apply_kernel(uint32_t *cnt, u
 // others, else ~0 -- four bytes per record that tell order_rank_list_kernel whom to rank (a dense worklist appended with one
 // counter atomic per wave made this kernel 130 us: 20 000 atomics on one address, profiles/r04_paths/chain_kernels_worklist.csv)
 __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hits, OrderParams *p, const uint32_t *start,
-							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final, uint32_t *work)
+							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *final, uint32_t *work, const uint32_t *gate)
 {
+	if (gate && !*gate)
+		return;
 	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -255,9 +261,9 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const btbbx_hit *hit
 
 // one thread per record, the ones that share a bucket work: rank among the bucket-mates (they sit in L1 / L2), into place
 __global__ __launch_bounds__(256) void order_rank_list_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
-							      const uint32_t *work, btbbx_hit *out)
+							      const uint32_t *work, btbbx_hit *out, const uint32_t *gate)
 {
-	if (!p->any_shared)
+	if ((gate && !*gate) || !p->any_shared)
 		return;                                         // every record alone in its bucket (sparse lists: the usual case)
 	const uint32_t n = p->n, shift = p->shift;
 	const unsigned long long mul = p->mul;
@@ -299,13 +305,13 @@ __global__ __launch_bounds__(256) void order_rank_kernel(const btbbx_hit *groupe
 // the record's own -- exact because keys are unique, and checked: a bucket whose bitmap holds fewer bits than it has
 // members (a repeated key) is redone by all pairs.
 __global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
-							     uint32_t nb, btbbx_hit *out)
+							     uint32_t nb, btbbx_hit *out, const uint32_t *gate)
 {
 	extern __shared__ uint32_t bits[];                  // 2^shift bits, then 1024 group prefixes
 	__shared__ uint32_t lds_wave[16];
 	__shared__ uint32_t found[1024], n_found;
 	__shared__ unsigned long long win_lo, win_hi;
-	if (!p->crowded)
+	if ((gate && !*gate) || !p->crowded)
 		return;
 	const uint32_t shift = p->shift;
 	const unsigned long long mul = p->mul;
@@ -411,6 +417,153 @@ __global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *gr
 	}
 }
 
+// ---- segment slots: the ordered LAP_ANY scan without a sort (round 6) ------------------------------------------------------
+//
+// scan_slide_kernel<..., ORD> (scan.hip) leaves every hit in a slot of its SEGMENT -- the 63 words of a tile one wave owns, 4032
+// offsets -- at its rank among the segment's hits, and the segment's count in cnt[segment]: plain stores next to each other in
+// stream order, which the L2 of the XCD that works on that part of the stream merges into whole lines.  The list in (stream, offset)
+// order is then a COMPACTION of the slots: counts -> prefix -> one copy, every read and write coalesced; no bucket atomics in the
+// scan, no scatter, no ranking of bucket-mates.  Hits ranked beyond the slots (more than SLOT_N in 4032 offsets) wait in an overflow
+// list with (segment, rank) and are put at prefix[segment] + rank by one more launch that usually finds nothing.
+#ifndef SLOT_N
+#define SLOT_N 2u                              // slots per segment
+#endif
+#define SLOT_BLOCK 1024u                       // segments per workgroup of the compaction
+
+struct SlotHeader {
+	uint32_t ovf_count;        // records in the overflow list (scan)
+	uint32_t irregular;        // the scan could not rank a hit (ScanArgs::irregular): the general path redoes the call
+	uint32_t total;            // hits found
+	uint32_t pad;
+};
+
+// (zeroing as a kernel: the fallback's counters are only cleared when the fallback runs)
+__global__ __launch_bounds__(256) void slot_gated_zero_kernel(uint4 *p, uint64_t n16, uint32_t *count, const uint32_t *gate)
+{
+	if (gate && !*gate)
+		return;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+		p[i] = make_uint4(0, 0, 0, 0);
+	if (count && blockIdx.x == 0 && threadIdx.x == 0)
+		*count = 0;
+}
+
+// slots -> list: a workgroup takes SLOT_BLOCK x SLOT_PER segments, a thread SLOT_PER consecutive ones (their counts are one 16-byte
+// load).  Two launches: the sums of the workgroups' counts; then every workgroup adds up the sums in front of it itself (about a
+// thousand numbers out of L2 for a 4 GiB stream) and copies its segments' records to where they go -- the records of a segment's
+// slots lie in rank order.  A segment with hits in the overflow list leaves its start for slot_overflow_kernel.
+// (One launch with a look-back between the workgroups was tried first: 870 us against 110 -- a release / acquire at device scope
+// writes back / invalidates the L2 of an XCD, and every workgroup did both; profiles/r06_order.)
+#define SLOT_PER 8u                            // segments per thread
+static_assert(SLOT_PER == 8, "a thread's counts are one uint4");
+
+__device__ __forceinline__ uint32_t slot_counts(const uint16_t *cnt, uint32_t n_segs, uint32_t first, uint32_t (&c)[SLOT_PER])
+{
+	uint32_t sum = 0;
+	if (first + SLOT_PER <= n_segs) {                     // (cnt is 256-byte aligned, first a multiple of 8)
+		const uint4 v = *reinterpret_cast<const uint4 *>(cnt + first);
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			c[2 * k] = w[k] & 0xffffu;
+			c[2 * k + 1] = w[k] >> 16;
+		}
+	} else {
+#pragma unroll
+		for (uint32_t k = 0; k < SLOT_PER; k++)
+			c[k] = first + k < n_segs ? cnt[first + k] : 0u;
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < SLOT_PER; k++)
+		sum += c[k];
+	return sum;
+}
+
+__global__ __launch_bounds__(1024) void slot_sums_kernel(const uint16_t *cnt, uint32_t n_segs, uint32_t *block_sums)
+{
+	__shared__ uint32_t lds_wave[16];
+	uint32_t c[SLOT_PER], total;
+	const uint32_t mine = slot_counts(cnt, n_segs, (blockIdx.x * SLOT_BLOCK + threadIdx.x) * SLOT_PER, c);
+	(void)block_exclusive_scan_1024(mine, lds_wave, total);
+	if (threadIdx.x == 0)
+		block_sums[blockIdx.x] = total;
+}
+
+// (a wave takes 64 x SLOT_PER consecutive segments, a lane every 64th of them: counts, slots and output are read and written
+// by neighbouring lanes next to each other -- eight consecutive segments per lane instead made this kernel 194 us against 75)
+__global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, uint32_t n_segs, const uint32_t *block_sums, SlotHeader *hd,
+							  const HitRec *slots, uint32_t *seg_start, HitRec *out, uint32_t cap, uint32_t *d_count)
+{
+	__shared__ uint32_t lds_wave[16];
+	uint32_t before = 0, all = 0;                         // sums of the workgroups in front of this one / of all of them
+	for (uint32_t first = 0; first < gridDim.x; first += 1024) {
+		const uint32_t i = first + threadIdx.x;
+		const uint32_t v = i < gridDim.x ? block_sums[i] : 0u;
+		uint32_t t_before, t_all;
+		(void)block_exclusive_scan_1024(i < blockIdx.x ? v : 0u, lds_wave, t_before);
+		(void)block_exclusive_scan_1024(v, lds_wave, t_all);
+		before += t_before;
+		all += t_all;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		hd->total = all;
+		*d_count = all;
+	}
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t wfirst = (blockIdx.x * SLOT_BLOCK + wave * 64) * SLOT_PER;      // the wave's first segment
+	uint32_t c[SLOT_PER], mine = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < SLOT_PER; k++) {
+		const uint32_t seg = wfirst + k * 64 + lane;
+		c[k] = seg < n_segs ? cnt[seg] : 0u;
+		mine += c[k];
+	}
+	for (int d = 32; d; d >>= 1)
+		mine += __shfl_xor(mine, d);
+	if (lane == 0)
+		lds_wave[wave] = mine;
+	__syncthreads();
+	uint32_t run = before;
+	for (uint32_t w = 0; w < wave; w++)
+		run += lds_wave[w];
+	if (mine == 0)
+		return;                                           // (wave-uniform)
+#pragma unroll
+	for (uint32_t k = 0; k < SLOT_PER; k++) {
+		const uint32_t n = c[k];
+		uint32_t inc = n;
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(inc, d);
+			if (lane >= (uint32_t)d)
+				inc += t;
+		}
+		const uint32_t pos = run + inc - n;
+		run += __shfl(inc, 63);
+		if (n == 0)
+			continue;
+		const uint32_t seg = wfirst + k * 64 + lane;
+		const HitRec *src = slots + (uint64_t)seg * SLOT_N;
+#pragma unroll
+		for (uint32_t r = 0; r < SLOT_N; r++)
+			if (r < n && pos + r < cap)
+				out[pos + r] = src[r];
+		if (n > SLOT_N)
+			seg_start[seg] = pos;
+	}
+}
+
+__global__ __launch_bounds__(256) void slot_overflow_kernel(const SlotHeader *hd, const HitRec *recs, const uint2 *meta, uint32_t ovf_cap,
+							     const uint32_t *seg_start, HitRec *out, uint32_t cap)
+{
+	const uint32_t n = min(hd->ovf_count, ovf_cap);
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const uint2 m = meta[i];
+		const uint64_t pos = (uint64_t)seg_start[m.x] + m.y;
+		if (pos < cap)
+			out[pos] = recs[i];
+	}
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 
 static uint32_t order_nb_log2(uint32_t cap)
@@ -469,7 +622,7 @@ extern "C" size_t btbbx_order_hits_scratch_bytes(uint32_t cap)
 // d_hits only receives the ordered list
 static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_imm, uint32_t cap, void *d_scratch,
 			size_t scratch_bytes, hipStream_t stream, uint32_t n_streams = 0, uint64_t max_offset = 0,
-			bool counted_by_scan = false)
+			bool counted_by_scan = false, const uint32_t *gate = nullptr)
 {
 	if (cap < 2)
 		return BTBBX_OK;
@@ -529,30 +682,30 @@ static int order_launch(btbbx_hit *d_hits, const uint32_t *d_count, uint32_t n_i
 	}
 	if (scan_items == 4) {
 		hipLaunchKernelGGL(order_scan_sums_kernel<4>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
-				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset, gate);
 		mark();
-		hipLaunchKernelGGL(order_scan_apply_kernel<4>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+		hipLaunchKernelGGL(order_scan_apply_kernel<4>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, gate);
 	} else {
 		hipLaunchKernelGGL(order_scan_sums_kernel<16>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, p, d_count, n_imm, cap, L.nb_log2,
-				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset);
+				   bounds && counted_by_scan ? n_streams : 0u, (unsigned long long)max_offset, gate);
 		mark();
-		hipLaunchKernelGGL(order_scan_apply_kernel<16>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums);
+		hipLaunchKernelGGL(order_scan_apply_kernel<16>, dim3(scan_blocks), dim3(1024), 0, stream, start, nb, sums, gate);
 	}
 	mark();
 	if (counted_by_scan) {
 		// parked -> d_hits (records alone in their bucket: in place) / grouped (the others), then the records that share a bucket
 		const btbbx_hit *parked = (const btbbx_hit *)(base + L.parked);
 		uint32_t *work = (uint32_t *)(base + L.work);
-		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits, work);
+		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, parked, p, start, cursor, grouped, d_hits, work, gate);
 		mark();
-		hipLaunchKernelGGL(order_rank_list_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, work, d_hits);
+		hipLaunchKernelGGL(order_rank_list_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, work, d_hits, gate);
 	} else {
 		hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits, p, start, cursor, grouped, (btbbx_hit *)nullptr,
-				   (uint32_t *)nullptr);
+				   (uint32_t *)nullptr, gate);
 		hipLaunchKernelGGL(order_rank_kernel, dim3(blocks), dim3(256), 0, stream, grouped, p, start, d_hits);
 	}
 	mark();
-	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits);
+	hipLaunchKernelGGL(order_crowded_kernel, dim3(std::min(nb, 256u)), dim3(1024), crowded_lds, stream, grouped, p, start, nb, d_hits, gate);
 	mark();
 	if (timing && n_ev) {
 		(void)hipEventSynchronize(ev[n_ev - 1]);
@@ -601,7 +754,44 @@ extern "C" int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d
 // leaves it.  Nothing is synchronised.
 int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams, uint64_t search_bits,
 		uint32_t lap, int max_ac_errors, btbbx_hit *d_hits, uint32_t hit_cap, uint32_t *d_hit_count,
-		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift, bool msb);
+		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift, bool msb,
+		const ScanSlots *slots, const uint32_t *gate);
+
+// ---- segment slots: layout behind the general ordering's scratch (which the fallback uses) ----
+bool scan_slot_geometry(uint64_t search_bits, uint32_t n_streams, uint32_t lap, uint32_t *segs_per_stream, uint64_t *n_segs);
+
+struct SlotLayout { size_t header, cnt, sums, seg_start, slots, ovf_recs, ovf_meta, total; uint32_t n_segs, n_blocks, ovf_cap, segs_per_stream; };
+static SlotLayout slot_layout(size_t front, uint32_t segs_per_stream, uint64_t n_segs, uint32_t cap)
+{
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	SlotLayout S;
+	S.n_segs = (uint32_t)n_segs;
+	S.segs_per_stream = segs_per_stream;
+	S.n_blocks = (uint32_t)((n_segs + SLOT_BLOCK * SLOT_PER - 1) / (SLOT_BLOCK * SLOT_PER));
+	S.ovf_cap = cap;
+	S.header = up(front);
+	S.cnt = S.header + 256;                                   // (header and counts: one memset)
+	S.sums = S.cnt + up(n_segs * sizeof(uint16_t) + 16);
+	S.seg_start = S.sums + up(((size_t)S.n_blocks + 1) * 4);
+	S.slots = S.seg_start + up(n_segs * 4);
+	S.ovf_recs = S.slots + up(n_segs * SLOT_N * sizeof(btbbx_hit));
+	S.ovf_meta = S.ovf_recs + up((size_t)cap * sizeof(btbbx_hit));
+	S.total = S.ovf_meta + up((size_t)cap * 8);
+	return S;
+}
+
+// Scratch of btbbx_scan_ordered_device for a scan of these streams: the general ordering's (btbbx_order_hits_scratch_bytes(cap))
+// plus, where the scan has the segment-slot form (LAP_ANY with tables for up to two errors), its slots -- 32 bytes per 4032
+// offsets + 24 bytes per record of cap.  A caller that hands over btbbx_order_hits_scratch_bytes(cap) only gets the general path.
+extern "C" size_t btbbx_scan_ordered_scratch_bytes(uint64_t search_bits, uint32_t n_streams, uint32_t lap, uint32_t cap)
+{
+	const size_t front = order_layout(cap ? cap : 1, n_streams, search_bits).total;
+	uint32_t sps = 0;
+	uint64_t n_segs = 0;
+	if (!n_streams || !search_bits || ctx_require() || !scan_slot_geometry(search_bits, n_streams, lap, &sps, &n_segs))
+		return front;
+	return slot_layout(front, sps, n_segs, cap).total;
+}
 
 extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,
 					     uint64_t search_bits, uint32_t lap, int max_ac_errors, int format, btbbx_hit *d_hits, uint32_t cap,
@@ -619,17 +809,58 @@ extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n
 	}
 	hipStream_t stream = (hipStream_t)hip_stream;
 	char *base = (char *)d_scratch;
-	HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
-	// the list is built from this call's matches only (they are parked in the scratch, not appended to d_hits): the counter
-	// starts at zero whatever the caller left in it -- a stale count would send uninitialised parked records through the ordering
-	HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
 	const uint32_t shift = order_shift(n_streams, search_bits, L.nb_log2);
+	const bool msb = format == BTBBX_FMT_PACKED_MSB;
+	const uint32_t *gate = nullptr;
+	{	// segment slots where the scan has them and the caller's scratch holds them: scan into the slots, compact
+		uint32_t sps = 0;
+		uint64_t n_segs = 0;
+		if (scan_slot_geometry(search_bits, n_streams, lap, &sps, &n_segs) && ((uintptr_t)d_hits & 15) == 0) {
+			const SlotLayout S = slot_layout(L.total, sps, n_segs, cap);
+			if (scratch_bytes >= S.total) {
+				SlotHeader *hd = (SlotHeader *)(base + S.header);
+				HIP_TRY(hipMemsetAsync(base + S.header, 0, S.sums - S.header, stream));
+				ScanSlots sl;
+				sl.slots = (btbbx_hit *)(base + S.slots);
+				sl.cnt = (uint16_t *)(base + S.cnt);
+				sl.slot_n = SLOT_N;
+				sl.segs_per_stream = S.segs_per_stream;
+				sl.ovf_recs = (btbbx_hit *)(base + S.ovf_recs);
+				sl.ovf_meta = base + S.ovf_meta;
+				sl.ovf_cap = S.ovf_cap;
+				sl.ovf_count = &hd->ovf_count;
+				sl.irregular = &hd->irregular;
+				int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, nullptr, 0, d_count,
+						     nullptr, stream, nullptr, 0, 0, msb, &sl, nullptr);
+				if (rc)
+					return rc;
+				uint32_t *sums = (uint32_t *)(base + S.sums);
+				hipLaunchKernelGGL(slot_sums_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums);
+				hipLaunchKernelGGL(slot_place_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums, hd,
+						   (const HitRec *)(base + S.slots), (uint32_t *)(base + S.seg_start), (HitRec *)d_hits, cap, d_count);
+				hipLaunchKernelGGL(slot_overflow_kernel, dim3(64), dim3(256), 0, stream, hd, (const HitRec *)(base + S.ovf_recs),
+						   (const uint2 *)(base + S.ovf_meta), S.ovf_cap, (const uint32_t *)(base + S.seg_start), (HitRec *)d_hits, cap);
+				HIP_TRY(hipGetLastError());
+				// a hit the scan could not rank (ScanArgs::irregular: streams made of sync words): everything below runs again, this
+				// time for real; otherwise each of its launches returns at its first instruction
+				gate = &hd->irregular;
+			}
+		}
+	}
+	if (gate) {
+		hipLaunchKernelGGL(slot_gated_zero_kernel, dim3(512), dim3(256), 0, stream, (uint4 *)base, (uint64_t)(L.sums / 16), d_count, gate);
+	} else {
+		HIP_TRY(hipMemsetAsync(base, 0, L.sums, stream));
+		// the list is built from this call's matches only (they are parked in the scratch, not appended to d_hits): the counter
+		// starts at zero whatever the caller left in it -- a stale count would send uninitialised parked records through the ordering
+		HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+	}
 	// the scan leaves its records in the scratch (and counts each in its bucket); the ordering puts them into d_hits
 	int rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, (btbbx_hit *)(base + L.parked), cap, d_count,
-			     nullptr, stream, (uint32_t *)(base + L.start), search_bits, shift, format == BTBBX_FMT_PACKED_MSB);
+			     nullptr, stream, (uint32_t *)(base + L.start), search_bits, shift, msb, nullptr, gate);
 	if (rc)
 		return rc;
-	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, stream, n_streams, search_bits - 1, true);
+	return order_launch(d_hits, d_count, 0, cap, d_scratch, scratch_bytes, stream, n_streams, search_bits - 1, true, gate);
 }
 
 extern "C" int btbbx_scan_ordered_device(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words, uint32_t n_streams,

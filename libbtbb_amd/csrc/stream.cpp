@@ -177,7 +177,8 @@ extern "C" int64_t btbbx_stream_feed(btbbx_stream *s, const void *data, uint64_t
 		return BTBBX_E_ARG;
 	}
 	// the staging copy is the slowest stage of feed(): split large chunks over a few host threads
-	staging_copy(dst, data, s->format == BTBBX_FMT_SYMBOLS ? n_symbols : ((n_symbols + 63) / 64) * 8);
+	// (a byte-packed MSB-first buffer holds ceil(n / 8) bytes: nothing beyond them is read; submit() zeroes the rest of the last word)
+	staging_copy(dst, data, s->format == BTBBX_FMT_SYMBOLS ? n_symbols : s->format == BTBBX_FMT_PACKED_MSB ? (n_symbols + 7) / 8 : ((n_symbols + 63) / 64) * 8);
 	return btbbx_stream_submit(s, n_symbols, hits, cap);
 }
 

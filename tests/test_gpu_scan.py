@@ -594,11 +594,16 @@ def test_device_hit_order_with_the_count_in_hbm():
         run(hits(np.arange(n, dtype=np.uint64) * 77, 0), cap=max(n, 4))
 
 
+@pytest.mark.parametrize("slots", [False, True])
 @pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33, 0x1E8B33])
-def test_scan_ordered_device(lap):
+def test_scan_ordered_device(lap, slots):
     """btbbx_scan_ordered_device: one call, the list comes back in (stream, offset) order and equals the oracle's per
     stream -- LAP_ANY and known LAPs of both barker classes, several streams with a pitch, a hit buffer smaller than the
-    number of matches (the records kept are then some subset, still ordered, and the counter says how many there were)."""
+    number of matches (the records kept are then some subset, still ordered, and the counter says how many there were).
+    slots: the scratch of btbbx_scan_ordered_scratch_bytes -- the LAP_ANY scan then leaves its hits in the segment slots (round 6;
+    a sync word every 512 symbols = eight hits per 4032-offset segment of two slots: most of the list goes through the overflow
+    list, and a hit buffer that is too small keeps exactly the smallest records); else btbbx_order_hits_scratch_bytes -- the
+    general ordering, which is also what a known LAP gets either way."""
     lib = bt.lib()
     kw = dict(stride=512) if lap == bt.LAP_ANY else dict(stride=512, lap=lap)
     n_streams, nwords, pitch = 5, 3000 + 7, 3100
@@ -617,7 +622,8 @@ def test_scan_ordered_device(lap):
     for cap in (len(want) + 100, len(want) // 3, (1 << 21) - 3, (1 << 21) + 1, (1 << 22) + 5, (1 << 23) + 5, (1 << 24) + 3):
         d_h = bt.DeviceBuffer(cap * 16).zero()
         d_c = bt.DeviceBuffer(16).zero()
-        sb = lib.btbbx_order_hits_scratch_bytes(cap)
+        sb = lib.btbbx_scan_ordered_scratch_bytes(nwords * 64 - 63 - 11, n_streams, lap, cap) if slots else lib.btbbx_order_hits_scratch_bytes(cap)
+        assert (sb > lib.btbbx_order_hits_scratch_bytes(cap)) == (slots and lap == bt.LAP_ANY)
         d_s = bt.DeviceBuffer(sb)
         bt.check(lib.btbbx_scan_ordered_device(d_w.ptr, nwords, pitch, n_streams, nwords * 64 - 63 - 11, lap, 2, d_h.ptr, cap, d_c.ptr,
                                                d_s.ptr, sb, None), "btbbx_scan_ordered_device")
@@ -632,6 +638,9 @@ def test_scan_ordered_device(lap):
         if cap >= cnt:
             assert tup == want
         else:
+            # (segment slots: the compaction writes positions 0 .. cap - 1 of the whole list -- the cap smallest records --
+            # unless the overflow list, cap entries, ran full as well and the general ordering redid the call: eight hits per
+            # two-slot segment here)
             assert len(tup) == cap and set(tup) <= set(want)
     d_w.free()
 
@@ -660,7 +669,8 @@ def test_msb_first_capture_scanned_as_it_is(lap):
     d_h = bt.DeviceBuffer(cap * 16)
     d_c = bt.DeviceBuffer(16)
     sb = lib.btbbx_order_hits_scratch_bytes(cap)
-    d_s = bt.DeviceBuffer(sb)
+    sb_slots = lib.btbbx_scan_ordered_scratch_bytes(nwords * 64 - 63, n_streams, lap, cap)    # (LAP_ANY: with the segment slots)
+    d_s = bt.DeviceBuffer(max(sb, sb_slots))
 
     def plain(d_w, fmt, bits):
         d_c.zero()
@@ -669,10 +679,10 @@ def test_msb_first_capture_scanned_as_it_is(lap):
         cnt = int(d_c.download(np.uint32, 4)[0])
         return sorted((int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt])
 
-    def ordered(d_w, fmt, bits):
+    def ordered(d_w, fmt, bits, scratch_bytes=None):
         d_c.upload(np.array([12345, 0, 0, 0], np.uint32))               # stale: the call must not trust it
         bt.check(lib.btbbx_scan_ordered_device_fmt(d_w.ptr, nwords, pitch, n_streams, bits, lap, 2, fmt, d_h.ptr, cap, d_c.ptr,
-                                                   d_s.ptr, sb, None), "scan_ordered_fmt")
+                                                   d_s.ptr, scratch_bytes or sb, None), "scan_ordered_fmt")
         bt.check(lib.btbbx_sync(None))
         cnt = int(d_c.download(np.uint32, 4)[0])
         return [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in d_h.download(bt.HIT_DTYPE, cap)[:cnt]]
@@ -685,6 +695,7 @@ def test_msb_first_capture_scanned_as_it_is(lap):
         got_m = plain(d_m, 2, bits)
         assert got_m == plain(d_l, 0, bits) == want, (lap, bits, len(got_m), len(want))
         assert ordered(d_m, 2, bits) == want == ordered(d_l, 0, bits), (lap, bits)
+        assert ordered(d_m, 2, bits, sb_slots) == want == ordered(d_l, 0, bits, sb_slots), (lap, bits, "segment slots")
         total += len(want)
     assert total > 300
     with pytest.raises(bt.BtbbError):

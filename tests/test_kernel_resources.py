@@ -67,7 +67,9 @@ def _waves_per_simd(vgprs):
 
 def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
     """2 x 768 threads per CU = 6 waves per SIMD; the set + rings are dynamic LDS (76 KiB per workgroup)."""
-    for pat in (r"scan_slide_kernelI8SlideStdLi2ELb0E", r"scan_slide_kernelI8SlideStdLi2ELb1E"):
+    # (MSB first or not) x (hits appended to a list, or left in their segment's slots for the ordered scan: round 6)
+    for pat in (r"scan_slide_kernelI8SlideStdLi2ELb0ELb0E", r"scan_slide_kernelI8SlideStdLi2ELb1ELb0E",
+                r"scan_slide_kernelI8SlideStdLi2ELb0ELb1E", r"scan_slide_kernelI8SlideStdLi2ELb1ELb1E"):
         k = _one(kernels, pat)
         assert k["vgpr_count"] <= 80 and _waves_per_simd(k["vgpr_count"]) >= 6, k
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
@@ -77,7 +79,7 @@ def test_lap_any_kernel_two_workgroups_of_768_per_cu(kernels):
 def test_lap_any_kernel_for_three_and_four_errors_one_workgroup_per_cu(kernels):
     """the two-level form owns the CU -- 1024 threads = 4 waves per SIMD, the 2^20-bit set + rings = the whole LDS."""
     for msb in (0, 1):
-        k = _one(kernels, r"scan_slide_kernelI6Slide4Li3ELb%dE" % msb)
+        k = _one(kernels, r"scan_slide_kernelI6Slide4Li3ELb%dELb0E" % msb)
         assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
         assert k["max_flat_workgroup_size"] == 1024, k
 

@@ -46,7 +46,9 @@ out = {"csrc_sha16": fp, "source": "%s/pmc_sec_<line>.json: rocprofv3 --pmc FETC
        "`python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary <line>` (one line of the block at a time: a kernel's mean "
        "per launch then belongs to one workload); (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
 CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel")
-for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_")), ("lap_any_4gib_init4", ("Slide4",)), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
+DOMINANT = {"lap_any_4gib_ordered": "scan_slide_kernel", "lap_any_4gib_init4": "Slide4", "known_lap_79ch_chain_full_payloads": "scan_known_lap_kernel",
+            "known_lap_79ch_chain": "scan_known_lap_kernel", "clk6_bruteforce": "trials_linear_kernel", "clk6_bruteforce_all_types": "trials_linear_kernel"}
+for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_", "slot_")), ("lap_any_4gib_init4", ("Slide4",)), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
                    ("clk6_bruteforce", ("trials_linear_kernel", "trials_wave_kernel")),
                    ("clk6_bruteforce_all_types", ("trials_linear_kernel", "trials_wave_kernel"))):
     path = os.path.join(d, "pmc_sec_%s.json" % line)
@@ -61,5 +63,16 @@ for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_")), ("
     out[line] = {"bytes_per_step": int(tot), "kernels": " + ".join(used), "algorithmic_bytes_per_step": alg,
                  "ratio_to_algorithmic": round(tot / alg, 3),
                  "per_kernel_bytes": {k: int(hbm(sec[k])) for k in used}}
+    # the line's dominant kernel for roofline.valu (bench.valu_block): instruction counts of the same PMC passes; cycles per
+    # instruction = 3.1, the scan kernels' static mix priced with tools/valu_rate.hip (2.4 / 4.2 cycles for full- and half-rate forms)
+    dom = [k for k in used if DOMINANT[line] in k]
+    if dom and sec[dom[0]].get("SQ_INSTS_VALU"):
+        e = sec[dom[0]]
+        wc = e.get("SQ_WAVE_CYCLES", {}).get("mean_per_launch")
+        out[line]["valu"] = {"kernel": dom[0], "insts_per_launch": e["SQ_INSTS_VALU"]["mean_per_launch"], "cycles_per_inst": 3.1,
+                             "simds": 1024, "clock_ghz": 2.4,
+                             "salu_insts_per_launch": e.get("SQ_INSTS_SALU", {}).get("mean_per_launch"),
+                             "lds_insts_per_launch": e.get("SQ_INSTS_LDS", {}).get("mean_per_launch"),
+                             "wait_any_frac": round(e["SQ_WAIT_ANY"]["mean_per_launch"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_secondary.json"), "w"), indent=1)
 print("traffic_secondary.json:", {k: v["ratio_to_algorithmic"] for k, v in out.items() if isinstance(v, dict)})
