@@ -389,10 +389,41 @@ static int build_two_level_sets(const HostTables &t, int max_ac_errors, std::vec
 	return BTBBX_OK;
 }
 
+// Tables for FIVE errors (round 6): 5.0 M patterns leave no set that fits the LDS and filters, so every barker survivor of
+// scan_lap_any_kernel used to probe the 2^26-bit bitmap over the syndrome hash (8 MiB: half of it outside an XCD's L2) -- the
+// kernel ran at that table's probe rate.  The 2^SLIDE4B_BITS-bit set over SLIDE4B_TAPS (2 MiB, L2-resident, the same layout as the
+// second level of the two-level form) goes in front of it: 22.4 % of the survivors pass it (3 756 016 members), the rest never
+// compute a syndrome or leave the L2.
+static int build_five_error_front_set(const HostTables &t, std::vector<uint32_t> &second)
+{
+	const int rc = build_slide_set(t, 5, second, SLIDE4B_BITS, SLIDE4B_TAPS);
+	if (rc < 0)
+		return rc;
+	for (uint32_t &w : second) {
+		uint32_t r = 0;
+		for (int k = 0; k < 32; k++)
+			r |= ((w >> k) & 1u) << (31 - k);
+		w = r;
+	}
+	return rc;
+}
+
 extern "C" int btbbx_slide_sets_two_level(int max_ac_errors, uint32_t *first_words, uint32_t *second_words, uint64_t *taps)
 {
+	if (max_ac_errors == 5 && second_words) {       // (tables for five errors: the front set of scan_lap_any_kernel only; first_words is not written)
+		std::vector<uint32_t> second;
+		const int rc5 = build_five_error_front_set(host_tables(), second);
+		if (rc5 < 0)
+			return rc5;
+		memcpy(second_words, second.data(), second.size() * sizeof(uint32_t));
+		if (taps) {
+			taps[0] = 0;
+			taps[1] = SLIDE4B_TAPS;
+		}
+		return BTBBX_OK;
+	}
 	if ((max_ac_errors != 3 && max_ac_errors != 4) || !first_words || !second_words) {
-		set_error("btbbx_slide_sets_two_level: bad argument (tables for three or four errors have these sets)");
+		set_error("btbbx_slide_sets_two_level: bad argument (tables for three, four or five errors have these sets)");
 		return BTBBX_E_ARG;
 	}
 	std::vector<uint32_t> first, second;
@@ -426,7 +457,11 @@ extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64
 
 // size of the second-level bitmap by the error count the tables are built for (2^bits bits; 26 = 8 MiB, rounds 1-3)
 #define BITMAP2_BITS_3 26
-#define BITMAP2_BITS_4 24          // 2 MiB: stays in every XCD's 4 MiB L2 beside the stream (2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51)
+#ifndef BITMAP2_BITS_4
+#define BITMAP2_BITS_4 22          // 512 KiB.  (rounds 3-4, when every survivor probed it: 2^24 = 2 MiB, "2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51".)
+#endif                             // Round 6: only the exact check of the two-level kernel's candidates looks at it now, and 2 MiB of it beside the 2 MiB
+                                   // second-level set were the whole L2 of an XCD: 2.07 x the algorithmic bytes per launch -> 1.50 x, same time (profiles/r06_init4)
+//         // 2 MiB: stays in every XCD's 4 MiB L2 beside the stream (2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51)
 #define BITMAP2_BITS_5 26
 static int upload_tables(int max_ac_errors)
 {
@@ -506,6 +541,10 @@ static int upload_tables(int max_ac_errors)
 		const int rc4 = build_two_level_sets(t, max_ac_errors, slide4, slide4b);
 		if (rc4 < 0)
 			return rc4;
+	} else if (max_ac_errors == 5) {
+		const int rc5 = build_five_error_front_set(t, slide4b);      // (slide4 stays empty: scan_lap_any_kernel, not the two-level form)
+		if (rc5 < 0)
+			return rc5;
 	}
 
 	// one block: tabA | tabB | slide set | the two sets of the two-level form
@@ -529,10 +568,10 @@ static int upload_tables(int max_ac_errors)
 	HIP_TRY(hipMemcpy(base + off_a, tabA.data(), 4 * LDS_TABA_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_b, tabB.data(), 4 * LDS_TABB_WORDS, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(base + off_s, slide_bitmap.data(), 4 * SLIDE_WORDS, hipMemcpyHostToDevice));
-	if (!slide4.empty()) {
+	if (!slide4.empty())
 		HIP_TRY(hipMemcpy(base + off_s4, slide4.data(), 4 * slide4.size(), hipMemcpyHostToDevice));
+	if (!slide4b.empty())
 		HIP_TRY(hipMemcpy(base + off_s4b, slide4b.data(), 4 * slide4b.size(), hipMemcpyHostToDevice));
-	}
 	HIP_TRY(hipMemcpy(fresh.hslots, mb.slots.data(), mb.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	HIP_TRY(hipDeviceSynchronize());                   // scans queued on any stream still read the old tables
 	// The set just replaced is not freed here: a launcher on another thread may have copied `c.scan` (the old

@@ -129,7 +129,11 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint32_t stream, uin
 // >= 4-error kernels out of the cache changed nothing: 12.0 against 12.06 ms per GiB at five errors, round 3.)
 __device__ __forceinline__ uint64_t stream_ld(const uint64_t *p)
 {
+#ifdef STREAM_NT                                 // (measuring switch, round 6: profiles/r06_init4)
+	return __builtin_nontemporal_load(p);
+#else
 	return *p;
+#endif
 }
 // MSB-first bytes (first received symbol in bit 7, the order a radio front end delivers) -> the library's LSB-first dword:
 // reverse the dword's 32 bits, put the four bytes back in order (v_bfrev_b32 + v_perm_b32).  The scan kernels do this to the
@@ -519,8 +523,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	auto tile_full = [&](uint32_t tt) {                         // (one scalar compare; the launcher did the 64-bit arithmetic)
 		return tt < a.full_tiles;
 	};
-	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
+	// front set (tables for five errors, round 6): window positions of the second check stream behind offset 63 reach 23 bits into
+	// the word after next -- its low dword comes along
+	const bool front = a.t.slide4b_bitmap != nullptr;          // launch-uniform
+	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi, uint32_t &far) {
 		lo = hi = 0;
+		far = 0;
 		if (c.stream >= a.n_streams)
 			return;
 		const uint64_t *tp = a.words + (uint64_t)c.stream * a.pitch_words + (uint64_t)c.t * SCAN_THREADS;   // uniform
@@ -532,6 +540,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			lo = w < a.n_words ? stream_ld(tp + tid) : 0;
 			hi = w + 1 < a.n_words ? stream_ld(tp + tid + 1) : 0;
 		}
+		if (front) {
+			const uint64_t w = (uint64_t)c.t * SCAN_THREADS + tid;
+			far = w + 2 < a.n_words ? *reinterpret_cast<const uint32_t *>(tp + tid + 2) : 0u;
+		}
 	};
 
 	// Each trip of the main loop works on UNROLL tiles at once (independent words in the same
@@ -540,10 +552,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 	constexpr int UNROLL = SCAN_UNROLL;
 	Cursor tc[UNROLL];
 	uint64_t lo[UNROLL], hi[UNROLL];
+	uint32_t far[UNROLL];
 #pragma unroll
 	for (int u = 0; u < UNROLL; u++) {
 		tc[u] = cur;
-		load_pair(cur, lo[u], hi[u]);
+		load_pair(cur, lo[u], hi[u], far[u]);
 		advance(cur);
 	}
 
@@ -551,14 +564,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 		// software prefetch of the next tiles: the loads fly while these are processed
 		Cursor nc[UNROLL];
 		uint64_t nlo[UNROLL], nhi[UNROLL];
+		uint32_t nfar[UNROLL];
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			nc[u] = cur;
-			load_pair(cur, nlo[u], nhi[u]);
+			load_pair(cur, nlo[u], nhi[u], nfar[u]);
 			advance(cur);
 		}
 
 		uint32_t d[UNROLL][4], m[UNROLL][2], cls[UNROLL][2];
+		uint32_t c2[UNROLL][3] = {};                             // the second check stream (front set), positions 0 .. 95 of the lane's word
 #pragma unroll
 		for (int u = 0; u < UNROLL; u++) {
 			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
@@ -581,6 +596,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			}
 			barker32(d[u][1], d[u][2], validA, m[u][0], cls[u][0]);    // offsets 0..31: window bits 57.. in d1:d2
 			barker32(d[u][2], d[u][3], validB, m[u][1], cls[u][1]);    // offsets 32..63
+			if (front) {
+				const uint32_t d4 = a.msb ? msb_dword(far[u]) : far[u];
+				c2[u][0] = slide32<SLIDE4B_TAPS>(d[u][0], d[u][1], d[u][2]);
+				c2[u][1] = slide32<SLIDE4B_TAPS>(d[u][1], d[u][2], d[u][3]);
+				c2[u][2] = slide32<SLIDE4B_TAPS>(d[u][2], d[u][3], d4);
+			}
 #ifdef SCAN_PROFILE
 			PROF_PIN(m[u][0]); PROF_PIN(m[u][1]);
 			if (u == UNROLL - 1) PROF_MARK(14);
@@ -621,16 +642,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 					t2[u][h] = lds_ld(LDS_OFF_TABB + q[u][h].offB);
 				}
 			uint32_t anybit = 0, bit[UNROLL][2], live[UNROLL][2], i2[UNROLL][2];
+			// front set (round 6): 24 positions of the second check stream at the survivor's offset, one dword of a 2 MiB set in L2 per
+			// survivor (the four chains' loads in flight together); only its members (22 %) go on to the bitmap over the syndrome.
+			// (Sending the front-set loads of pass k + 1 behind the bitmap loads of pass k -- a two-stage pipeline, 107 VGPRs --
+			// changed nothing: 7.40 against 7.28 ms per GiB; the kernel runs at the two tables' probe rates, 236 G/s out of the L2 and
+			// 88 G/s for the 8 MiB one, not at their latency.  profiles/r06_init5)
+			bool go[UNROLL][2];
+			if (front) {
+				uint32_t v1[UNROLL][2], w1[UNROLL][2];
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						v1[u][h] = alignbit(c2[u][h + 1], c2[u][h], p[u][h]);
+						w1[u][h] = 0;
+						if (m[u][h])
+							w1[u][h] = a.t.slide4b_bitmap[(v1[u][h] >> 5) & ((1u << (SLIDE4B_BITS - 5)) - 1)];
+					}
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						go[u][h] = (int32_t)(w1[u][h] << (v1[u][h] & 31)) < 0;      // (words bit-reversed: member = sign; 0 for an empty chain)
+			} else {
+#pragma unroll
+				for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						go[u][h] = m[u][h] != 0;
+			}
 #pragma unroll
 			for (int u = 0; u < UNROLL; u++)
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					proj[u][h] = xor3(q[u][h].x, t1[u][h], t2[u][h]);
-					// tables for five errors: every value of any set that fits the LDS is a sum of five columns, so each
-					// survivor probes the 2^26-bit bitmap in L2 / Infinity Cache right here
+					// tables for five errors: every value of any set that fits the LDS is a sum of five columns, so the
+					// survivors (round 6: those the front set lets through) probe the 2^26-bit bitmap in L2 / Infinity Cache right here
 					i2[u][h] = (proj[u][h] * 0x9E3779B1u) >> a.t.bitmap2_shift;
 					bw[u][h] = 0;
-					if (m[u][h])
+					if (go[u][h])
 						bw[u][h] = a.t.bitmap2[i2[u][h] >> 5];
 				}
 #pragma unroll
@@ -673,6 +723,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 			tc[u] = nc[u];
 			lo[u] = nlo[u];
 			hi[u] = nhi[u];
+			far[u] = nfar[u];
 		}
 	}
 	compact(true);
@@ -1055,13 +1106,21 @@ void scan_slide_kernel(ScanArgs a)
 		if (c.stream >= a.n_streams)
 			return;
 		const uint64_t *p = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(c.tp) + voff);
+		// (two-level form, -DSLIDE4_NT: the stream read non-temporally, so that it does not push the second-level set out of the L2)
+		auto ld = [](const uint64_t *q) {
+#ifdef SLIDE4_NT
+			if constexpr (CFG::LEVEL2)
+				return (uint64_t)__builtin_nontemporal_load(q);
+#endif
+			return stream_ld(q);
+		};
 		if (tile_full(c.t)) {
-			lo = stream_ld(p);
-			hi = stream_ld(p + 1);
+			lo = ld(p);
+			hi = ld(p + 1);
 		} else {
 			const uint64_t w = (uint64_t)c.t * TILE_WORDS + wid;
-			lo = w < a.n_words ? stream_ld(p) : 0;
-			hi = w + 1 < a.n_words ? stream_ld(p + 1) : 0;
+			lo = w < a.n_words ? ld(p) : 0;
+			hi = w + 1 < a.n_words ? ld(p + 1) : 0;
 		}
 	};
 

@@ -164,3 +164,31 @@ def test_two_level_sets_contain_every_acceptable_window_and_no_idle_chain(tmp_pa
             i2 = sum((bin(window & (t2 << b)).count("1") & 1) << b for b in range(b2))
             assert (int(f[i1 >> 5]) >> (i1 & 31)) & 1, (n, hex(window))
             assert (int(s[i2 >> 5]) >> (31 - (i2 & 31))) & 1, (n, hex(window))
+
+
+def test_front_set_of_the_five_error_tables_contains_every_acceptable_window(tmp_path):
+    """btbbx_slide_sets_two_level(5, ...) hands out the 2^24-bit set scan_lap_any_kernel probes first when the tables are built for
+    five errors (round 6; bit-reversed words, the layout of the two-level form's second set): every window within five errors of a
+    sync word (anything in the barker bits) is a member, and 22.4 % of all values are (3 756 016 members: what lets four survivors in
+    five skip the 8 MiB bitmap over the syndrome)."""
+    import ctypes as C
+
+    import libbtbb_amd as bt
+
+    lib = bt.lib()
+    _, _, t2, b2 = _two_level_constants(tmp_path)
+    orc = oracle()
+    rng = np.random.default_rng(seed(4115))
+    second = (C.c_uint32 * (1 << (b2 - 5)))()
+    taps = (C.c_uint64 * 2)()
+    assert lib.btbbx_slide_sets_two_level(5, None, second, taps) == 0
+    assert taps[1] == t2
+    s = np.frombuffer(second, dtype=np.uint32)
+    assert int(np.unpackbits(s.view(np.uint8)).sum()) == 3756016
+    for _ in range(3000):
+        window = orc.orc_gen_syncword(int(rng.integers(0, 1 << 24)))
+        for e in rng.choice(57, size=int(rng.integers(0, 6)), replace=False):
+            window ^= 1 << int(e)
+        window ^= int(rng.integers(0, 128)) << 57
+        i2 = sum((bin(window & (t2 << b)).count("1") & 1) << b for b in range(b2))
+        assert (int(s[i2 >> 5]) >> (31 - (i2 & 31))) & 1, hex(window)
