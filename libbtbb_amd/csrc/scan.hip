@@ -1643,13 +1643,20 @@ struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per s
 // LIMIT = max_ac_errors when it is 0 .. 4 (the count <= limit compare of the filters then folds into a few
 // and / andn of the count planes; with the limit in a register it is sixteen instructions with SGPR masks), -1 = any
 // CLS = bit 23 of the LAP (the barker class of its sync word), -1 = not specialised
-template <int LIMIT, int CLS, bool MSB>
+// ORD: the ordered scan's form -- hits leave through the segment slots (a template flag: the code that fills them costs the plain form
+// eight registers, one wave per SIMD, if it is only branched around)
+template <int LIMIT, int CLS, bool MSB, bool ORD = false>
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
 	__shared__ KnownHit ring_mem[4][KRING];
+	__shared__ uint32_t slot_cnt[4][64];                   // (ordered scan, segment slots: hits per tile tag of a batch ...
+	__shared__ uint16_t slot_code[4][64][4];               //  ... and up to four of their 12-bit offsets inside the segment)
+	if (a.gate && *a.gate == 0)
+		return;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	KnownHit *ring = ring_mem[tid >> 6];
+	constexpr bool ord = ORD;
 	uint32_t ac_lo = (uint32_t)a.syncword, ac_hi = (uint32_t)(a.syncword >> 32);
 	asm volatile("" : "+v"(ac_lo), "+v"(ac_hi));          // (an SGPR operand halves the issue rate of the XORs in the survivor pass)
 	// the planes of the filter are XORed with all-ones where the sync word has a 1: sixteen masks, kept in
@@ -1698,6 +1705,10 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 		q_head += n;
 	};
+	// Ordered scan (round 6, as in scan_slide_kernel<..., ORD>): a SEGMENT = 4096 offsets = the 64 words of a tile one wave owns
+	// (a tile is 2 x 256 words: two segments per wave).  Hits wait in the ring as before, but leave it at a tile end only -- every
+	// hit of a segment is then in the batch --, ranked by offset inside their segment, into the segment's own slots.
+	uint32_t iter = 0, ring_first_iter = 0;         // wave-uniform: tiles this wave has worked on; the tile of the oldest ring entry
 	auto stage = [&](bool hit, uint32_t stream, uint64_t offset, uint32_t nerr) {
 		const uint64_t mask = __ballot(hit);
 		if (!mask)
@@ -1707,15 +1718,100 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 				emit_hit(a, stream, offset, a.lap, nerr);
 			return;
 		}
-		if (q_tail - q_head + 64 > KRING)
+		if (q_tail - q_head + 64 > KRING) {
+			if (ord) {                              // more than 64 hits in a wave's tile(s): a stream of sync words -- the general ordering redoes the call
+				*a.irregular = 1u;
+				return;
+			}
 			flush(64);
+		}
+		if (q_tail == q_head)
+			ring_first_iter = iter;
 		if (hit) {
 			const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
 					__builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-			KnownHit k = { (uint32_t)offset, (uint32_t)(offset >> 32), (stream << 8) | nerr };
+			// (ordered scan: bits 24 .. 31 = the segment's tag inside the batch, two per tile: word bit 8 = offset bit 14 tells which)
+			const uint32_t tag = ((iter << 1) | ((uint32_t)(offset >> 14) & 1u)) & 0xffu;
+			KnownHit k = { (uint32_t)offset, (uint32_t)(offset >> 32), (stream << 8) | nerr | (ord ? tag << 24 : 0u) };
 			ring[slot & (KRING - 1)] = k;
 		}
 		q_tail += (uint32_t)__popcll(mask);
+	};
+	auto to_slots = [&](bool final) {               // at a tile end: the whole ring (<= 128 entries) into the segment slots
+		const uint32_t n = q_tail - q_head;
+		if (n == 0 || (n < 48 && !final))
+			return;
+		uint32_t *cnt = slot_cnt[tid >> 6];
+		uint16_t (*codes)[4] = slot_code[tid >> 6];
+		const bool tags_ok = iter - ring_first_iter < 32;      // two tags per tile, 64 counters: no two segments of the batch share one
+		// (one round of 64 entries at a time and nothing kept between the rounds: the kernel's 64 registers are its eight waves per SIMD)
+		bool fast = tags_ok;
+		if (tags_ok) {
+			cnt[lane] = 0;
+#pragma unroll 1
+			for (uint32_t r = 0; r < n; r += 64)
+				if (r + lane < n) {
+					const KnownHit e = ring[(q_head + r + lane) & (KRING - 1)];
+					const uint32_t key = (e.stream_err >> 24) & 63u;
+					const uint32_t idx = atomicAdd(&cnt[key], 1u);
+					if (idx < 4)
+						codes[key][idx] = (uint16_t)(e.off_lo & 0xfffu);
+				}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			if (__ballot(*(volatile __attribute__((address_space(3))) const uint32_t *)&cnt[lane] > 4u))
+				fast = false;
+		}
+#pragma unroll 1
+		for (uint32_t r = 0; r < n; r += 64) {
+			const bool have = r + lane < n;
+			const KnownHit e = ring[(q_head + r + lane) & (KRING - 1)];
+			uint32_t count = 0, rank = 0;
+			if (fast) {
+				if (have) {
+					const uint32_t key = (e.stream_err >> 24) & 63u, mine = e.off_lo & 0xfffu;
+					count = *(volatile __attribute__((address_space(3))) const uint32_t *)&cnt[key];
+					for (uint32_t j = 0; j < count; j++)
+						rank += codes[key][j] < mine ? 1u : 0u;
+				}
+			} else {                                // a sparse stream (a batch over 32 tiles or more) or a crowded segment: every entry against every other
+#pragma unroll 1
+				for (uint32_t j = 0; j < n; j++) {
+					const KnownHit o = ring[(q_head + j) & (KRING - 1)];          // (wave-uniform address: a broadcast)
+					const bool same = ((o.stream_err ^ e.stream_err) & 0xffff00u) == 0 && o.off_hi == e.off_hi && (o.off_lo >> 12) == (e.off_lo >> 12);
+					count += same ? 1u : 0u;
+					rank += same && o.off_lo < e.off_lo ? 1u : 0u;
+				}
+			}
+			const uint32_t stream = (e.stream_err >> 8) & 0xffffu;
+			const uint32_t seg = stream * a.segs_per_stream + (uint32_t)((((uint64_t)e.off_hi << 32) | e.off_lo) >> 12);
+			uint4 out;
+			out.x = e.off_lo;
+			out.y = e.off_hi;
+			out.z = a.lap;
+			out.w = (e.stream_err & 0xffu) | (stream << 16);
+			const bool spill = have && rank >= a.seg_slot_n;
+			if (have && !spill)
+				reinterpret_cast<uint4 *>(a.seg_slots)[(uint64_t)seg * a.seg_slot_n + rank] = out;
+			if (have && rank + 1 == count)
+				a.seg_cnt[seg] = (uint16_t)count;
+			const uint64_t om = __ballot(spill);
+			if (om) {
+				uint32_t base = 0;
+				if (lane == 0)
+					base = atomicAdd(a.ovf_count, (uint32_t)__popcll(om));
+				base = __builtin_amdgcn_readfirstlane(base);
+				const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
+				if (spill) {
+					if (at < a.ovf_cap) {
+						reinterpret_cast<uint4 *>(a.ovf_recs)[at] = out;
+						a.ovf_meta[at] = make_uint2(seg, rank);
+					} else {
+						*a.irregular = 1u;
+					}
+				}
+			}
+		}
+		q_head += n;
 	};
 
 	// division-free (stream, tile) cursor, as in the LAP_ANY kernel
@@ -1872,12 +1968,20 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 		}
 		PROF_MARK(2);
-		while (q_tail - q_head >= 64)
-			flush(64);
+		iter++;
+		if (ord) {
+			to_slots(false);
+		} else {
+			while (q_tail - q_head >= 64)
+				flush(64);
+		}
 		PROF_MARK(3);
 	}
-	if (q_tail != q_head)
+	if (ord) {
+		to_slots(true);
+	} else if (q_tail != q_head) {
 		flush(q_tail - q_head);
+	}
 #ifdef SCAN_PROFILE
 	if (lane < 32)
 		atomicAdd(&g_scan_prof[lane], (unsigned long long)kl_prof[tid >> 6][lane]);
@@ -1977,11 +2081,17 @@ bool scan_slot_geometry(uint64_t search_bits, uint32_t n_streams, uint32_t lap, 
 	int table_errors = 0;
 	ScanTables t;
 	ctx_scan_snapshot(&t, &table_errors);
-	if (lap != BTBBX_LAP_ANY || table_errors > 2 || !t.slide_bitmap)
-		return false;
 	const uint64_t search_words = (search_bits + 63) / 64;
-	const uint64_t tiles = (search_words + SlideGeom<SlideStd>::TILE_WORDS - 1) / SlideGeom<SlideStd>::TILE_WORDS;
-	const uint64_t per_stream = tiles * (SlideStd::THREADS / 64), total = per_stream * n_streams;
+	uint64_t per_stream;
+	if (lap != BTBBX_LAP_ANY) {                        // known LAP: segments of 4096 offsets, eight per tile of 512 words
+		per_stream = (search_words + 256ull * KL_WORDS - 1) / (256ull * KL_WORDS) * (4 * KL_WORDS);
+	} else {
+		if (table_errors > 2 || !t.slide_bitmap)
+			return false;
+		const uint64_t tiles = (search_words + SlideGeom<SlideStd>::TILE_WORDS - 1) / SlideGeom<SlideStd>::TILE_WORDS;
+		per_stream = tiles * (SlideStd::THREADS / 64);
+	}
+	const uint64_t total = per_stream * n_streams;
 	if (total >= (1ull << 31))
 		return false;
 	*segs_per_stream = (uint32_t)per_stream;
@@ -2152,8 +2262,13 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 			set_error("btbbx_scan: stream too long for one launch (split it)");
 			return BTBBX_E_ARG;
 		}
+		if (slots && (a.segs_per_stream != a.tiles_per_stream * (4 * KL_WORDS) || d_first)) {
+			set_error("btbbx_scan: internal: segment slots laid out for another geometry");
+			return BTBBX_E_ARG;
+		}
 		const bool cls1 = ((a.syncword >> 57) & 1) != 0;          // = bit 23 of the LAP
-#define LAUNCH_KNOWN_(L, C_, M_) hipLaunchKernelGGL((scan_known_lap_kernel<L, C_, M_>), dim3((uint32_t)grid), dim3(256), 0, stream, a)
+#define LAUNCH_KNOWN__(L, C_, M_, O_) hipLaunchKernelGGL((scan_known_lap_kernel<L, C_, M_, O_>), dim3((uint32_t)grid), dim3(256), 0, stream, a)
+#define LAUNCH_KNOWN_(L, C_, M_) do { if (slots) LAUNCH_KNOWN__(L, C_, M_, true); else LAUNCH_KNOWN__(L, C_, M_, false); } while (0)
 #define LAUNCH_KNOWN(L) do { if (cls1) { if (msb) LAUNCH_KNOWN_(L, 1, true); else LAUNCH_KNOWN_(L, 1, false); } \
 		else { if (msb) LAUNCH_KNOWN_(L, 0, true); else LAUNCH_KNOWN_(L, 0, false); } } while (0)
 		switch (max_ac_errors) {
@@ -2166,6 +2281,7 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		}
 #undef LAUNCH_KNOWN
 #undef LAUNCH_KNOWN_
+#undef LAUNCH_KNOWN__
 #ifdef SCAN_PROFILE
 		{
 			unsigned long long prof[32], total = 0;

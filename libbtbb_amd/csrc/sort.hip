@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <vector>
 #include "common.h"
 
 struct __attribute__((aligned(16))) HitRec { uint64_t a, b; };      // a btbbx_hit as an opaque 16-byte value
@@ -304,20 +305,21 @@ __global__ __launch_bounds__(256) void order_rank_kernel(const btbbx_hit *groupe
 // every other; beyond that a presence bitmap of the bucket's keys in LDS (2^20 keys per window), rank = set bits below
 // the record's own -- exact because keys are unique, and checked: a bucket whose bitmap holds fewer bits than it has
 // members (a repeated key) is redone by all pairs.
-__global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
-							     uint32_t nb, btbbx_hit *out, const uint32_t *gate)
+// (vblock of vgrid: the workgroup's place in the launch -- or 0 of 1 when order_single_kernel runs the whole ordering in one workgroup)
+__device__ void order_crowded_body(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start, uint32_t nb, btbbx_hit *out,
+				   uint32_t vblock, uint32_t vgrid)
 {
 	extern __shared__ uint32_t bits[];                  // 2^shift bits, then 1024 group prefixes
 	__shared__ uint32_t lds_wave[16];
 	__shared__ uint32_t found[1024], n_found;
 	__shared__ unsigned long long win_lo, win_hi;
-	if ((gate && !*gate) || !p->crowded)
+	if (!p->crowded)
 		return;
 	const uint32_t shift = p->shift;
 	const unsigned long long mul = p->mul;
 	// 1024 buckets are looked at per step, one per thread (a workgroup stepping through the buckets one by one spent
 	// 5 ms on 2^22 of them waiting for its own loads); the crowded ones among them are then worked off one at a time
-	for (uint32_t first = blockIdx.x * 1024; first < nb; first += gridDim.x * 1024) {
+	for (uint32_t first = vblock * 1024; first < nb; first += vgrid * 1024) {
 		if (threadIdx.x == 0)
 			n_found = 0;
 		__syncthreads();
@@ -417,6 +419,113 @@ __global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *gr
 	}
 }
 
+__global__ __launch_bounds__(1024) void order_crowded_kernel(const btbbx_hit *grouped, const OrderParams *p, const uint32_t *start,
+							     uint32_t nb, btbbx_hit *out, const uint32_t *gate)
+{
+	if (gate && !*gate)
+		return;
+	order_crowded_body(grouped, p, start, nb, out, blockIdx.x, gridDim.x);
+}
+
+// The whole ordering of a parked list in ONE workgroup (round 6): what redoes an ordered scan whose stream the segment slots could
+// not rank -- one made of sync words.  It follows the gated re-scan on a side stream beside the compaction, returns at its first
+// instruction for every other stream, and is one launch where the general path is six that wait for each other (4.7 us apiece
+// even when they have nothing to do: 33 us of the 0.6 ms config-3 chain).  Slow -- one CU -- and exact: zero the counters,
+// histogram, scan, scatter, ranks of shared buckets, crowded buckets, the steps of order_launch in its own order.
+__global__ __launch_bounds__(1024) void order_single_kernel(const btbbx_hit *list, const uint32_t *d_count, uint32_t cap, uint32_t nb, uint32_t nb_log2,
+							    uint32_t n_streams, unsigned long long max_offset, OrderParams *p, uint32_t *start,
+							    uint32_t *cursor, btbbx_hit *grouped, btbbx_hit *out, uint32_t *work, uint32_t *count_out,
+							    const uint32_t *gate)
+{
+	__shared__ uint32_t lds_wave[16];
+	__shared__ uint32_t s_crowded, s_shared;
+	if (gate && !*gate)
+		return;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t n = min(*d_count, cap);
+	if (tid == 0)
+		*count_out = *d_count;                            // (every match counts, also beyond the capacity: btbbx_scan_device's rule)
+	const unsigned long long mul = max_offset + 1;
+	const uint32_t shift = order_shift(n_streams, mul, nb_log2);
+	for (uint32_t i = tid; i <= nb; i += 1024)
+		start[i] = 0;
+	for (uint32_t i = tid; i < nb; i += 1024)
+		cursor[i] = 0;
+	if (tid == 0) {
+		p->mul = mul;
+		p->n = n;
+		p->shift = shift;
+		p->crowded = 0;
+		p->any_shared = 0;
+		s_crowded = s_shared = 0;
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += 1024)
+		atomicAdd(&start[order_lin(list[i], mul) >> shift], 1u);
+	__syncthreads();
+	{	// exclusive scan of the counts in place, sixteen per thread and step
+		uint32_t carry = 0;
+		for (uint32_t first = 0; first < nb; first += 1024 * 16) {
+			const uint32_t mine = first + tid * 16;
+			uint32_t v[16], sum = 0;
+			bool big = false;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				v[k] = mine + k < nb ? __hip_atomic_load(&start[mine + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				sum += v[k];
+				big |= v[k] > ORDER_SMALL;
+			}
+			if (big)
+				s_crowded = 1;
+			uint32_t total;
+			uint32_t run = carry + block_exclusive_scan_1024(sum, lds_wave, total);
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				if (mine + k < nb)
+					start[mine + k] = run;
+				run += v[k];
+			}
+			carry += total;
+		}
+		if (tid == 0)
+			start[nb] = carry;
+	}
+	__syncthreads();
+	if (tid == 0)
+		p->crowded = s_crowded;
+	for (uint32_t i = tid; i < n; i += 1024) {           // scatter (order_scatter_kernel)
+		const btbbx_hit h = list[i];
+		const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+		const uint32_t s0 = start[b], k = start[b + 1] - s0;
+		const uint32_t pos = k == 1 ? s0 : s0 + atomicAdd(&cursor[b], 1u);
+		HitRec *dst = reinterpret_cast<HitRec *>(k == 1 ? out : grouped);
+		dst[pos] = *reinterpret_cast<const HitRec *>(&h);
+		const bool shared = k > 1 && k <= ORDER_SMALL;
+		work[i] = shared ? pos : ~0u;
+		if (shared)
+			s_shared = 1;
+	}
+	__syncthreads();
+	if (tid == 0)
+		p->any_shared = s_shared;
+	if (s_shared) {
+		for (uint32_t w = tid; w < n; w += 1024) {       // ranks of bucket-mates (order_rank_list_kernel)
+			const uint32_t i = work[w];
+			if (i == ~0u)
+				continue;
+			const btbbx_hit h = grouped[i];
+			const uint32_t b = (uint32_t)(order_lin(h, mul) >> shift);
+			const uint32_t s0 = start[b], k = start[b + 1] - s0;
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < k; j++)
+				rank += order_before(grouped[s0 + j], s0 + j, h, i) ? 1u : 0u;
+			reinterpret_cast<HitRec *>(out)[s0 + rank] = *reinterpret_cast<const HitRec *>(&h);
+		}
+	}
+	__syncthreads();
+	order_crowded_body(grouped, p, start, nb, out, 0, 1);
+}
+
 // ---- segment slots: the ordered LAP_ANY scan without a sort (round 6) ------------------------------------------------------
 //
 // scan_slide_kernel<..., ORD> (scan.hip) leaves every hit in a slot of its SEGMENT -- the 63 words of a tile one wave owns, 4032
@@ -434,7 +543,7 @@ struct SlotHeader {
 	uint32_t ovf_count;        // records in the overflow list (scan)
 	uint32_t irregular;        // the scan could not rank a hit (ScanArgs::irregular): the general path redoes the call
 	uint32_t total;            // hits found
-	uint32_t pad;
+	uint32_t redo_count;       // the fallback's re-scan counts its hits here (zeroed with the header)
 };
 
 // (zeroing as a kernel: the fallback's counters are only cleared when the fallback runs)
@@ -505,6 +614,8 @@ __global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, u
 		before += t_before;
 		all += t_all;
 	}
+	if (hd->irregular)
+		return;                                           // the general ordering redoes the call (and owns d_count and the list)
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		hd->total = all;
 		*d_count = all;
@@ -555,6 +666,8 @@ __global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, u
 __global__ __launch_bounds__(256) void slot_overflow_kernel(const SlotHeader *hd, const HitRec *recs, const uint2 *meta, uint32_t ovf_cap,
 							     const uint32_t *seg_start, HitRec *out, uint32_t cap)
 {
+	if (hd->irregular)
+		return;
 	const uint32_t n = min(hd->ovf_count, ovf_cap);
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
 		const uint2 m = meta[i];
@@ -757,6 +870,59 @@ int launch_scan(const uint64_t *d_words, uint64_t n_words, uint64_t pitch_words,
 		unsigned long long *d_first, hipStream_t stream, uint32_t *bucket_cnt, uint64_t bucket_mul, uint32_t bucket_shift, bool msb,
 		const ScanSlots *slots, const uint32_t *gate);
 
+// The fallback of the segment slots -- the general path, every launch of it gated on SlotHeader::irregular -- is seven launches that
+// return at once for any stream but one made of sync words, 4.7 us each when they queue behind one another: 33 us of a 0.6 ms
+// chain.  They run on a side stream instead, forked behind the scan (the flag is final then) and joined at the end of the call, beside
+// the compaction, which leaves the list alone when the flag is set: exactly one of the two writes d_hits and *d_count.
+struct SideLane { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::mutex side_lock;
+static std::vector<SideLane> side_pool[BTBBX_MAX_DEVICES];
+static bool side_acquire(int dev, SideLane *out)
+{
+	{
+		std::lock_guard<std::mutex> g(side_lock);
+		if (!side_pool[dev].empty()) {
+			*out = side_pool[dev].back();
+			side_pool[dev].pop_back();
+			return true;
+		}
+	}
+	SideLane l;
+	if (hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) != hipSuccess)
+		return false;
+	if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
+		if (l.fork) (void)hipEventDestroy(l.fork);
+		(void)hipStreamDestroy(l.s);
+		return false;
+	}
+	*out = l;
+	return true;
+}
+static void side_release(int dev, const SideLane &l)      // (work queued on it stays ordered: the next user queues behind it)
+{
+	std::lock_guard<std::mutex> g(side_lock);
+	side_pool[dev].push_back(l);
+}
+static void side_pool_release()                            // btbbx_shutdown
+{
+	std::lock_guard<std::mutex> g(side_lock);
+	int home = 0;
+	(void)hipGetDevice(&home);
+	for (int d = 0; d < BTBBX_MAX_DEVICES; d++) {
+		if (side_pool[d].empty())
+			continue;
+		(void)hipSetDevice(d);
+		for (SideLane &l : side_pool[d]) {
+			(void)hipStreamSynchronize(l.s);
+			(void)hipEventDestroy(l.fork);
+			(void)hipEventDestroy(l.join);
+			(void)hipStreamDestroy(l.s);
+		}
+		side_pool[d].clear();
+	}
+	(void)hipSetDevice(home);
+}
+
 // ---- segment slots: layout behind the general ordering's scratch (which the fallback uses) ----
 bool scan_slot_geometry(uint64_t search_bits, uint32_t n_streams, uint32_t lap, uint32_t *segs_per_stream, uint64_t *n_segs);
 
@@ -834,6 +1000,32 @@ extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n
 						     nullptr, stream, nullptr, 0, 0, msb, &sl, nullptr);
 				if (rc)
 					return rc;
+				// the gated fallback beside the compaction (see SideLane); without a side stream it follows on `stream`
+				int dev = 0;
+				SideLane lane;
+				const bool forked = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < BTBBX_MAX_DEVICES && side_acquire(dev, &lane);
+				if (forked) {
+					const uint32_t *g = &hd->irregular;
+					HIP_TRY(hipEventRecord(lane.fork, stream));
+					HIP_TRY(hipStreamWaitEvent(lane.s, lane.fork, 0));
+					// (the re-scan appends to the parked list behind its own counter in the header: d_count is the compaction's until the
+					// single-workgroup ordering has the list in place)
+					rc = launch_scan(d_words, n_words, pitch_words, n_streams, search_bits, lap, max_ac_errors, (btbbx_hit *)(base + L.parked), cap,
+							 &hd->redo_count, nullptr, lane.s, nullptr, 0, 0, msb, nullptr, g);
+					if (!rc) {
+						const uint32_t crowded_lds = 4u * ((1u << (ORDER_BIG_BITS - 5)) + 1024u);
+						HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(order_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, crowded_lds));
+						hipLaunchKernelGGL(order_single_kernel, dim3(1), dim3(1024), crowded_lds, lane.s, (const btbbx_hit *)(base + L.parked),
+								   (const uint32_t *)&hd->redo_count, cap, L.nb, L.nb_log2, n_streams, (unsigned long long)(search_bits - 1),
+								   (OrderParams *)(base + L.params), (uint32_t *)(base + L.start), (uint32_t *)(base + L.cursor),
+								   (btbbx_hit *)(base + L.grouped), d_hits, (uint32_t *)(base + L.work), d_count, g);
+					}
+					const hipError_t e_join = hipEventRecord(lane.join, lane.s);
+					side_release(dev, lane);
+					if (rc)
+						return rc;
+					HIP_TRY(e_join);
+				}
 				uint32_t *sums = (uint32_t *)(base + S.sums);
 				hipLaunchKernelGGL(slot_sums_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums);
 				hipLaunchKernelGGL(slot_place_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums, hd,
@@ -841,6 +1033,10 @@ extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n
 				hipLaunchKernelGGL(slot_overflow_kernel, dim3(64), dim3(256), 0, stream, hd, (const HitRec *)(base + S.ovf_recs),
 						   (const uint2 *)(base + S.ovf_meta), S.ovf_cap, (const uint32_t *)(base + S.seg_start), (HitRec *)d_hits, cap);
 				HIP_TRY(hipGetLastError());
+				if (forked) {
+					HIP_TRY(hipStreamWaitEvent(stream, lane.join, 0));
+					return BTBBX_OK;
+				}
 				// a hit the scan could not rank (ScanArgs::irregular: streams made of sync words): everything below runs again, this
 				// time for real; otherwise each of its launches returns at its first instruction
 				gate = &hd->irregular;
@@ -881,6 +1077,7 @@ static SortScratch sort_scratch[BTBBX_MAX_DEVICES];
 
 void sort_scratch_release()         // btbbx_shutdown
 {
+	side_pool_release();
 	int home = 0;
 	(void)hipGetDevice(&home);
 	for (int d = 0; d < BTBBX_MAX_DEVICES; d++) {

@@ -600,10 +600,9 @@ def test_scan_ordered_device(lap, slots):
     """btbbx_scan_ordered_device: one call, the list comes back in (stream, offset) order and equals the oracle's per
     stream -- LAP_ANY and known LAPs of both barker classes, several streams with a pitch, a hit buffer smaller than the
     number of matches (the records kept are then some subset, still ordered, and the counter says how many there were).
-    slots: the scratch of btbbx_scan_ordered_scratch_bytes -- the LAP_ANY scan then leaves its hits in the segment slots (round 6;
-    a sync word every 512 symbols = eight hits per 4032-offset segment of two slots: most of the list goes through the overflow
-    list, and a hit buffer that is too small keeps exactly the smallest records); else btbbx_order_hits_scratch_bytes -- the
-    general ordering, which is also what a known LAP gets either way."""
+    slots: the scratch of btbbx_scan_ordered_scratch_bytes -- the scan then leaves its hits in the segment slots (round 6; a sync
+    word every 512 symbols = eight hits per segment of two slots: most of the list goes through the overflow list); else
+    btbbx_order_hits_scratch_bytes -- the general ordering."""
     lib = bt.lib()
     kw = dict(stride=512) if lap == bt.LAP_ANY else dict(stride=512, lap=lap)
     n_streams, nwords, pitch = 5, 3000 + 7, 3100
@@ -623,7 +622,7 @@ def test_scan_ordered_device(lap, slots):
         d_h = bt.DeviceBuffer(cap * 16).zero()
         d_c = bt.DeviceBuffer(16).zero()
         sb = lib.btbbx_scan_ordered_scratch_bytes(nwords * 64 - 63 - 11, n_streams, lap, cap) if slots else lib.btbbx_order_hits_scratch_bytes(cap)
-        assert (sb > lib.btbbx_order_hits_scratch_bytes(cap)) == (slots and lap == bt.LAP_ANY)
+        assert (sb > lib.btbbx_order_hits_scratch_bytes(cap)) == slots
         d_s = bt.DeviceBuffer(sb)
         bt.check(lib.btbbx_scan_ordered_device(d_w.ptr, nwords, pitch, n_streams, nwords * 64 - 63 - 11, lap, 2, d_h.ptr, cap, d_c.ptr,
                                                d_s.ptr, sb, None), "btbbx_scan_ordered_device")

@@ -86,8 +86,12 @@ def test_lap_any_kernel_for_three_and_four_errors_one_workgroup_per_cu(kernels):
 
 def test_known_lap_kernel_eight_waves_per_simd(kernels):
     for cls in (0, 1):
-        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dELb0E" % cls)
+        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dELb0ELb0E" % cls)
         assert k["vgpr_count"] <= 64 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        assert k["group_segment_fixed_size"] * 7 <= LDS_PER_CU, k
+        # the ordered scan's form (round 6: hits leave through the segment slots): seven waves per SIMD, nothing in scratch
+        k = _one(kernels, r"scan_known_lap_kernelILi2ELi%dELb0ELb1E" % cls)
+        assert _waves_per_simd(k["vgpr_count"]) >= 7 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
         assert k["group_segment_fixed_size"] * 7 <= LDS_PER_CU, k
 
 
