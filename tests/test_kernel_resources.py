@@ -118,7 +118,8 @@ def test_decoders_and_trials_keep_their_state_in_registers(kernels):
 
 
 def test_order_kernels_have_no_scratch(kernels):
-    """(order_crowded_kernel, the cold pass over buckets of thousands, keeps one record in private memory)"""
+    """(order_crowded_kernel, the cold pass over buckets of thousands, keeps one record in private memory -- and so does
+    order_single_kernel, the segment slots' fallback for streams of sync words, which contains it)"""
     for name, k in kernels.items():
-        if "order_" in name and "crowded" not in name:
+        if "order_" in name and "crowded" not in name and "order_single" not in name:
             assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
