@@ -336,7 +336,7 @@ def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
     pk = torch.zeros(cap * 50, dtype=torch.int64, device=dev)
     ln = torch.zeros(cap, dtype=torch.int32, device=dev)
     pout = torch.zeros(cap * bt.PKTOUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    order_bytes = lib.btbbx_scan_ordered_scratch_bytes(nbits, nch, lap, cap)     # (with the segment slots: 32 B per 4096 offsets)
+    order_bytes = lib.btbbx_scan_ordered_scratch_bytes(nbits, nch, lap, cap)     # (with the segment slots: 16 B per 4096 offsets)
     order_scratch = torch.empty(order_bytes, dtype=torch.uint8, device=dev)
     # what every packet of the piconet enters the decoders with: WHITENED | UAP_VALID | CLK6_VALID, the piconet's UAP; the
     # clock of a packet = the slot number of its access code (offset / 4096: the capture's rule), worked out by the
@@ -726,7 +726,7 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
     scratch; scan of the counts, scatter, rank: sort.hip).  Checked in the run: strictly increasing offsets, and the same set
     of records as the unordered list of the timed headline loop."""
     unordered = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:int(cnt_t.item())].copy()
-    order_bytes = lib.btbbx_scan_ordered_scratch_bytes(nbits, 1, bt.LAP_ANY, cap)     # (with the segment slots: 32 B per 4032 offsets)
+    order_bytes = lib.btbbx_scan_ordered_scratch_bytes(nbits, 1, bt.LAP_ANY, cap)     # (with the segment slots: 16 B per 4032 offsets)
     scratch = torch.empty(order_bytes, dtype=torch.uint8, device=dev)
 
     def step():

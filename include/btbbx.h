@@ -213,7 +213,7 @@ int btbbx_order_scan_hits_device(btbbx_hit *d_hits, const uint32_t *d_count, uin
  * are not carried over -- chain scans with btbbx_scan_device and order the whole list once with btbbx_order_hits_device. */
 /* Scratch for btbbx_scan_ordered_device over n_streams streams of search_bits offsets each (round 6).  Where the scan has its
  * segment-slot form -- LAP_ANY with tables for up to two errors -- every wave leaves its hits, ranked, in slots of the 4032 offsets
- * they lie in (32 bytes per 4032 offsets of scratch), and the ordered list is one compaction of those slots: no bucket counters, no
+ * they lie in (16 bytes per 4032 offsets of scratch), and the ordered list is one compaction of those slots: no bucket counters, no
  * scatter, no ranking pass.  The size returned covers that (and the general ordering, which stays the fallback for a stream the
  * slots cannot rank: one made of sync words); for other scans it equals btbbx_order_hits_scratch_bytes(cap).  A call that is
  * handed btbbx_order_hits_scratch_bytes(cap) bytes only runs the general ordering.  Needs btbb_init / btbbx_init first (the

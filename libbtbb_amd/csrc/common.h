@@ -62,7 +62,8 @@ struct ScanTables {
 
 // Segment slots of the ordered LAP_ANY scan (scan.hip scan_slide_kernel<..., ORD> fills them, sort.hip lays them out and compacts them)
 struct ScanSlots {
-	btbbx_hit *slots;          // [segments][slot_n]
+	uint64_t *slots;           // [segments][slot_n], 8 bytes each (ScanArgs::seg_slots)
+	uint32_t seg_offsets;      // offsets a segment covers: 4032 (LAP_ANY: 63 words) or 4096 (known LAP)
 	uint16_t *cnt;             // [segments] hits per segment, zeroed before the scan
 	uint32_t slot_n;
 	uint32_t segs_per_stream;

@@ -457,11 +457,9 @@ extern "C" int btbbx_slide_set(int max_ac_errors, uint32_t *bitmap_words, uint64
 
 // size of the second-level bitmap by the error count the tables are built for (2^bits bits; 26 = 8 MiB, rounds 1-3)
 #define BITMAP2_BITS_3 26
-#ifndef BITMAP2_BITS_4
 #define BITMAP2_BITS_4 22          // 512 KiB.  (rounds 3-4, when every survivor probed it: 2^24 = 2 MiB, "2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51".)
-#endif                             // Round 6: only the exact check of the two-level kernel's candidates looks at it now, and 2 MiB of it beside the 2 MiB
+                                   // Round 6: only the exact check of the two-level kernel's candidates looks at it now, and 2 MiB of it beside the 2 MiB
                                    // second-level set were the whole L2 of an XCD: 2.07 x the algorithmic bytes per launch -> 1.50 x, same time (profiles/r06_init4)
-//         // 2 MiB: stays in every XCD's 4 MiB L2 beside the stream (2.78 against 3.32 ms per GiB with 8 MiB; 2^22: 3.51)
 #define BITMAP2_BITS_5 26
 static int upload_tables(int max_ac_errors)
 {

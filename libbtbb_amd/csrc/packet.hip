@@ -1341,15 +1341,11 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 			// chunk-major: chunk 0 of every packet, then chunk 1 of every packet, ... -- a packet needs only the chunks in front of its
 			// first failing block, so the tasks that have work lie at the front of the list and the second round of TL_THREADS
 			// tasks (640 tasks on 512 threads) is empty for everything but full-length DM3 / DM5 payloads (round 6; packet-major
-			// left a quarter of the threads a full chunk each in that round)
+			// left a quarter of the threads a full chunk each in that round: 0.924-0.931 against 0.873 ms per 2^20 packets, all types
+			// 0.862 against 0.823 -- profiles/r06_trials; the EV4 scan, taken out as a probe, is 2 % of the batch)
 			const uint32_t u = t - mine * 12;
-#ifdef TL_CHUNK_PACKET_MAJOR
-			p = u / 8;
-			j = u % 8;
-#else
 			j = mine == TL_PACKETS ? u / TL_PACKETS : u / mine;
 			p = u - j * mine;
-#endif
 			layout = 1;
 			r = 11 + j;
 			const uint32_t need = a_words(p);
@@ -1521,7 +1517,6 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 			rv = crc_is_zero(layout, (uint32_t)plen) ? 10 : 2;
 			break;
 		}
-#ifndef TL_PROBE_NO_EV4                                      // (timing probe: what the EV4 scan costs the batch)
 		case 12: {                                              // EV4 (:1044-1097)
 			// iterations b = 0 .. B-1 of the reference's block loop get past its two checks
 			uint32_t B = size >= 15 ? (uint32_t)size / 15 : 0;
@@ -1550,7 +1545,6 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 			}
 			break;
 		}
-#endif
 		case 5: rv = hv_rv[p]; break;                           // HV1
 		default: rv = 1; break;                                 // EV3 / EV5 always map to 1, the rest is not checked
 		}

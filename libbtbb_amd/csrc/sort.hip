@@ -534,9 +534,7 @@ __global__ __launch_bounds__(1024) void order_single_kernel(const btbbx_hit *lis
 // order is then a COMPACTION of the slots: counts -> prefix -> one copy, every read and write coalesced; no bucket atomics in the
 // scan, no scatter, no ranking of bucket-mates.  Hits ranked beyond the slots (more than SLOT_N in 4032 offsets) wait in an overflow
 // list with (segment, rank) and are put at prefix[segment] + rank by one more launch that usually finds nothing.
-#ifndef SLOT_N
-#define SLOT_N 2u                              // slots per segment
-#endif
+#define SLOT_N 2u                              // slots per segment (one: 40 % of the benchmark's list through the overflow list, 81 us more -- profiles/r06_order)
 #define SLOT_BLOCK 1024u                       // segments per workgroup of the compaction
 
 struct SlotHeader {
@@ -601,7 +599,8 @@ __global__ __launch_bounds__(1024) void slot_sums_kernel(const uint16_t *cnt, ui
 // (a wave takes 64 x SLOT_PER consecutive segments, a lane every 64th of them: counts, slots and output are read and written
 // by neighbouring lanes next to each other -- eight consecutive segments per lane instead made this kernel 194 us against 75)
 __global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, uint32_t n_segs, const uint32_t *block_sums, SlotHeader *hd,
-							  const HitRec *slots, uint32_t *seg_start, HitRec *out, uint32_t cap, uint32_t *d_count)
+							  const uint64_t *slots, uint32_t segs_per_stream, uint32_t seg_offsets, uint32_t *seg_start,
+							  btbbx_hit *out, uint32_t cap, uint32_t *d_count)
 {
 	__shared__ uint32_t lds_wave[16];
 	uint32_t before = 0, all = 0;                         // sums of the workgroups in front of this one / of all of them
@@ -653,11 +652,21 @@ __global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, u
 		if (n == 0)
 			continue;
 		const uint32_t seg = wfirst + k * 64 + lane;
-		const HitRec *src = slots + (uint64_t)seg * SLOT_N;
+		const uint64_t *src = slots + (uint64_t)seg * SLOT_N;
+		const uint32_t stream = seg / segs_per_stream;        // a slot holds what the segment does not say
+		const uint64_t seg_first = (uint64_t)(seg - stream * segs_per_stream) * seg_offsets;
 #pragma unroll
 		for (uint32_t r = 0; r < SLOT_N; r++)
-			if (r < n && pos + r < cap)
-				out[pos + r] = src[r];
+			if (r < n && pos + r < cap) {
+				const uint64_t v = src[r];
+				btbbx_hit h;
+				h.offset = seg_first + (v & 0xfffu);
+				h.lap = (uint32_t)(v >> 12) & 0xffffffu;
+				h.ac_errors = (uint8_t)(v >> 36);
+				h.reserved = 0;
+				h.stream = (uint16_t)stream;
+				reinterpret_cast<HitRec *>(out)[pos + r] = *reinterpret_cast<const HitRec *>(&h);
+			}
 		if (n > SLOT_N)
 			seg_start[seg] = pos;
 	}
@@ -940,7 +949,7 @@ static SlotLayout slot_layout(size_t front, uint32_t segs_per_stream, uint64_t n
 	S.sums = S.cnt + up(n_segs * sizeof(uint16_t) + 16);
 	S.seg_start = S.sums + up(((size_t)S.n_blocks + 1) * 4);
 	S.slots = S.seg_start + up(n_segs * 4);
-	S.ovf_recs = S.slots + up(n_segs * SLOT_N * sizeof(btbbx_hit));
+	S.ovf_recs = S.slots + up(n_segs * SLOT_N * sizeof(uint64_t));
 	S.ovf_meta = S.ovf_recs + up((size_t)cap * sizeof(btbbx_hit));
 	S.total = S.ovf_meta + up((size_t)cap * 8);
 	return S;
@@ -987,7 +996,8 @@ extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n
 				SlotHeader *hd = (SlotHeader *)(base + S.header);
 				HIP_TRY(hipMemsetAsync(base + S.header, 0, S.sums - S.header, stream));
 				ScanSlots sl;
-				sl.slots = (btbbx_hit *)(base + S.slots);
+				sl.slots = (uint64_t *)(base + S.slots);
+				sl.seg_offsets = lap == BTBBX_LAP_ANY ? 4032u : 4096u;
 				sl.cnt = (uint16_t *)(base + S.cnt);
 				sl.slot_n = SLOT_N;
 				sl.segs_per_stream = S.segs_per_stream;
@@ -1029,7 +1039,8 @@ extern "C" int btbbx_scan_ordered_device_fmt(const uint64_t *d_words, uint64_t n
 				uint32_t *sums = (uint32_t *)(base + S.sums);
 				hipLaunchKernelGGL(slot_sums_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums);
 				hipLaunchKernelGGL(slot_place_kernel, dim3(S.n_blocks), dim3(1024), 0, stream, sl.cnt, S.n_segs, sums, hd,
-						   (const HitRec *)(base + S.slots), (uint32_t *)(base + S.seg_start), (HitRec *)d_hits, cap, d_count);
+						   (const uint64_t *)(base + S.slots), S.segs_per_stream, sl.seg_offsets, (uint32_t *)(base + S.seg_start), d_hits, cap,
+						   d_count);
 				hipLaunchKernelGGL(slot_overflow_kernel, dim3(64), dim3(256), 0, stream, hd, (const HitRec *)(base + S.ovf_recs),
 						   (const uint2 *)(base + S.ovf_meta), S.ovf_cap, (const uint32_t *)(base + S.seg_start), (HitRec *)d_hits, cap);
 				HIP_TRY(hipGetLastError());
