@@ -735,13 +735,28 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
     step()
     torch.cuda.synchronize()
     reps = 10
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(cur)
-    for _ in range(reps):
-        step()
-    b.record(cur)
+
+    def timed(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+        for _ in range(reps):
+            fn()
+        b.record(cur)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    # the unordered launch again, right beside the ordered one (the headline loop ran minutes ago, on a cooler chip): the ratio of
+    # these two is what ordering costs
+    def plain():
+        cnt_t.zero_()
+        bt.check(lib.btbbx_scan_device(stream.data_ptr(), nwords, nwords, 1, nbits, bt.LAP_ANY, 2, hits_t.data_ptr(), cap, cnt_t.data_ptr(), hs))
+    plain()
     torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
+    plain_ms = timed(plain)
+    ms = timed(step)
+    plain_ms = min(plain_ms, timed(plain))               # (before and behind the ordered loop)
+    step()
+    torch.cuda.synchronize()
     n = int(cnt_t.item())
     got = hits_t.cpu().numpy().view(bt.HIT_DTYPE)[:n].copy()
     increasing = bool(np.all(got["offset"][1:] > got["offset"][:-1]))
@@ -755,7 +770,8 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
                   "coalesced copy), one stream, no host round trip",
         "scratch_bytes": int(order_bytes),
         "value": round(nbits / (ms * 1e-3) / 1e9, 2), "unit": "Gbit/s", "ms_per_step": round(ms, 4), "hits": n,
-        "ordering_ms": round(ms - unordered_ms, 4), "unordered_kernel_ms": round(unordered_ms, 4),
+        "ordering_ms": round(ms - plain_ms, 4), "unordered_ms_beside": round(plain_ms, 4), "ordered_over_unordered": round(ms / plain_ms, 4),
+        "unordered_kernel_ms_headline_loop": round(unordered_ms, 4),
         "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
                      "kernel": "scan_slide_kernel<ORD> + slot_*", "traffic": secondary_traffic("lap_any_4gib_ordered")[0],
