@@ -45,10 +45,12 @@ print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / al
 out = {"csrc_sha16": fp, "source": "%s/pmc_sec_<line>.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
        "`python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary <line>` (one line of the block at a time: a kernel's mean "
        "per launch then belongs to one workload); (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, as in traffic.json" % rel}
-CHAIN = ("scan_known_lap_kernel", "order_", "decode_hits_kernel")
-DOMINANT = {"lap_any_4gib_ordered": "scan_slide_kernel", "lap_any_4gib_init4": "Slide4", "known_lap_79ch_chain_full_payloads": "scan_known_lap_kernel",
-            "known_lap_79ch_chain": "scan_known_lap_kernel", "clk6_bruteforce": "trials_linear_kernel", "clk6_bruteforce_all_types": "trials_linear_kernel"}
-for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel", "order_", "slot_")), ("lap_any_4gib_init4", ("Slide4",)), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
+# (round 6: the ordered lines run the scan kernels' slot form -- "..., true>" -- and the compaction; the plain forms also appear in those
+# runs, as the lines' own unordered timing and as the gated fallback's launches that return at once: not part of the step)
+CHAIN = ("scan_known_lap_kernel<2, 1, false, true>", "slot_", "order_single", "decode_hits_kernel")
+DOMINANT = {"lap_any_4gib_ordered": "scan_slide_kernel<SlideStd, 2, false, true>", "lap_any_4gib_init4": "Slide4",
+            "known_lap_79ch_chain_full_payloads": "scan_known_lap_kernel<2, 1, false, true>", "known_lap_79ch_chain": "scan_known_lap_kernel<2, 1, false, true>", "clk6_bruteforce": "trials_linear_kernel", "clk6_bruteforce_all_types": "trials_linear_kernel"}
+for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel<SlideStd, 2, false, true>", "slot_", "order_single")), ("lap_any_4gib_init4", ("Slide4",)), ("known_lap_79ch_chain_full_payloads", CHAIN), ("known_lap_79ch_chain", CHAIN),
                    ("clk6_bruteforce", ("trials_linear_kernel", "trials_wave_kernel")),
                    ("clk6_bruteforce_all_types", ("trials_linear_kernel", "trials_wave_kernel"))):
     path = os.path.join(d, "pmc_sec_%s.json" % line)
