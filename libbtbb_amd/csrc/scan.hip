@@ -1391,19 +1391,33 @@ constexpr bool barker_bit(int cls, int j) { return (((cls ? BARKER1 : BARKER0) >
 template <uint32_t TT>
 __device__ __forceinline__ uint32_t bitop3_tt(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
 
-// bit-sliced "mismatches in sync-word bits 52..63 <= limit" for 32 offsets: twelve planes
-// (window bit 52 + k of offset p is bit p + 20 + k of dh:dm), a carry-save adder tree to a 4-bit
-// count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
+// The planes of the known-LAP filters (round 6, late): the filter may count mismatches in ANY subset of the sync word's bits, so it
+// takes them where the funnel shifts can be shared -- window bits 24 + j and 56 + j (j = 0 .. 7) of the offsets p of a 32-offset half
+// are the stream bits p + 24 + j of two neighbouring dword pairs, and the UPPER planes of one half are the LOWER planes of the next:
+// three sets of eight shifts per word instead of four (sixteen top bits per half: 32 v_alignbit per word -> 24).  Bits 57 .. 63 are
+// still the class bits whose complement folds into the adders' truth tables.
+// P[j] = stream bit p + 24 + j of hi:lo for the 32 offsets p of a half (j = FIRST .. 7)
+template <int FIRST>
+__device__ __forceinline__ void pair_planes(uint32_t lo, uint32_t hi, uint32_t *P)
+{
+#pragma unroll
+	for (int j = FIRST; j < 8; j++)
+		P[j] = alignbit(hi, lo, 24 + j);
+}
+
+// bit-sliced "mismatches in sync-word bits 28..31 and 56..63 <= limit" for 32 offsets: twelve planes
+// (lowp[4 .. 7] = window bits 28 .. 31, highp[0 .. 7] = window bits 56 .. 63; flip[4 + k] = the sync word's bit of plane k),
+// a carry-save adder tree to a 4-bit count per offset, and a bit-sliced compare with the run-time limit.  For limit 2 it keeps
 // 79 / 4096 = 1.9 % of the offsets of a random stream.
 template <int CLS>
-__device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
+__device__ __forceinline__ uint32_t top12_filter(const uint32_t *lowp, const uint32_t *highp, const uint32_t *flip, int limit)
 {
 	if (limit >= 12)
 		return 0xffffffffu;
 	uint32_t m[12];
 #pragma unroll
-	for (int k = 0; k < 12; k++) {                      // plane k = window bit 52 + k; 5 .. 11 are the class bits 57 .. 63
-		m[k] = alignbit(dh, dm, 20 + k);
+	for (int k = 0; k < 12; k++) {                      // plane k: 0 .. 3 = window bits 28 .. 31, 4 = bit 56, 5 .. 11 = the class bits 57 .. 63
+		m[k] = k < 4 ? lowp[4 + k] : highp[k - 4];
 		if (CLS < 0 || k < 5)
 			m[k] ^= flip[4 + k];
 	}
@@ -1441,18 +1455,18 @@ __device__ __forceinline__ uint32_t top12_filter(uint32_t dm, uint32_t dh, const
 	return ~gt;
 }
 
-// The same over the top sixteen sync-word bits (48..63): five more adders, but for limit >= 2 it
+// The same over sixteen sync-word bits (24..31 and 56..63): five more adders, but for limit >= 2 it
 // leaves a tenth of the survivors (0.2 % instead of 1.9 % at limit 2), which is worth more than it
 // costs; for limit <= 1 the twelve-plane filter is already sparse enough and cheaper.
 template <int CLS>
-__device__ __forceinline__ uint32_t top16_filter(uint32_t dm, uint32_t dh, const uint32_t *flip, int limit)
+__device__ __forceinline__ uint32_t top16_filter(const uint32_t *lowp, const uint32_t *highp, const uint32_t *flip, int limit)
 {
 	if (limit >= 16)
 		return 0xffffffffu;
 	uint32_t m[16];
 #pragma unroll
-	for (int k = 0; k < 16; k++) {                      // plane k = window bit 48 + k; 9 .. 15 are the class bits 57 .. 63
-		m[k] = alignbit(dh, dm, 16 + k);
+	for (int k = 0; k < 16; k++) {                      // plane k: 0 .. 7 = window bits 24 .. 31, 8 = bit 56, 9 .. 15 = the class bits 57 .. 63
+		m[k] = k < 8 ? lowp[k] : highp[k - 8];
 		if (CLS < 0 || k < 9)
 			m[k] ^= flip[k];
 	}
@@ -1536,7 +1550,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	uint32_t flip[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) {
-		flip[k] = ((ac_hi >> (16 + k)) & 1) ? 0xffffffffu : 0u;
+		flip[k] = (((k < 8 ? ac_lo : ac_hi) >> (24 + (k & 7))) & 1) ? 0xffffffffu : 0u;   // plane k = sync-word bit 24 + k (k < 8), 48 + k (k >= 8)
 		asm volatile("" : "+v"(flip[k]));
 	}
 	const int limit = LIMIT >= 0 ? LIMIT : (a.max_err < 0 ? -1 : a.max_err);
@@ -1762,12 +1776,20 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 				for (int k = 0; k < 4; k++)
 					d[u][k] = msb_dword(d[u][k]);
 			}
+			// (pair_planes above: the planes of d1:d2 are the upper planes of offsets 0 .. 31 and the lower ones of 32 .. 63)
+			uint32_t pa[8], pb[8], pc[8];
 			if (wide) {
-				m[u][0] = top16_filter<CLS>(d[u][1], d[u][2], flip, limit);
-				m[u][1] = top16_filter<CLS>(d[u][2], d[u][3], flip, limit);
+				pair_planes<0>(d[u][0], d[u][1], pa);
+				pair_planes<0>(d[u][1], d[u][2], pb);
+				m[u][0] = top16_filter<CLS>(pa, pb, flip, limit);
+				pair_planes<0>(d[u][2], d[u][3], pc);
+				m[u][1] = top16_filter<CLS>(pb, pc, flip, limit);
 			} else {
-				m[u][0] = top12_filter<CLS>(d[u][1], d[u][2], flip, limit);
-				m[u][1] = top12_filter<CLS>(d[u][2], d[u][3], flip, limit);
+				pair_planes<4>(d[u][0], d[u][1], pa);
+				pair_planes<0>(d[u][1], d[u][2], pb);
+				m[u][0] = top12_filter<CLS>(pa, pb, flip, limit);
+				pair_planes<0>(d[u][2], d[u][3], pc);
+				m[u][1] = top12_filter<CLS>(pb, pc, flip, limit);
 			}
 			m[u][0] &= (uint32_t)valid[u];
 			m[u][1] &= (uint32_t)(valid[u] >> 32);
