@@ -1520,8 +1520,9 @@ __device__ __forceinline__ uint32_t top16_filter(const uint32_t *lowp, const uin
 // counter atomic per 64 hits (a single counter word saturates near 88 M atomics/s on this
 // chip, which a dense hit stream would otherwise run into).
 #define KRING 128
-#define KL_WORDS 2                             // stream words per lane and tile (tile = KL_WORDS x 256 words); the next tile's
-                                               // words are loaded while this one is worked on (0.466 against 0.4865 ms, round 3)
+#ifndef KL_WORDS
+#define KL_WORDS 2                             // consecutive stream words per lane and tile (tile = KL_WORDS x 256 words; a power of two); the
+#endif                                         // next tile's words are loaded while this one is worked on (0.466 against 0.4865 ms, round 3)
 #define KL_SELECT_LIMIT 1                      // limits up to here: one survivor per lane and pass (scan_known_lap_kernel)
 struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per staged hit
 
@@ -1615,8 +1616,9 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		if (hit) {
 			const uint32_t slot = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
 					__builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-			// (ordered scan: bits 24 .. 31 = the segment's tag inside the batch, two per tile: word bit 8 = offset bit 14 tells which)
-			const uint32_t tag = ((iter << 1) | ((uint32_t)(offset >> 14) & 1u)) & 0xffu;
+			// (ordered scan: bits 24 .. 31 = the segment's tag inside the batch, KL_WORDS per tile: a wave's run of a tile starts at a
+			// multiple of 64 KL_WORDS words, so the segment number's low bits tell which)
+			const uint32_t tag = ((iter * KL_WORDS) | ((uint32_t)(offset >> 12) & (KL_WORDS - 1u))) & 0xffu;
 			KnownHit k = { (uint32_t)offset, (uint32_t)(offset >> 32), (stream << 8) | nerr | (ord ? tag << 24 : 0u) };
 			ring[slot & (KRING - 1)] = k;
 		}
@@ -1628,7 +1630,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			return;
 		uint32_t *cnt = slot_cnt[tid >> 6];
 		uint16_t (*codes)[4] = slot_code[tid >> 6];
-		const bool tags_ok = iter - ring_first_iter < 32;      // two tags per tile, 64 counters: no two segments of the batch share one
+		const bool tags_ok = iter - ring_first_iter < 64 / KL_WORDS;      // KL_WORDS tags per tile, 64 counters: no two segments of the batch share one
 		// (one round of 64 entries at a time and nothing kept between the rounds: the kernel's 64 registers are its eight waves per SIMD)
 		bool fast = tags_ok;
 		if (tags_ok) {
@@ -1708,48 +1710,52 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		t -= tiles_per_stream;
 		stream++;
 	}
-	// a tile is KL_WORDS x 256 words: every lane owns KL_WORDS words 256 apart.  The next tile's words are loaded while
-	// this one is worked on: the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per
-	// SIMD taking turns at their loads (profiles/r03_chain/pmc_known_before.json).
-	uint64_t nlo[KL_WORDS], nhi[KL_WORDS];
+	// A tile is KL_WORDS x 256 words and a lane owns KL_WORDS CONSECUTIVE words of it (round 6, late; rounds 1-5: words 256 apart),
+	// so the filter's planes are shared all along the lane's run of 2 * KL_WORDS halves: 8 x (2 * KL_WORDS + 1) funnel shifts per
+	// tile instead of 8 x 3 x KL_WORDS, and one halo word per lane instead of one per word.  The next tile's words are loaded while
+	// this one is worked on: the counters had 43 % of the wave-cycles in s_waitcnt with eight waves per SIMD taking turns at their
+	// loads (profiles/r03_chain/pmc_known_before.json).
+	constexpr int NCH = 2 * KL_WORDS;                   // chains (32-offset halves) per lane and tile
+	const uint32_t lw = tid * KL_WORDS;                 // the lane's first word in a tile
+	uint64_t nw[KL_WORDS + 1];                          // the lane's words of the next tile and the word behind them
 	auto fetch = [&](uint32_t ft, uint32_t fstream) {
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++)
-			nlo[u] = nhi[u] = 0;
+		for (int u = 0; u <= KL_WORDS; u++)
+			nw[u] = 0;
 		if (fstream >= a.n_streams)
 			return;
 		// wave-uniform tile pointer + the lane's constant index: no 64-bit address arithmetic per lane and tile (issuing
 		// the loads had been 8.5 % of the wave time, profiles/r03_chain/known_lap_phases.txt)
 		const uint64_t *tp = a.words + (uint64_t)fstream * a.pitch_words + (uint64_t)ft * (KL_WORDS * 256);
+		if (ft < a.full_tiles) {                        // wave-uniform: every word, halo word and offset of the tile is in range
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++) {
-			if (ft < a.full_tiles) {                    // wave-uniform: every word, halo word and offset of the tile is in range
-				nlo[u] = tp[u * 256 + tid];
-				nhi[u] = tp[u * 256 + tid + 1];
-			} else {
-				const uint64_t w = ((uint64_t)ft * KL_WORDS + u) * 256 + tid;
-				nlo[u] = w < a.n_words ? tp[u * 256 + tid] : 0;
-				nhi[u] = w + 1 < a.n_words ? tp[u * 256 + tid + 1] : 0;
-			}
+			for (int u = 0; u <= KL_WORDS; u++)
+				nw[u] = tp[lw + u];
+		} else {
+			const uint64_t w = (uint64_t)ft * (KL_WORDS * 256) + lw;
+#pragma unroll
+			for (int u = 0; u <= KL_WORDS; u++)
+				nw[u] = w + u < a.n_words ? tp[lw + u] : 0;
 		}
 	};
 	fetch(t, stream);
 	while (stream < a.n_streams) {
 		// word index and validity of this tile's offsets from the (wave-uniform) tile number: nothing per lane is carried
-		// from the fetch but the words themselves
-		uint64_t word[KL_WORDS];
-		uint32_t d[KL_WORDS][4], m[KL_WORDS][2];
-		uint64_t lo[KL_WORDS], hi[KL_WORDS], valid[KL_WORDS];
+		// from the fetch but the words themselves.  Chain c = offsets 32 c .. 32 c + 31 of the lane's run; its windows lie in D[c .. c + 2].
+		const uint64_t word0 = (uint64_t)t * (KL_WORDS * 256) + lw;
+		uint32_t D[NCH + 2], m[NCH], valid[NCH];
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++) {
-			word[u] = ((uint64_t)t * KL_WORDS + u) * 256 + tid;
-			lo[u] = nlo[u];
-			hi[u] = nhi[u];
-			valid[u] = FULL_MASK;
+		for (int u = 0; u <= KL_WORDS; u++) {
+			D[2 * u] = (uint32_t)nw[u];
+			D[2 * u + 1] = (uint32_t)(nw[u] >> 32);
+		}
+#pragma unroll
+		for (int c = 0; c < NCH; c++) {
+			valid[c] = 0xffffffffu;
 			if (t >= a.full_tiles) {
-				const uint64_t first_off = word[u] * 64;
-				valid[u] = first_off >= a.search_bits ? 0ULL
-					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
+				const uint64_t first_off = word0 * 64 + 32u * c;
+				valid[c] = first_off >= a.search_bits ? 0u
+					: (a.search_bits - first_off >= 32 ? 0xffffffffu : ((1u << (uint32_t)(a.search_bits - first_off)) - 1u));
 			}
 		}
 		const uint32_t this_stream = stream;
@@ -1762,101 +1768,89 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		PROF_MARK(4);
 #ifdef SCAN_PROFILE
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++)
-			asm volatile("" : "+v"(lo[u]), "+v"(hi[u]));        // this tile's words have arrived
+		for (int k = 0; k < NCH + 2; k++)
+			asm volatile("" : "+v"(D[k]));                  // this tile's words have arrived
 		PROF_MARK(0);
 #endif
 		__builtin_amdgcn_s_setprio(0);                  // bit-sliced filter: lowest (see PRIO_FILTER above)
+		if constexpr (MSB) {
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++) {
-			d[u][0] = (uint32_t)lo[u]; d[u][1] = (uint32_t)(lo[u] >> 32);
-			d[u][2] = (uint32_t)hi[u]; d[u][3] = (uint32_t)(hi[u] >> 32);
-			if constexpr (MSB) {
+			for (int k = 0; k < NCH + 2; k++)
+				D[k] = msb_dword(D[k]);
+		}
+		{	// (pair_planes above: the planes of D[c + 1] : D[c + 2] are the upper planes of chain c and the lower ones of chain c + 1)
+			uint32_t P[2][8];
+			if (wide)
+				pair_planes<0>(D[0], D[1], P[0]);
+			else
+				pair_planes<4>(D[0], D[1], P[0]);
 #pragma unroll
-				for (int k = 0; k < 4; k++)
-					d[u][k] = msb_dword(d[u][k]);
+			for (int c = 0; c < NCH; c++) {
+				pair_planes<0>(D[c + 1], D[c + 2], P[(c + 1) & 1]);
+				m[c] = (wide ? top16_filter<CLS>(P[c & 1], P[(c + 1) & 1], flip, limit)
+					     : top12_filter<CLS>(P[c & 1], P[(c + 1) & 1], flip, limit)) & valid[c];
 			}
-			// (pair_planes above: the planes of d1:d2 are the upper planes of offsets 0 .. 31 and the lower ones of 32 .. 63)
-			uint32_t pa[8], pb[8], pc[8];
-			if (wide) {
-				pair_planes<0>(d[u][0], d[u][1], pa);
-				pair_planes<0>(d[u][1], d[u][2], pb);
-				m[u][0] = top16_filter<CLS>(pa, pb, flip, limit);
-				pair_planes<0>(d[u][2], d[u][3], pc);
-				m[u][1] = top16_filter<CLS>(pb, pc, flip, limit);
-			} else {
-				pair_planes<4>(d[u][0], d[u][1], pa);
-				pair_planes<0>(d[u][1], d[u][2], pb);
-				m[u][0] = top12_filter<CLS>(pa, pb, flip, limit);
-				pair_planes<0>(d[u][2], d[u][3], pc);
-				m[u][1] = top12_filter<CLS>(pb, pc, flip, limit);
-			}
-			m[u][0] &= (uint32_t)valid[u];
-			m[u][1] &= (uint32_t)(valid[u] >> 32);
 		}
 #ifdef SCAN_PROFILE
 #pragma unroll
-		for (int u = 0; u < KL_WORDS; u++) {
-			PROF_PIN(m[u][0]);
-			PROF_PIN(m[u][1]);
-		}
+		for (int c = 0; c < NCH; c++)
+			PROF_PIN(m[c]);
 		PROF_MARK(1);
 #endif
 		__builtin_amdgcn_s_setprio(3);                  // survivors, hit staging, flush and the next tile's loads: highest
 		// Limits 0 and 1 (few survivors: the filter passes 2.6e-4 / 1.5e-5 of the offsets): ONE survivor per lane and pass -- the
-		// next one of whichever half of whichever word holds one; a pass that looks at one offset of every half costs four checks
+		// next one of whichever chain holds one; a pass that looks at one offset of every chain costs NCH checks
 		// for a small fraction of a survivor per lane.  4 GiB at limit 0: 1.85 -> 1.71 ms; at limit 2 nothing (2.52 / 2.50), at
-		// limit 4 the lane's survivors queue up (3.14 -> 3.91): the four-halves pass stays for limits of 2 and more.
-		if constexpr (KL_WORDS == 2 && LIMIT >= 0 && LIMIT <= KL_SELECT_LIMIT) {
+		// limit 4 the lane's survivors queue up (3.14 -> 3.91): the every-chain pass stays for limits of 2 and more.
+		if constexpr (LIMIT >= 0 && LIMIT <= KL_SELECT_LIMIT) {
 		for (;;) {
-			const uint32_t m00 = m[0][0], m01 = m[0][1], m10 = m[1][0], m11 = m[1][1];
-			const bool s0 = m00 != 0, s1 = !s0 && m01 != 0, s2 = !s0 && !s1 && m10 != 0, s3 = !s0 && !s1 && !s2;
-			const uint32_t mm = s0 ? m00 : s1 ? m01 : s2 ? m10 : m11;
+			uint32_t mm = m[NCH - 1], da = D[NCH - 1], db = D[NCH], dc = D[NCH + 1], ci = NCH - 1;   // the lane's first chain that holds a survivor
+#pragma unroll
+			for (int c = NCH - 2; c >= 0; c--) {
+				const bool s = m[c] != 0;
+				mm = s ? m[c] : mm;
+				da = s ? D[c] : da;
+				db = s ? D[c + 1] : db;
+				dc = s ? D[c + 2] : dc;
+				ci = s ? (uint32_t)c : ci;
+			}
 			if (!__ballot(mm != 0))
 				break;
-			const uint32_t da = s0 ? d[0][0] : s1 ? d[0][1] : s2 ? d[1][0] : d[1][1];
-			const uint32_t db = s0 ? d[0][1] : s1 ? d[0][2] : s2 ? d[1][1] : d[1][2];
-			const uint32_t dc = s0 ? d[0][2] : s1 ? d[0][3] : s2 ? d[1][2] : d[1][3];
 			const uint32_t p1 = __builtin_ctz(mm | 0x80000000u);
 			const int e1 = __popc(alignbit(db, da, p1) ^ ac_lo) + __popc(alignbit(dc, db, p1) ^ ac_hi);          // :433
 			const bool hit1 = mm != 0 && e1 <= limit;
 			const uint32_t rest = mm & (mm - 1);
-			m[0][0] = s0 ? rest : m00;
-			m[0][1] = s1 ? rest : m01;
-			m[1][0] = s2 ? rest : m10;
-			m[1][1] = s3 ? rest : m11;
+#pragma unroll
+			for (int c = 0; c < NCH; c++)
+				m[c] = ci == (uint32_t)c ? rest : m[c];
 			if (__ballot(hit1))
-				stage(hit1, this_stream, ((s0 || s1) ? word[0] : word[1]) * 64 + ((s1 || s3) ? 32u : 0u) + p1, (uint32_t)e1);
+				stage(hit1, this_stream, word0 * 64 + 32u * ci + p1, (uint32_t)e1);
 		}
 		} else {
-		// wave-uniform survivor loop, one offset of every 32-offset half per pass
+		// wave-uniform survivor loop, one offset of every chain per pass
 		for (;;) {
 			uint32_t any = 0;
 #pragma unroll
-			for (int u = 0; u < KL_WORDS; u++)
-				any |= m[u][0] | m[u][1];
+			for (int c = 0; c < NCH; c++)
+				any |= m[c];
 			if (!__ballot(any != 0))
 				break;
-			uint32_t p[KL_WORDS][2];
-			int e[KL_WORDS][2];
-			bool hit[KL_WORDS][2], anyhit = false;
+			uint32_t p[NCH];
+			int e[NCH];
+			bool hit[NCH], anyhit = false;
 #pragma unroll
-			for (int u = 0; u < KL_WORDS; u++)
-#pragma unroll
-				for (int h = 0; h < 2; h++) {
-					p[u][h] = __builtin_ctz(m[u][h] | 0x80000000u);
-					e[u][h] = __popc(alignbit(d[u][h + 1], d[u][h], p[u][h]) ^ ac_lo)
-						+ __popc(alignbit(d[u][h + 2], d[u][h + 1], p[u][h]) ^ ac_hi);          // :433
-					hit[u][h] = m[u][h] != 0 && e[u][h] <= limit;
-					anyhit |= hit[u][h];
-					m[u][h] &= m[u][h] - 1;
-				}
+			for (int c = 0; c < NCH; c++) {
+				p[c] = __builtin_ctz(m[c] | 0x80000000u);
+				e[c] = __popc(alignbit(D[c + 1], D[c], p[c]) ^ ac_lo)
+					+ __popc(alignbit(D[c + 2], D[c + 1], p[c]) ^ ac_hi);          // :433
+				hit[c] = m[c] != 0 && e[c] <= limit;
+				anyhit |= hit[c];
+				m[c] &= m[c] - 1;
+			}
 			if (__ballot(anyhit)) {
 #pragma unroll
-				for (int u = 0; u < KL_WORDS; u++)
-#pragma unroll
-					for (int h = 0; h < 2; h++)
-						stage(hit[u][h], this_stream, word[u] * 64 + 32 * h + p[u][h], (uint32_t)e[u][h]);
+				for (int c = 0; c < NCH; c++)
+					stage(hit[c], this_stream, word0 * 64 + 32u * c + p[c], (uint32_t)e[c]);
 			}
 		}
 		}
