@@ -1352,7 +1352,8 @@ void scan_slide_kernel(ScanArgs a)
 #pragma unroll
 		for (int u = 0; u < TILES; u++) {
 			// no software prefetch: the other five waves of the SIMD cover the loads, and the eight registers it took are
-			// worth more (round 5: 3.35 against 3.38 ms)
+			// worth more (round 5: 3.35 against 3.38 ms; round 6 again, the loads issued right behind the filter and checked in
+			// the ISA to be waited for only at the next trip's head, 77 VGPRs: 3.03-3.06 against 2.93-2.95 -- profiles/r06_scan)
 			tc[u] = cur;
 			load_pair(cur, lo[u], hi[u]);
 			advance(cur);
@@ -1739,6 +1740,12 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 	};
 	fetch(t, stream);
+	// The first tile's words are waited for HERE: with these loads still counted as pending at the loop head the compiler waits for
+	// "everything in flight" (s_waitcnt vmcnt(0)) in front of the filter of EVERY tile -- right behind the next tile's loads, which
+	// undid the prefetch (rounds 3-6: 15-25 % of a wave's time in that wait, profiles/r06_known).
+#pragma unroll
+	for (int u = 0; u <= KL_WORDS; u++)
+		asm volatile("" : "+v"(nw[u]));
 	while (stream < a.n_streams) {
 		// word index and validity of this tile's offsets from the (wave-uniform) tile number: nothing per lane is carried
 		// from the fetch but the words themselves.  Chain c = offsets 32 c .. 32 c + 31 of the lane's run; its windows lie in D[c .. c + 2].
