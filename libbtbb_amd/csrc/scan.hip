@@ -1533,6 +1533,7 @@ struct KnownHit { uint32_t off_lo, off_hi, stream_err; };      // 12 bytes per s
 // ORD: the ordered scan's form -- hits leave through the segment slots (a template flag: the code that fills them costs the plain form
 // eight registers, one wave per SIMD, if it is only branched around)
 template <int LIMIT, int CLS, bool MSB, bool ORD = false>
+// (round 6: the ORD form at 65 VGPRs = seven waves per SIMD; forced to 64 / eight by amdgpu_waves_per_eu: no difference, 0.540-0.542 against 0.538-0.544 ms per chain step)
 __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 {
 	__shared__ KnownHit ring_mem[4][KRING];
@@ -1834,30 +1835,53 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 				stage(hit1, this_stream, word0 * 64 + 32u * ci + p1, (uint32_t)e1);
 		}
 		} else {
-		// wave-uniform survivor loop, one offset of every chain per pass
-		for (;;) {
+		// wave-uniform survivor loop.  First pass: one offset of every chain (a wave's 64 lanes practically always hold a survivor in
+		// each of the NCH chains).  Further passes: a chain has a second survivor in some lane in one tile of eight, so a chain that
+		// is empty wave-wide is skipped (the ballots are the loop's exit test as well) instead of running its check for nobody.
+		uint32_t p[NCH];
+		int e[NCH];
+		bool hit[NCH];
+		auto check = [&](int c) {
+			p[c] = __builtin_ctz(m[c] | 0x80000000u);
+			e[c] = __popc(alignbit(D[c + 1], D[c], p[c]) ^ ac_lo)
+				+ __popc(alignbit(D[c + 2], D[c + 1], p[c]) ^ ac_hi);          // :433
+			hit[c] = m[c] != 0 && e[c] <= limit;
+			m[c] &= m[c] - 1;
+		};
+		{
 			uint32_t any = 0;
 #pragma unroll
 			for (int c = 0; c < NCH; c++)
 				any |= m[c];
-			if (!__ballot(any != 0))
-				break;
-			uint32_t p[NCH];
-			int e[NCH];
-			bool hit[NCH], anyhit = false;
+			if (__ballot(any != 0)) {
+				bool anyhit = false;
 #pragma unroll
-			for (int c = 0; c < NCH; c++) {
-				p[c] = __builtin_ctz(m[c] | 0x80000000u);
-				e[c] = __popc(alignbit(D[c + 1], D[c], p[c]) ^ ac_lo)
-					+ __popc(alignbit(D[c + 2], D[c + 1], p[c]) ^ ac_hi);          // :433
-				hit[c] = m[c] != 0 && e[c] <= limit;
-				anyhit |= hit[c];
-				m[c] &= m[c] - 1;
-			}
-			if (__ballot(anyhit)) {
+				for (int c = 0; c < NCH; c++) {
+					check(c);
+					anyhit |= hit[c];
+				}
+				if (__ballot(anyhit)) {
 #pragma unroll
-				for (int c = 0; c < NCH; c++)
-					stage(hit[c], this_stream, word0 * 64 + 32u * c + p[c], (uint32_t)e[c]);
+					for (int c = 0; c < NCH; c++)
+						stage(hit[c], this_stream, word0 * 64 + 32u * c + p[c], (uint32_t)e[c]);
+				}
+				for (;;) {
+					uint64_t live[NCH], anyl = 0;
+#pragma unroll
+					for (int c = 0; c < NCH; c++) {
+						live[c] = __ballot(m[c] != 0);
+						anyl |= live[c];
+					}
+					if (!anyl)
+						break;
+#pragma unroll
+					for (int c = 0; c < NCH; c++) {
+						if (!live[c])
+							continue;
+						check(c);
+						stage(hit[c], this_stream, word0 * 64 + 32u * c + p[c], (uint32_t)e[c]);
+					}
+				}
 			}
 		}
 		}
