@@ -652,7 +652,7 @@ __global__ __launch_bounds__(1024) void slot_place_kernel(const uint16_t *cnt, u
 		if (n == 0)
 			continue;
 		const uint32_t seg = wfirst + k * 64 + lane;
-		const uint64_t *src = slots + (uint64_t)seg * SLOT_N;
+		const uint64_t *src = slots + (uint64_t)seg * SLOT_N;    // (both slots of the lane's eight segments as 16-byte loads ahead of the prefixes: 94 against 77 us)
 		const uint32_t stream = seg / segs_per_stream;        // a slot holds what the segment does not say
 		const uint64_t seg_first = (uint64_t)(seg - stream * segs_per_stream) * seg_offsets;
 #pragma unroll
