@@ -787,3 +787,61 @@ def test_concurrent_drop_in_callers():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("lap", [bt.LAP_ANY, 0x9E8B33, 0x1E8B33])
+def test_hits_at_the_seams_of_lanes_segments_waves_and_tiles(lap):
+    """Sync words planted ON the boundaries of what the scan kernels hand out -- scan_known_lap_kernel (round 6): a lane's run of two
+    words (128 offsets), a 4096-offset segment, a wave's 128 words, a tile of 512 words; scan_slide_kernel: a word, a wave's 63 words,
+    a tile of 756 -- at the offsets right before, on and behind each boundary and with windows that straddle it, 0 .. 2 errors each,
+    both barker classes, in fourteen streams with a pitch (every boundary meets every delta); the plain and the ordered call (segment slots) against the oracle."""
+    lib = bt.lib()
+    olap = _libs.LAP_ANY if lap == bt.LAP_ANY else lap
+    rng = np.random.default_rng(77)
+    deltas = (-65, -64, -63, -33, -32, -31, -1, 0, 1, 31, 32, 33, 63, 64)
+    bounds = (1, 2, 63, 64, 126, 128, 189, 256, 512, 756, 1024, 1512)                 # in words
+    n_streams, nwords, pitch = len(deltas), 2 * 512 + 2 * 756 + 37, 2 * 512 + 2 * 756 + 64
+    nbits = nwords * 64 - 63 - 5
+    rows, want, planted = [], [], 0
+    for ch in range(n_streams):
+        words = synth.noise_words(900 + ch, 0, nwords)
+        sym = np.ascontiguousarray(synth.unpack_bits(words))
+        last = -1000
+        for j, b in enumerate(bounds):                          # stream ch: boundary j gets the delta (ch + 3 j) mod 14
+            off = b * 64 + deltas[(ch + 3 * j) % len(deltas)]
+            if off < 0 or off + 64 > len(sym) or off - last < 64 + 7:
+                continue
+            sw = synth.syncword(lap if lap != bt.LAP_ANY else int(rng.integers(0, 1 << 24)))
+            for e in rng.choice(57, size=(j + ch) % 3, replace=False):           # errors below the barker bits
+                sw ^= 1 << int(e)
+            sym[off:off + 64] = synth.bits_lsb(sw, 64)
+            last = off
+            planted += 1
+        words = synth.pack_bits(sym)
+        rows.append(np.concatenate([words, np.zeros(pitch - nwords, np.uint64)]))
+        want += [(ch, o, l, e) for (o, l, e) in _libs.orc_find_all(sym, nbits, olap, 2)]
+    assert planted >= 150 and len(want) >= planted
+    buf = np.concatenate(rows)
+    d_w = bt.DeviceBuffer(buf.nbytes).upload(buf)
+    cap = len(want) + 50
+    for ordered in (False, True):
+        d_h = bt.DeviceBuffer(cap * 16).zero()
+        d_c = bt.DeviceBuffer(16).zero()
+        if ordered:
+            sb = lib.btbbx_scan_ordered_scratch_bytes(nbits, n_streams, lap, cap)
+            d_s = bt.DeviceBuffer(sb)
+            bt.check(lib.btbbx_scan_ordered_device(d_w.ptr, nwords, pitch, n_streams, nbits, lap, 2, d_h.ptr, cap, d_c.ptr, d_s.ptr, sb, None))
+        else:
+            bt.check(lib.btbbx_scan_device(d_w.ptr, nwords, pitch, n_streams, nbits, lap, 2, d_h.ptr, cap, d_c.ptr, None))
+        bt.check(lib.btbbx_sync(None))
+        cnt = int(d_c.download(np.uint32, 4)[0])
+        got = d_h.download(bt.HIT_DTYPE, cap)[:min(cnt, cap)]
+        tup = [(int(h["stream"]), int(h["offset"]), int(h["lap"]), int(h["ac_errors"])) for h in got]
+        if ordered:
+            assert tup == want
+            d_s.free()
+        else:
+            assert sorted(tup) == want
+        d_h.free()
+        d_c.free()
+    d_w.free()
