@@ -1427,8 +1427,9 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 		};
 		auto lin_terms = [&](uint32_t L) {
 			uint32_t x = 0;
-#pragma unroll 1
-			for (int half = 0; half < 2; half++) {             // (one 16-byte row half at a time: VGPR ceiling)
+#pragma unroll
+			for (int half = 0; half < 2; half++) {             // (both 16-byte halves of the row asked for together: 115 VGPRs; one at a time -- rounds 4-6a --
+			                                                   //  was 1-2 % slower: 0.861 / 0.817 against 0.853 / 0.795 ms, profiles/r06_trials)
 				const uint4 q = reinterpret_cast<const uint4 *>(lin)[2 * L + half];
 				const uint32_t r[4] = {q.x, q.y, q.z, q.w};
 				const uint32_t sl = sel >> (8 * half);
