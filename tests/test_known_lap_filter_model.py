@@ -1,0 +1,96 @@
+"""The arithmetic of scan_known_lap_kernel's bit-sliced filter (libbtbb_amd/csrc/scan.hip, second half of round 6), modelled in numpy
+and held against its definition on the CPU -- what the GPU tests can only observe as "same hit list":
+
+  * the filter counts mismatches in sync-word bits 24..31 and 56..63 (sixteen planes; twelve -- 28..31 and 56..63 -- for limits 0 / 1);
+  * plane j of a dword pair (hi : lo) = the funnel shift of the pair by 24 + j (v_alignbit); for the 32 offsets p of a half that starts
+    at dword k it is window bit 24 + j taken from the pair (k + 1 : k) and window bit 56 + j taken from the pair (k + 2 : k + 1) -- so the
+    UPPER planes of half k are the LOWER planes of half k + 1 (the kernel computes every set once: pair_planes), along a lane's run of
+    two consecutive words + the word behind them (six dwords, four halves, five plane sets);
+  * count <= limit over those planes is a necessary condition of find_known_lap's popcount(window ^ syncword) <= limit
+    (bluetooth_packet.c:433), never a sufficient one: every oracle hit passes the model, the model passes more."""
+import numpy as np
+
+from _libs import LAP_ANY, oracle, orc_find_all, seed
+from libbtbb_amd import synth
+
+M32 = 0xFFFFFFFF
+
+
+def _alignbit(hi, lo, sh):
+    return ((((hi & M32) << 32) | (lo & M32)) >> sh) & M32
+
+
+def _pair_planes(lo, hi):
+    return [_alignbit(hi, lo, 24 + j) for j in range(8)]
+
+
+def _count_le(lowp, highp, sync, limit, first_low):
+    """32-bit mask of the offsets of a half whose mismatch count in the chosen sync-word bits is <= limit"""
+    out = 0
+    for p in range(32):
+        n = 0
+        for j in range(first_low, 8):
+            n += ((lowp[j] >> p) & 1) ^ ((sync >> (24 + j)) & 1)
+        for j in range(8):
+            n += ((highp[j] >> p) & 1) ^ ((sync >> (56 + j)) & 1)
+        out |= (1 if n <= limit else 0) << p
+    return out
+
+
+def _model_survivors(dwords, sync, limit):
+    """the kernel's filter over a stream given as dwords: lanes own runs of two words (four halves), the planes of a pair are
+    computed once and used by both halves they belong to -> set of surviving offsets"""
+    first_low = 0 if limit >= 2 else 4
+    surv = set()
+    n_halves = len(dwords) - 2
+    for run in range(0, n_halves, 4):                       # a lane's run: halves run .. run + 3, dwords run .. run + 5
+        D = [dwords[run + k] if run + k < len(dwords) else 0 for k in range(6)]
+        sets = [_pair_planes(D[k], D[k + 1]) for k in range(5)]          # five plane sets for four halves
+        for c in range(4):
+            if run + c >= n_halves:
+                break
+            m = _count_le(sets[c], sets[c + 1], sync, limit, first_low)
+            surv |= {32 * (run + c) + p for p in range(32) if (m >> p) & 1}
+    return surv
+
+
+def test_the_shared_planes_are_the_window_bits_they_stand_for():
+    rng = np.random.default_rng(seed(5))
+    d = [int(x) for x in rng.integers(0, 1 << 32, 7, dtype=np.uint64)]
+    stream = 0
+    for k, v in enumerate(d):
+        stream |= v << (32 * k)
+    for k in range(4):                                       # half k: offsets 32 k .. 32 k + 31
+        low, high = _pair_planes(d[k], d[k + 1]), _pair_planes(d[k + 1], d[k + 2])
+        for p in (0, 1, 7, 8, 15, 24, 30, 31):
+            window = (stream >> (32 * k + p)) & ((1 << 64) - 1)
+            for j in range(8):
+                assert (low[j] >> p) & 1 == (window >> (24 + j)) & 1
+                assert (high[j] >> p) & 1 == (window >> (56 + j)) & 1
+    # (so the set of the pair (k + 2 : k + 1) serves half k as its upper planes and half k + 1 as its lower ones: checked above for both)
+
+
+def test_filter_model_is_a_necessary_condition_and_equals_its_definition():
+    orc = oracle()
+    orc.orc_reset_syndrome_map()
+    orc.orc_init(2)
+    for lap in (0x9E8B33, 0x1E8B33):
+        sync = synth.syncword(lap)
+        words, _ = synth.make_stream(seed(77), 512, stride=512, lap=lap)
+        sym = np.ascontiguousarray(synth.unpack_bits(words))
+        dwords = [int(x) for x in words.view(np.uint32)]
+        n = len(sym) - 63
+        for limit in (0, 1, 2, 3):
+            model = _model_survivors(dwords, sync, limit)
+            # the definition: mismatches of the window in the chosen bits
+            chosen = [b for b in range(64) if (24 + (0 if limit >= 2 else 4) <= b <= 31) or b >= 56]
+            sbits = np.array([(sync >> b) & 1 for b in range(64)], dtype=np.uint8)
+            cnt = np.zeros(n, dtype=np.int32)
+            for b in chosen:
+                cnt += sym[b:b + n] != sbits[b]
+            want = set(np.nonzero(cnt <= limit)[0].tolist())
+            assert {o for o in model if o < n} == want
+            hits = {o for (o, _, _) in orc_find_all(sym, n, lap, limit)}
+            assert hits <= want and len(hits) >= 10
+            if limit >= 2:
+                assert len(want) < n // 50                                # sixteen planes: a sparse survivor set
