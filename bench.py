@@ -309,7 +309,10 @@ def valu_block(v, kernel_ms):
     return {"kernel": v.get("kernel"), "insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
             "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kernel_ms * 1e-3), 4),
             "salu_per_valu": round((v.get("salu_insts_per_launch") or 0) / v["insts_per_launch"], 3),
-            "wait_any_frac": v.get("wait_any_frac")}
+            "wait_any_frac": v.get("wait_any_frac"),
+            # measured in the same PMC run (tools/pmc_pipe.sh): SQ_THREAD_CYCLES_VALU against SQ_CYCLES -- the share of the SIMDs' cycles
+            # the vector pipe was busy, and its cycles per vector instruction
+            "pipe_busy_frac": v.get("pipe_busy_frac"), "pipe_cycles_per_inst": v.get("pipe_cycles_per_inst")}
 
 
 def secondary(bt, lib, dev, cur, hs, cpu, with_cpu, only=None):
@@ -775,7 +778,8 @@ def ordered_headline(bt, lib, dev, cur, hs, stream, nwords, nbits, hits_t, cnt_t
         "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(alg),
                      "kernel": "scan_slide_kernel<ORD> + slot_*", "traffic": secondary_traffic("lap_any_4gib_ordered")[0],
-                     "traffic_source": secondary_traffic("lap_any_4gib_ordered")[1]},
+                     "traffic_source": secondary_traffic("lap_any_4gib_ordered")[1],
+                     "valu": valu_block(secondary_traffic("lap_any_4gib_ordered")[2], ms)},
         "parity": bool(increasing and same), "strictly_increasing": increasing, "equals_sorted_unordered_list": same,
     }
 
@@ -957,7 +961,8 @@ def main():
                     # instruction / (SIMDs x clock) / kernel time (instruction count from the PMC run named in traffic_source)
                     busy_s = v["insts_per_launch"] * v["cycles_per_inst"] / (v["simds"] * v["clock_ghz"] * 1e9)
                     valu = {"insts_per_launch": int(v["insts_per_launch"]), "cycles_per_inst": v["cycles_per_inst"],
-                            "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kern_ms * 1e-3), 4)}
+                            "issue_ms": round(busy_s * 1e3, 4), "frac": round(busy_s / (kern_ms * 1e-3), 4),
+                            "pipe_busy_frac": v.get("pipe_busy_frac"), "pipe_cycles_per_inst": v.get("pipe_cycles_per_inst")}
                     # ... and how far the instruction stream itself is from the fewest vector instructions ANY exact filter of
                     # this shape needs per 64-bit stream word (NOTEBOOK.md 6.4: 7 barker planes + their adder tree for both halves
                     # 30, the sliding check stream 30, eight survivors x eight instructions since round 5: 64):

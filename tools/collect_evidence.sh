@@ -8,6 +8,7 @@
 #   pmc_scan.json     separate --pmc passes (never combined with traces) over the headline loop: FETCH_SIZE, WRITE_SIZE, SQ_*
 #   pmc_sec_<line>.json  the same for ONE line of the secondary block at a time (bench.py --only-secondary <line>): a kernel's
 #                     mean per launch then belongs to one workload (the two config-3 captures share their kernels)
+#   pmc_pipe_<line>.json  SQ_THREAD_CYCLES_VALU / SQ_CYCLES per kernel: how busy the vector pipe was (tools/pmc_pipe.sh)
 #   init_sweep.json, multistream.txt, decode_by_type.txt
 out=${1:-gpurun_out/evidence}
 mkdir -p $out
@@ -27,6 +28,7 @@ for line in lap_any_4gib_ordered lap_any_4gib_init4 known_lap_79ch_chain_full_pa
     -- python bench.py --steps 2 --warmup 1 --no-cpu --only-secondary $line > $out/pmc_sec_$line.json 2> $out/pmc2.err
   rm -rf $out/pmc2
 done
+tools/pmc_pipe.sh $out
 timeout 120 python tools/init_sweep.py 2>/dev/null | tail -1 > $out/init_sweep.json
 timeout 120 python tools/multistream_time.py 2>/dev/null > $out/multistream.txt
 timeout 200 python tools/decode_time.py > $out/decode_by_type.txt 2>/dev/null

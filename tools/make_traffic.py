@@ -20,6 +20,25 @@ def hbm(entry):
     return (2 * entry["FETCH_SIZE"]["mean_per_launch"] + entry["WRITE_SIZE"]["mean_per_launch"]) * 1024
 
 
+def pipe(path, kernel_substr):
+    """measured occupancy of the vector pipe by the kernel whose name contains kernel_substr (tools/pmc_pipe.sh): SQ_THREAD_CYCLES_VALU
+    counts lane-quad-cycles, SQ_CYCLES is summed over the 32 shader engines -> fraction of the 1024 SIMDs' cycles, cycles per instruction"""
+    try:
+        e = json.load(open(path))
+    except Exception:
+        return {}
+    ks = [k for k in e if kernel_substr in k and "SQ_THREAD_CYCLES_VALU" in e[k] and "SQ_CYCLES" in e[k]]
+    if not ks:
+        return {}
+    k = max(ks, key=lambda k: e[k]["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"])
+    busy = e[k]["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / 64.0 * 4.0
+    cyc = e[k]["SQ_CYCLES"]["mean_per_launch"] / 32.0
+    r = {"pipe_busy_frac": round(busy / 1024.0 / cyc, 3)}
+    if e[k].get("SQ_INSTS_VALU"):
+        r["pipe_cycles_per_inst"] = round(busy / e[k]["SQ_INSTS_VALU"]["mean_per_launch"], 2)
+    return r
+
+
 pmc = json.load(open(os.path.join(d, "pmc_scan.json")))
 name = [k for k in pmc if "scan_slide_kernel" in k][0]
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
@@ -38,7 +57,8 @@ json.dump({
     "valu": {"insts_per_launch": pmc[name].get("SQ_INSTS_VALU", {}).get("mean_per_launch"), "cycles_per_inst": 3.1,
              "simds": 1024, "clock_ghz": 2.4,
              "lds_insts_per_launch": pmc[name].get("SQ_INSTS_LDS", {}).get("mean_per_launch"),
-             "salu_insts_per_launch": pmc[name].get("SQ_INSTS_SALU", {}).get("mean_per_launch")},
+             "salu_insts_per_launch": pmc[name].get("SQ_INSTS_SALU", {}).get("mean_per_launch"),
+             **pipe(os.path.join(d, "pmc_pipe_headline.json"), "scan_slide_kernel")},
 }, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print("traffic.json: %.3f GB per launch = %.3f x algorithmic" % (b / 1e9, b / alg))
 
@@ -75,6 +95,7 @@ for line, keys in (("lap_any_4gib_ordered", ("scan_slide_kernel<SlideStd, 2, fal
                              "simds": 1024, "clock_ghz": 2.4,
                              "salu_insts_per_launch": e.get("SQ_INSTS_SALU", {}).get("mean_per_launch"),
                              "lds_insts_per_launch": e.get("SQ_INSTS_LDS", {}).get("mean_per_launch"),
-                             "wait_any_frac": round(e["SQ_WAIT_ANY"]["mean_per_launch"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None}
+                             "wait_any_frac": round(e["SQ_WAIT_ANY"]["mean_per_launch"] / wc, 3) if wc and e.get("SQ_WAIT_ANY") else None,
+                             **pipe(os.path.join(d, "pmc_pipe_%s.json" % line), DOMINANT[line])}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_secondary.json"), "w"), indent=1)
 print("traffic_secondary.json:", {k: v["ratio_to_algorithmic"] for k, v in out.items() if isinstance(v, dict)})
