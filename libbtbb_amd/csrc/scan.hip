@@ -153,7 +153,17 @@ __device__ __forceinline__ uint64_t load_word(const uint64_t *base, uint64_t j, 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 __device__ __forceinline__ uint32_t lds_ld(uint32_t byte_off) { return *reinterpret_cast<lds_u32_t *>(byte_off); }
 __device__ __forceinline__ void lds_st(uint32_t byte_off, uint32_t v) { *reinterpret_cast<lds_u32_t *>(byte_off) = v; }
-// a candidate record (position code, 64-bit window, pad) moves as one 16-byte DS access
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t byte_off) { return *reinterpret_cast<lds_u16_t *>(byte_off); }
+// lanes whose 16-bit entry x, shifted LEFT by sh & 15, is negative as a 16-bit number: the fast-rate left shift (see
+// scan_slide_kernel) and the 16-bit compare, both as written here (from C the compiler widens the test to v_bfe_u32 + v_cmp_ne_u32)
+__device__ __forceinline__ uint64_t sign16_after_shl(uint32_t x, uint32_t sh)
+{
+	uint32_t r;
+	uint64_t m;
+	asm("v_lshlrev_b16 %1, %2, %3\n\tv_cmp_gt_i16_e64 %0, 0, %1" : "=s"(m), "=&v"(r) : "v"(sh), "v"(x));
+	return m;
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
 __device__ __forceinline__ u32x4 lds_ld4(uint32_t byte_off) { return *reinterpret_cast<lds_u32x4_t *>(byte_off); }
@@ -843,14 +853,18 @@ void scan_slide_kernel(ScanArgs a)
 		n_mine = first_tile < a.n_tiles ? (uint32_t)((a.n_tiles - first_tile + tile_step - 1) / tile_step) : 0;
 	}
 
-	{	// candidate set -> LDS byte 0, 16 bytes per lane per step, every word bit-reversed: the member bit of index i is bit
-		// 31 - (i & 31), so that a LEFT shift by i brings it to the sign bit -- "member" is then one signed compare, whose
-		// result (a lane mask in scalar registers) is also the ballot the candidate path needs
+	{	// candidate set -> LDS byte 0, 16 bytes per lane per step, as 16-bit entries, every entry bit-reversed: the member bit of
+		// index i is bit 15 - (i & 15) of entry i >> 4, so that a LEFT shift by i brings it to the entry's sign bit -- "member" is
+		// then one signed 16-bit compare, whose result (a lane mask in scalar registers) is also the ballot the candidate path
+		// needs.  Sixteen bits, not thirty-two (rounds 5-6a): on gfx950 v_lshlrev_b32 issues at the slow rate (4.1 cycles per wave,
+		// like v_alignbit) while v_lshlrev_b16 and the RIGHT shifts issue at the fast one (2.3-2.5; tools/valu_rate.hip,
+		// profiles/r06_scan/valu_rate_shifts.txt) -- one left shift per survivor.
 		const uint4 *src = reinterpret_cast<const uint4 *>(CFG::LEVEL2 ? a.t.slide4_bitmap : a.t.slide_bitmap);
 		uint4 *dst = reinterpret_cast<uint4 *>(lds);
+		auto rev16 = [](uint32_t x) { const uint32_t r = __brev(x); return (r >> 16) | (r << 16); };   // both halves reversed in place
 		for (uint32_t i = tid; i < SET_WORDS / 4; i += THREADS) {
 			const uint4 v = src[i];
-			dst[i] = make_uint4(__brev(v.x), __brev(v.y), __brev(v.z), __brev(v.w));
+			dst[i] = make_uint4(rev16(v.x), rev16(v.y), rev16(v.z), rev16(v.w));
 		}
 	}
 	__syncthreads();
@@ -1196,11 +1210,11 @@ void scan_slide_kernel(ScanArgs a)
 			m[u][h] >>= p & 31;
 			C[u][h] >>= p & 63;
 			g.v[u][h] = (uint32_t)C[u][h];
-			g.bw[u][h] = lds_ld((g.v[u][h] >> 3) & ((SET_WORDS - 1) << 2));
+			g.bw[u][h] = lds_ld16((g.v[u][h] >> 3) & (SET_BYTES - 2));
 			m[u][h] &= ~1u;
 		};
 		auto member = [&](int u, int h, const Stage &g) {   // lanes whose index is in the set (the compare's own mask: no ballot)
-			return __ballot((int32_t)(g.bw[u][h] << (g.v[u][h] & 31)) < 0);
+			return sign16_after_shl(g.bw[u][h], g.v[u][h]);
 		};
 		// Two-level form: a third of the survivors are members of the LDS set; they alone (exec mask) look their SLIDE4B_BITS
 		// positions of the second check stream up in the set in L2 -- one dword each, the four chains' loads in flight together.
@@ -1247,6 +1261,9 @@ void scan_slide_kernel(ScanArgs a)
 #pragma unroll
 				for (int h = 0; h < 2; h++)
 					step(u, h, g);
+			// (the compiler knows nothing about the latency of the shift and compare written as asm in member(): without this it
+			// slips each set read behind the previous chain's compare and waits for the reads one at a time)
+			__builtin_amdgcn_sched_barrier(0);
 			uint64_t cms[TILES][2], any = 0;
 #pragma unroll
 			for (int u = 0; u < TILES; u++)

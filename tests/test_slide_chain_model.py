@@ -7,7 +7,8 @@ against the straightforward form on the CPU -- what the GPU tests can only obser
   * an exhausted chain shifts itself out (ffbl of 0 = -1: shift amounts 31 / 63) and indexes 0 or 1 ever after -- and 0
     and 1 are members of no candidate set (context.cpp refuses a table set where they are), so no "this lane has a
     survivor" term is needed;
-  * the set's words bit-reversed, membership = the sign of (word << (index & 31)).
+  * the set as 16-bit entries, each bit-reversed, membership = the 16-bit sign of (entry << (index & 15)) -- sixteen bits since
+    the third session of round 6: v_lshlrev_b16 issues at the fast rate on gfx950, v_lshlrev_b32 at the slow one.
 
 Also the property trials_linear_kernel's arithmetic trial order rests on: the four bits that whiten a header's type field
 take every value for exactly four of the 64 CLK1-6 candidates (packet.hip checks the same on the table it uploads)."""
@@ -74,13 +75,15 @@ def test_indices_0_and_1_are_in_no_candidate_set():
         assert members > 0 and (words[0] & 3) == 0, (n, members, hex(words[0]))
 
 
-def test_membership_as_the_sign_of_a_left_shift_of_the_bit_reversed_word():
+def test_membership_as_the_sign_of_a_left_shift_of_the_bit_reversed_entry():
     import libbtbb_amd as bt
     lib = bt.lib()
     words = (C.c_uint32 * (1 << 14))()
     assert lib.btbbx_slide_set(2, words, None) == 1585
     plain = np.frombuffer(words, dtype=np.uint32)
-    rev = np.array([_brev32(int(w)) for w in plain], dtype=np.uint64)
+    # the kernel's copy-in: every word bit-reversed, then its halves swapped = both 16-bit halves reversed in place
+    lds = np.array([((_brev32(int(w)) >> 16) | (_brev32(int(w)) << 16)) & 0xFFFFFFFF for w in plain], dtype=np.uint32)
+    entries = lds.view(np.uint16)                             # little-endian: entry k = half k & 1 of word k >> 1
     rng = np.random.default_rng(seed(5101))
     members = [i for i in range(1 << 19) if (int(plain[i >> 5]) >> (i & 31)) & 1]
     assert len(members) == 1585
@@ -88,8 +91,10 @@ def test_membership_as_the_sign_of_a_left_shift_of_the_bit_reversed_word():
     for idx in probe:
         junk = int(rng.integers(0, 1 << 13)) << 19            # the register holds check bits above the index too
         v = idx | junk
-        word = int(rev[(v >> 5) & 0x3FFF])                    # the kernel's address: (v >> 3) & 0xfffc, in words
-        sign = ((word << (v & 31)) >> 31) & 1
+        byte_off = (v >> 3) & 0xFFFE                          # the kernel's address (SET_BYTES - 2 = 0xfffe)
+        assert byte_off % 2 == 0
+        entry = int(entries[byte_off >> 1])
+        sign = (((entry << (v & 15)) & 0xFFFF) >> 15) & 1     # v_lshlrev_b16 takes the low four bits of v; v_cmp_gt_i16 0, ...
         assert sign == ((int(plain[idx >> 5]) >> (idx & 31)) & 1), idx
 
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void name(uint32_t *out, uint32_t seed)      
 		_Pragma("unroll") for (int u = 0; u < UNROLL / 8; u++)                              \
 			asm volatile(i0 "\n" i1 "\n" i2 "\n" i3 "\n" i4 "\n" i5 "\n" i6 "\n" i7 "\n" : : :    \
 				     "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
-				     "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27");                     \
+				     "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "vcc", "s20", "s21", "s22", "s23");  \
 	}                                                                                       \
 	asm volatile("v_xor_b32 %0, %0, v20\n v_xor_b32 %0, %0, v27" : "+v"(acc) : : "v20", "v27"); \
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                       \
@@ -179,6 +179,62 @@ BANK_KERNEL(k_alignbitc_b00, "v_alignbit_b32 v20, v8, v12, 7", "v_alignbit_b32 v
 BANK_KERNEL(k_lshr64_reg, "v_lshrrev_b64 v[20:21], v8, v[12:13]", "v_lshrrev_b64 v[22:23], v9, v[14:15]", "v_lshrrev_b64 v[24:25], v10, v[16:17]",
 	    "v_lshrrev_b64 v[26:27], v11, v[18:19]", "v_lshrrev_b64 v[20:21], v8, v[12:13]", "v_lshrrev_b64 v[22:23], v9, v[14:15]",
 	    "v_lshrrev_b64 v[24:25], v10, v[16:17]", "v_lshrrev_b64 v[26:27], v11, v[18:19]")
+
+
+// ---- round 6, third session: the 16-bit and packed forms a 16-bit-entry set would need, and a few more plain ones
+KERNEL(k_lshl, OP8("v_lshlrev_b32"))
+KERNEL(k_sub, OP8("v_sub_u32"))
+KERNEL(k_min, OP8("v_min_u32"))
+KERNEL(k_ashr, OP8("v_ashrrev_i32"))
+KERNEL(k_mul24, OP8("v_mul_u32_u24"))
+KERNEL(k_not, OP8_1("v_not_b32"))
+KERNEL(k_bfrev, OP8_1("v_bfrev_b32"))
+KERNEL(k_lshl16, OP8("v_lshlrev_b16"))
+KERNEL(k_add16, OP8("v_add_u16"))
+#define OP8_PK(ins, mods) asm volatile(ins " %0, %8, %0 " mods "\n" ins " %1, %8, %1 " mods "\n" ins " %2, %8, %2 " mods "\n" ins " %3, %8, %3 " mods "\n" \
+	ins " %4, %8, %4 " mods "\n" ins " %5, %8, %5 " mods "\n" ins " %6, %8, %6 " mods "\n" ins " %7, %8, %7 " mods "\n" \
+	: "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(seed));
+KERNEL(k_pk_lshl16, OP8_PK("v_pk_lshlrev_b16", ""))
+KERNEL(k_pk_lshl16_sel, OP8_PK("v_pk_lshlrev_b16", "op_sel:[1,0] op_sel_hi:[1,0]"))
+KERNEL(k_pk_add16, OP8_PK("v_pk_add_u16", ""))
+#define CMP8X(ins, dst) asm volatile(ins " " dst ", 0, %0\n " ins " " dst ", 0, %1\n " ins " " dst ", 0, %2\n " ins " " dst ", 0, %3\n" \
+	ins " " dst ", 0, %4\n " ins " " dst ", 0, %5\n " ins " " dst ", 0, %6\n " ins " " dst ", 0, %7\n" \
+	: : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h) : "vcc", "s20", "s21");
+KERNEL(k_cmp16_vcc, CMP8X("v_cmp_gt_i16", "vcc"))
+KERNEL(k_cmp16_sgpr, CMP8X("v_cmp_gt_i16", "s[20:21]"))
+KERNEL(k_cmpne_vcc, CMP8X("v_cmp_ne_u32", "vcc"))
+
+
+// v_cndmask_b32: the chained form above reads 23 cycles; these say whether that is the instruction or the probe
+BANK_KERNEL(k_cndmask_indep, "v_cndmask_b32 v20, v8, v9, vcc", "v_cndmask_b32 v21, v9, v10, vcc", "v_cndmask_b32 v22, v10, v11, vcc",
+	    "v_cndmask_b32 v23, v11, v12, vcc", "v_cndmask_b32 v24, v12, v13, vcc", "v_cndmask_b32 v25, v13, v14, vcc",
+	    "v_cndmask_b32 v26, v14, v15, vcc", "v_cndmask_b32 v27, v15, v16, vcc")
+BANK_KERNEL(k_cndmask_e64, "v_cndmask_b32_e64 v20, v8, v9, s[20:21]", "v_cndmask_b32_e64 v21, v9, v10, s[20:21]", "v_cndmask_b32_e64 v22, v10, v11, s[20:21]",
+	    "v_cndmask_b32_e64 v23, v11, v12, s[20:21]", "v_cndmask_b32_e64 v24, v12, v13, s[20:21]", "v_cndmask_b32_e64 v25, v13, v14, s[20:21]",
+	    "v_cndmask_b32_e64 v26, v14, v15, s[20:21]", "v_cndmask_b32_e64 v27, v15, v16, s[20:21]")
+BANK_KERNEL(k_cndmask_const, "v_cndmask_b32_e64 v20, 0, 1, s[20:21]", "v_cndmask_b32_e64 v21, 0, 1, s[20:21]", "v_cndmask_b32_e64 v22, 0, 1, s[20:21]",
+	    "v_cndmask_b32_e64 v23, 0, 1, s[20:21]", "v_cndmask_b32_e64 v24, 0, 1, s[20:21]", "v_cndmask_b32_e64 v25, 0, 1, s[20:21]",
+	    "v_cndmask_b32_e64 v26, 0, 1, s[20:21]", "v_cndmask_b32_e64 v27, 0, 1, s[20:21]")
+BANK_KERNEL(k_bitop3_select, "v_bitop3_b32 v20, v8, v9, v10 bitop3:0xca", "v_bitop3_b32 v21, v9, v10, v11 bitop3:0xca", "v_bitop3_b32 v22, v10, v11, v12 bitop3:0xca",
+	    "v_bitop3_b32 v23, v11, v12, v13 bitop3:0xca", "v_bitop3_b32 v24, v12, v13, v14 bitop3:0xca", "v_bitop3_b32 v25, v13, v14, v15 bitop3:0xca",
+	    "v_bitop3_b32 v26, v14, v15, v16 bitop3:0xca", "v_bitop3_b32 v27, v15, v16, v17 bitop3:0xca")
+BANK_KERNEL(k_lshl_const, "v_lshlrev_b32 v20, 2, v8", "v_lshlrev_b32 v21, 2, v9", "v_lshlrev_b32 v22, 2, v10", "v_lshlrev_b32 v23, 2, v11",
+	    "v_lshlrev_b32 v24, 2, v12", "v_lshlrev_b32 v25, 2, v13", "v_lshlrev_b32 v26, 2, v14", "v_lshlrev_b32 v27, 2, v15")
+BANK_KERNEL(k_lshr_const, "v_lshrrev_b32 v20, 2, v8", "v_lshrrev_b32 v21, 2, v9", "v_lshrrev_b32 v22, 2, v10", "v_lshrrev_b32 v23, 2, v11",
+	    "v_lshrrev_b32 v24, 2, v12", "v_lshrrev_b32 v25, 2, v13", "v_lshrrev_b32 v26, 2, v14", "v_lshrrev_b32 v27, 2, v15")
+BANK_KERNEL(k_lshl_add_const, "v_lshl_add_u32 v20, v8, 2, v9", "v_lshl_add_u32 v21, v9, 2, v10", "v_lshl_add_u32 v22, v10, 2, v11", "v_lshl_add_u32 v23, v11, 2, v12",
+	    "v_lshl_add_u32 v24, v12, 2, v13", "v_lshl_add_u32 v25, v13, 2, v14", "v_lshl_add_u32 v26, v14, 2, v15", "v_lshl_add_u32 v27, v15, 2, v16")
+BANK_KERNEL(k_mul_u24_const, "v_mul_u32_u24 v20, 4, v8", "v_mul_u32_u24 v21, 4, v9", "v_mul_u32_u24 v22, 4, v10", "v_mul_u32_u24 v23, 4, v11",
+	    "v_mul_u32_u24 v24, 4, v12", "v_mul_u32_u24 v25, 4, v13", "v_mul_u32_u24 v26, 4, v14", "v_mul_u32_u24 v27, 4, v15")
+
+
+// compare + select pairs as the compiler writes them: through vcc (VOP2 select) and through an SGPR pair (VOP3 select)
+BANK_KERNEL(k_cmp_sel_vcc, "v_cmp_gt_u32 vcc, v8, v9", "v_cndmask_b32 v20, v10, v11, vcc", "v_cmp_gt_u32 vcc, v12, v13", "v_cndmask_b32 v21, v14, v15, vcc",
+	    "v_cmp_gt_u32 vcc, v9, v10", "v_cndmask_b32 v22, v11, v12, vcc", "v_cmp_gt_u32 vcc, v13, v14", "v_cndmask_b32 v23, v15, v16, vcc")
+BANK_KERNEL(k_cmp_sel_sgpr, "v_cmp_gt_u32 s[20:21], v8, v9", "v_cndmask_b32_e64 v20, v10, v11, s[20:21]", "v_cmp_gt_u32 s[22:23], v12, v13", "v_cndmask_b32_e64 v21, v14, v15, s[22:23]",
+	    "v_cmp_gt_u32 s[20:21], v9, v10", "v_cndmask_b32_e64 v22, v11, v12, s[20:21]", "v_cmp_gt_u32 s[22:23], v13, v14", "v_cndmask_b32_e64 v23, v15, v16, s[22:23]")
+BANK_KERNEL(k_addc_vcc, "v_add_co_u32 v20, vcc, v8, v9", "v_addc_co_u32 v21, vcc, v10, v11, vcc", "v_add_co_u32 v22, vcc, v12, v13", "v_addc_co_u32 v23, vcc, v14, v15, vcc",
+	    "v_add_co_u32 v24, vcc, v9, v10", "v_addc_co_u32 v25, vcc, v11, v12, vcc", "v_add_co_u32 v26, vcc, v13, v14", "v_addc_co_u32 v27, vcc, v15, v16, vcc")
 
 template <typename K>
 static void run(const char *name, K kernel, uint32_t *d_out, int waves_per_simd)
@@ -251,6 +307,32 @@ int main()
 		run("alignbit const banks 0,1", k_alignbitc_b01, d_out, w);
 		run("alignbit const banks 0,0", k_alignbitc_b00, d_out, w);
 		run("lshrrev_b64 by vgpr", k_lshr64_reg, d_out, w);
+		run("v_lshlrev_b32", k_lshl, d_out, w);
+		run("v_sub_u32", k_sub, d_out, w);
+		run("v_min_u32", k_min, d_out, w);
+		run("v_ashrrev_i32", k_ashr, d_out, w);
+		run("v_mul_u32_u24", k_mul24, d_out, w);
+		run("v_not_b32", k_not, d_out, w);
+		run("v_bfrev_b32", k_bfrev, d_out, w);
+		run("v_lshlrev_b16", k_lshl16, d_out, w);
+		run("v_add_u16", k_add16, d_out, w);
+		run("v_pk_lshlrev_b16", k_pk_lshl16, d_out, w);
+		run("v_pk_lshlrev_b16 op_sel", k_pk_lshl16_sel, d_out, w);
+		run("v_pk_add_u16", k_pk_add16, d_out, w);
+		run("v_cmp_gt_i16 -> vcc", k_cmp16_vcc, d_out, w);
+		run("v_cmp_gt_i16 -> sgpr pair", k_cmp16_sgpr, d_out, w);
+		run("v_cmp_ne_u32 -> vcc", k_cmpne_vcc, d_out, w);
+		run("v_cndmask e32 independent", k_cndmask_indep, d_out, w);
+		run("v_cndmask e64 sgpr pair", k_cndmask_e64, d_out, w);
+		run("v_cndmask e64 0,1", k_cndmask_const, d_out, w);
+		run("v_bitop3 select (0xca)", k_bitop3_select, d_out, w);
+		run("v_lshlrev_b32 const", k_lshl_const, d_out, w);
+		run("v_lshrrev_b32 const", k_lshr_const, d_out, w);
+		run("v_lshl_add_u32 const", k_lshl_add_const, d_out, w);
+		run("v_mul_u32_u24 const", k_mul_u24_const, d_out, w);
+		run("cmp+cndmask via vcc", k_cmp_sel_vcc, d_out, w);
+		run("cmp+cndmask via sgpr pair", k_cmp_sel_sgpr, d_out, w);
+		run("add_co+addc via vcc", k_addc_vcc, d_out, w);
 	}
 	return 0;
 }
