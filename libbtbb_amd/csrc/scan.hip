@@ -16,8 +16,8 @@
 //      window; 19 consecutive bits of the check stream at a survivor's offset are its candidate index.  A chain of 32
 //      offsets is a pair of shift registers (survivor mask, check bits) moved down to the survivor in hand, so the
 //      index is the low 19 bits: ONE read of a 2^19-bit set in LDS per survivor (the set = every index a window the
-//      reference accepts can have: gen_syndrome :147-159 and the map of :161-185 are linear in the same code; its
-//      words lie bit-reversed, membership is one signed compare).  0.30 % pass.
+//      reference accepts can have: gen_syndrome :147-159 and the map of :161-185 are linear in the same code; it lies
+//      there as bit-reversed 16-bit entries, membership is one fast-rate left shift and one signed compare).  0.30 % pass.
 //   3. candidates go straight to a per-wave LDS ring and are verified up to 64 at a time with the
 //      exact reference rule: full 34-bit syndrome, open-addressing lookup of the
 //      error pattern, popcount <= max_ac_errors, LAP from the corrected word
