@@ -168,6 +168,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
 __device__ __forceinline__ u32x4 lds_ld4(uint32_t byte_off) { return *reinterpret_cast<lds_u32x4_t *>(byte_off); }
 __device__ __forceinline__ void lds_st4(uint32_t byte_off, u32x4 v) { *reinterpret_cast<lds_u32x4_t *>(byte_off) = v; }
+// a ring record as four dword stores (the compiler pairs them into two ds_write2_b32): its dwords come from registers that
+// are not neighbours, and one 16-byte store first copies them into four that are -- vector instructions of a one-lane event
+__device__ __forceinline__ void lds_st_rec(uint32_t byte_off, u32x4 v)
+{
+	lds_st(byte_off, v.x);
+	lds_st(byte_off + 4u, v.y);
+	lds_st(byte_off + 8u, v.z);
+	lds_st(byte_off + 12u, v.w);
+}
 
 // w = the 64-symbol window at `offset` (the kernel keeps it with the candidate: by the time a
 // batch is verified the stream words have long left the L2, and re-reading them cost 40 % extra
@@ -1180,12 +1189,12 @@ void scan_slide_kernel(ScanArgs a)
 						const u32x4 rec = {code, d[u][h], d[u][h + 1], d[u][h + 2]};
 						if (in_wave == 1 && room) {
 							// one candidate in the wave (nine events in ten): its slot is the ring tail, no ranking
-							lds_st4(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
+							lds_st_rec(ring_off + CAND_BYTES * (q_tail & (RING - 1)), rec);
 						} else {
 							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32),
 									__builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0));
 							if (rank < room) {
-								lds_st4(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
+								lds_st_rec(ring_off + CAND_BYTES * ((q_tail + rank) & (RING - 1)), rec);
 							} else {
 								uint32_t stream, lap, nerr, cold = code;
 								asm volatile("" : "+v"(cold));      // keeps the tile -> stream division of this cold path out of every trip
