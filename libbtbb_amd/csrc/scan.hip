@@ -835,6 +835,12 @@ void scan_slide_kernel(ScanArgs a)
 	if (a.gate && *a.gate == 0)
 		return;
 	constexpr uint32_t RING = SlideGeom<CFG>::RING;
+	// ABS (third session of round 6, the one-level form): a chain is walked by ABSOLUTE positions -- p = v_ffbl of what is left of
+	// its mask, index = the untouched 64-bit check register >> p, mask &= mask - 1 -- instead of the pair of shift registers
+	// below.  The same instructions per survivor (v_add + v_and for v_lshrrev + v_and), but no marker to plant per chain and trip,
+	// no v_ffbh per candidate event (p IS the offset) and nothing loop-carried but the mask: 2.893 -> 2.879 ms over six
+	// alternating pairs (profiles/r06_shift).  The two-level form keeps the shift registers: its events run a pass behind.
+	constexpr bool ABS = !CFG::LEVEL2;
 	constexpr uint32_t THREADS = CFG::THREADS, SET_WORDS = SlideGeom<CFG>::SET_WORDS, SET_BYTES = SlideGeom<CFG>::SET_BYTES;
 
 	const uint32_t tid = threadIdx.x;
@@ -1076,19 +1082,25 @@ void scan_slide_kernel(ScanArgs a)
 	auto tile_full = [&](uint32_t tt) { return tt < a.full_tiles; };
 	uint32_t voff = wid * 8u;                                            // this lane's word in a tile, in bytes
 	asm volatile("" : "+v"(voff));
+	// A lane's two words (its own and the one behind it) come through a BUFFER descriptor over the tile: base = the cursor's tile
+	// address, extent = the words of the stream that are left there, so the hardware's range check returns zero for a word
+	// behind the stream's end (checked per dword) -- one 16-byte load from a 32-bit lane offset, no 64-bit vector address, no
+	// zero-initialised destination, no exec mask for the ragged tile.  (Third session of round 6: the global loads cost seven
+	// vector instructions per tile -- four v_mov, a v_mov_b64, a v_lshl_add_u64 -- on the path of every full tile.)
 	auto load_pair = [&](const Cursor &c, uint64_t &lo, uint64_t &hi) {
-		lo = hi = 0;
-		if (c.stream >= a.n_streams)
-			return;
-		const uint64_t *p = reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(c.tp) + voff);
-		if (tile_full(c.t)) {
-			lo = stream_ld(p);
-			hi = stream_ld(p + 1);
-		} else {
-			const uint64_t w = (uint64_t)c.t * TILE_WORDS + wid;
-			lo = w < a.n_words ? stream_ld(p) : 0;
-			hi = w + 1 < a.n_words ? stream_ld(p + 1) : 0;
+		uint32_t bytes = 0;                                                  // wave-uniform
+		if (c.stream < a.n_streams) {
+			bytes = (TILE_WORDS + 2u) * 8u;                                  // (a full tile: its words and two behind it are in range)
+			if (!tile_full(c.t)) {
+				const uint64_t first = (uint64_t)c.t * TILE_WORDS;
+				const uint64_t left = first < a.n_words ? a.n_words - first : 0;
+				bytes = (uint32_t)(left < TILE_WORDS + 2u ? left : TILE_WORDS + 2u) * 8u;
+			}
 		}
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(c.tp), 0, (int)bytes, 0x00020000);
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+		lo = ((uint64_t)v.y << 32) | v.x;
+		hi = ((uint64_t)v.w << 32) | v.z;
 	};
 
 	Cursor tc[TILES];
@@ -1113,19 +1125,20 @@ void scan_slide_kernel(ScanArgs a)
 				for (int k = 0; k < 4; k++)
 					d[u][k] = msb_dword(d[u][k]);
 			}
-			uint32_t validA = live, validB = live;
+			uint32_t cls_unused;
+			barker32(d[u][1], d[u][2], live, m[u][0], cls_unused);      // offsets 0..31: window bits 57.. in d1:d2
+			barker32(d[u][2], d[u][3], live, m[u][1], cls_unused);      // offsets 32..63
+			// offsets beyond the search length (the last tile of a stream only): cut out of the masks BEHIND the filter -- as two
+			// validity masks in front of it they were two register copies per tile on the path of every full tile
 			if (tc[u].stream >= a.n_streams) {
-				validA = validB = 0;
+				m[u][0] = m[u][1] = 0;
 			} else if (!tile_full(tc[u].t)) {
 				const uint64_t first_off = ((uint64_t)tc[u].t * TILE_WORDS + wid) * 64;
 				const uint64_t valid = first_off >= a.search_bits ? 0ULL
 					: (a.search_bits - first_off >= 64 ? FULL_MASK : ((1ULL << (a.search_bits - first_off)) - 1));
-				validA = (uint32_t)valid & live;
-				validB = (uint32_t)(valid >> 32) & live;
+				m[u][0] &= (uint32_t)valid;
+				m[u][1] &= (uint32_t)(valid >> 32);
 			}
-			uint32_t cls_unused;
-			barker32(d[u][1], d[u][2], validA, m[u][0], cls_unused);    // offsets 0..31: window bits 57.. in d1:d2
-			barker32(d[u][2], d[u][3], validB, m[u][1], cls_unused);    // offsets 32..63
 			c[u][0] = slide32<CFG::TAPS>(d[u][0], d[u][1], d[u][2]);
 			c[u][1] = slide32<CFG::TAPS>(d[u][1], d[u][2], d[u][3]);
 			if constexpr (CFG::INVERT) {
@@ -1149,7 +1162,7 @@ void scan_slide_kernel(ScanArgs a)
 		for (int u = 0; u < TILES; u++)
 #pragma unroll
 			for (int h = 0; h < 2; h++)
-				C[u][h] = ((uint64_t)(c[u][h + 1] | 0x80000000u) << 32) | c[u][h];
+				C[u][h] = ((uint64_t)(ABS ? c[u][h + 1] : (c[u][h + 1] | 0x80000000u)) << 32) | c[u][h];
 		struct Stage { uint32_t v[TILES][2], bw[TILES][2]; };
 		auto any_left = [&]() {
 			uint32_t any = 0;
@@ -1179,7 +1192,9 @@ void scan_slide_kernel(ScanArgs a)
 						asm volatile("" : "+v"(lane6));         // (otherwise four loop-invariant code bases sit in VGPRs through the pass loop)
 						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
 						uint32_t pos;
-						if constexpr (CFG::LEVEL2)
+						if constexpr (ABS)
+							pos = pos2[u][h] & 31u;
+						else if constexpr (CFG::LEVEL2)
 							pos = pos2[u][h];
 						else
 							asm("v_ffbh_u32 %0, %1" : "=v"(pos) : "v"((uint32_t)(C[u][h] >> 32)));
@@ -1216,11 +1231,18 @@ void scan_slide_kernel(ScanArgs a)
 		// so a lane without a survivor never looks like a candidate and the test needs no "this lane has one" term.)
 		auto step = [&](int u, int h, Stage &g) {       // next survivor of a chain: index, set read in flight
 			const uint32_t p = lowest_bit(m[u][h]);     // ~0 for an empty chain
-			m[u][h] >>= p & 31;
-			C[u][h] >>= p & 63;
-			g.v[u][h] = (uint32_t)C[u][h];
-			g.bw[u][h] = lds_ld16((g.v[u][h] >> 3) & (SET_BYTES - 2));
-			m[u][h] &= ~1u;
+			if constexpr (ABS) {
+				g.v[u][h] = (uint32_t)(C[u][h] >> (p & 63));      // (an empty chain: bit 63 alone = index 0 or 1)
+				g.bw[u][h] = lds_ld16((g.v[u][h] >> 3) & (SET_BYTES - 2));
+				m[u][h] &= m[u][h] - 1u;
+				pos2[u][h] = p;
+			} else {
+				m[u][h] >>= p & 31;
+				C[u][h] >>= p & 63;
+				g.v[u][h] = (uint32_t)C[u][h];
+				g.bw[u][h] = lds_ld16((g.v[u][h] >> 3) & (SET_BYTES - 2));
+				m[u][h] &= ~1u;
+			}
 		};
 		auto member = [&](int u, int h, const Stage &g) {   // lanes whose index is in the set (the compare's own mask: no ballot)
 			return sign16_after_shl(g.bw[u][h], g.v[u][h]);

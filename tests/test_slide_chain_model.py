@@ -1,7 +1,7 @@
 """The arithmetic of the round-5 survivor pass of scan_slide_kernel (libbtbb_amd/csrc/scan.hip), modelled in numpy and held
 against the straightforward form on the CPU -- what the GPU tests can only observe as "same hit list":
 
-  * a chain of 32 offsets as a pair of shift registers: the survivor mask and the 64-bit check register are moved down by
+  * (the two-level form; the one-level form until the third session of round 6) a chain of 32 offsets as a pair of shift registers: the survivor mask and the 64-bit check register are moved down by
     v_ffbl of the mask, so the survivor in hand sits at bit 0 and its 19-bit index is the register's low 19 bits; a marker
     planted at bit 63 of the check register tells the offset by its distance from the top (v_ffbh of the high dword);
   * an exhausted chain shifts itself out (ffbl of 0 = -1: shift amounts 31 / 63) and indexes 0 or 1 ever after -- and 0
@@ -63,6 +63,38 @@ def test_shift_register_chain_visits_every_survivor_with_its_index_and_offset():
         live = [g for g in got if g[0] is not None]
         assert live == want, (hex(mask), live[:4], want[:4])
         # (offset 31 needs check bits 31 .. 49: the marker at bit 63 is never among them)
+        assert all(idx in (0, 1) for pos, idx in got if pos is None)
+
+
+def _walk_abs(mask, c_lo, c_hi):
+    """the one-level form since the third session of round 6: absolute positions, the check register untouched, no marker"""
+    m = mask
+    reg = ((c_hi << 32) | c_lo) & M64
+    out = []
+    for _ in range(bin(mask).count("1") + 2):
+        p = _ffbl(m)                                         # 0xffffffff for an empty chain
+        v = (reg >> (p & 63)) & 0xFFFFFFFF                   # v_lshrrev_b64 takes the low six bits of p
+        if m:
+            out.append((p & 31, v & 0x7FFFF))                # p is the offset a candidate event reports
+        else:
+            assert v in (0, 1), "an exhausted chain must index 0 or 1 (bit 63 of the register alone)"
+            out.append((None, v & 0x7FFFF))
+        m &= (m - 1) & 0xFFFFFFFF
+    return out
+
+
+def test_absolute_position_chain_visits_every_survivor_with_its_index_and_offset():
+    rng = np.random.default_rng(seed(5102))
+    for it in range(4000):
+        c_lo, c_hi = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))
+        dens = (0.0, 0.05, 0.125, 0.5, 1.0)[it % 5]
+        mask = int(sum(1 << i for i in range(32) if rng.random() < dens))
+        if it % 97 == 0:
+            mask |= 1 << 31
+        stream = (c_hi << 32) | c_lo
+        got = _walk_abs(mask, c_lo, c_hi)
+        want = [(o, (stream >> o) & 0x7FFFF) for o in range(32) if (mask >> o) & 1]
+        assert [g for g in got if g[0] is not None] == want, (hex(mask), got[:4], want[:4])
         assert all(idx in (0, 1) for pos, idx in got if pos is None)
 
 
