@@ -165,6 +165,7 @@ __device__ __forceinline__ uint64_t sign16_after_shl(uint32_t x, uint32_t sh)
 	return m;
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
 __device__ __forceinline__ u32x4 lds_ld4(uint32_t byte_off) { return *reinterpret_cast<lds_u32x4_t *>(byte_off); }
 __device__ __forceinline__ void lds_st4(uint32_t byte_off, u32x4 v) { *reinterpret_cast<lds_u32x4_t *>(byte_off) = v; }
@@ -1063,14 +1064,20 @@ void scan_slide_kernel(ScanArgs a)
 		cur.t = first_tile - cur.stream * tiles_per_stream;
 		cur.tp = tile_address(cur);
 	}
-	const uint64_t step_words = (uint64_t)tile_step * TILE_WORDS;
+	// (the product is formed again at every tile -- two scalar multiplies: hoisted, it lived in a spilled SGPR pair and came back
+	// through two v_readlane per tile, vector instructions on the path of every trip)
+	auto step_words = [&]() {
+		uint32_t ts = tile_step;
+		asm volatile("" : "+s"(ts));
+		return (uint64_t)ts * TILE_WORDS;
+	};
 	auto advance = [&](Cursor &c) {
 		if (++handed >= n_mine) {
 			c.stream = a.n_streams;
 			return;
 		}
 		c.t += tile_step;
-		c.tp += step_words;
+		c.tp += step_words();
 		if (c.t >= tiles_per_stream) {
 			while (c.t >= tiles_per_stream && c.stream < a.n_streams) {
 				c.t -= tiles_per_stream;
@@ -1768,25 +1775,28 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 	constexpr int NCH = 2 * KL_WORDS;                   // chains (32-offset halves) per lane and tile
 	const uint32_t lw = tid * KL_WORDS;                 // the lane's first word in a tile
 	uint64_t nw[KL_WORDS + 1];                          // the lane's words of the next tile and the word behind them
+	static_assert(KL_WORDS == 2, "fetch: one 16-byte and one 8-byte buffer load per lane");
+	const uint32_t lw_bytes = lw * 8u;
 	auto fetch = [&](uint32_t ft, uint32_t fstream) {
-#pragma unroll
-		for (int u = 0; u <= KL_WORDS; u++)
-			nw[u] = 0;
-		if (fstream >= a.n_streams)
-			return;
-		// wave-uniform tile pointer + the lane's constant index: no 64-bit address arithmetic per lane and tile (issuing
-		// the loads had been 8.5 % of the wave time, profiles/r03_chain/known_lap_phases.txt)
-		const uint64_t *tp = a.words + (uint64_t)fstream * a.pitch_words + (uint64_t)ft * (KL_WORDS * 256);
-		if (ft < a.full_tiles) {                        // wave-uniform: every word, halo word and offset of the tile is in range
-#pragma unroll
-			for (int u = 0; u <= KL_WORDS; u++)
-				nw[u] = tp[lw + u];
-		} else {
-			const uint64_t w = (uint64_t)ft * (KL_WORDS * 256) + lw;
-#pragma unroll
-			for (int u = 0; u <= KL_WORDS; u++)
-				nw[u] = w + u < a.n_words ? tp[lw + u] : 0;
+		// The lane's run of the next tile through a buffer descriptor over the tile (as scan_slide_kernel's load_pair: the hardware's
+		// range check returns zero for the words behind the stream's end): no zero-initialised registers, no exec masks.
+		uint32_t bytes = 0;                             // wave-uniform
+		const uint64_t *tp = a.words;
+		if (fstream < a.n_streams) {
+			tp = a.words + (uint64_t)fstream * a.pitch_words + (uint64_t)ft * (KL_WORDS * 256);
+			bytes = (KL_WORDS * 256u + 1u) * 8u;         // (a full tile: every word and the halo word are in range)
+			if (ft >= a.full_tiles) {
+				const uint64_t first = (uint64_t)ft * (KL_WORDS * 256);
+				const uint64_t left = first < a.n_words ? a.n_words - first : 0;
+				bytes = (uint32_t)(left < KL_WORDS * 256u + 1u ? left : KL_WORDS * 256u + 1u) * 8u;
+			}
 		}
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(tp), 0, (int)bytes, 0x00020000);
+		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lw_bytes, 0, 0);
+		const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(lw_bytes + 16u), 0, 0);
+		nw[0] = ((uint64_t)v.y << 32) | v.x;
+		nw[1] = ((uint64_t)v.w << 32) | v.z;
+		nw[2] = ((uint64_t)w.y << 32) | w.x;
 	};
 	fetch(t, stream);
 	// The first tile's words are waited for HERE: with these loads still counted as pending at the loop head the compiler waits for
