@@ -1786,6 +1786,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			tp = a.words + (uint64_t)fstream * a.pitch_words + (uint64_t)ft * (KL_WORDS * 256);
 			bytes = (KL_WORDS * 256u + 1u) * 8u;         // (a full tile: every word and the halo word are in range)
 			if (ft >= a.full_tiles) {
+				asm volatile("" ::: "memory");              // (a real branch: flattened, its 64-bit compares are vector instructions of every tile)
 				const uint64_t first = (uint64_t)ft * (KL_WORDS * 256);
 				const uint64_t left = first < a.n_words ? a.n_words - first : 0;
 				bytes = (uint32_t)(left < KL_WORDS * 256u + 1u ? left : KL_WORDS * 256u + 1u) * 8u;
@@ -1793,7 +1794,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		}
 		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(tp), 0, (int)bytes, 0x00020000);
 		const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lw_bytes, 0, 0);
-		const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(lw_bytes + 16u), 0, 0);
+		const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lw_bytes, 16, 0);
 		nw[0] = ((uint64_t)v.y << 32) | v.x;
 		nw[1] = ((uint64_t)v.w << 32) | v.z;
 		nw[2] = ((uint64_t)w.y << 32) | w.x;
@@ -1809,21 +1810,13 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		// word index and validity of this tile's offsets from the (wave-uniform) tile number: nothing per lane is carried
 		// from the fetch but the words themselves.  Chain c = offsets 32 c .. 32 c + 31 of the lane's run; its windows lie in D[c .. c + 2].
 		const uint64_t word0 = (uint64_t)t * (KL_WORDS * 256) + lw;
-		uint32_t D[NCH + 2], m[NCH], valid[NCH];
+		uint32_t D[NCH + 2], m[NCH];
 #pragma unroll
 		for (int u = 0; u <= KL_WORDS; u++) {
 			D[2 * u] = (uint32_t)nw[u];
 			D[2 * u + 1] = (uint32_t)(nw[u] >> 32);
 		}
-#pragma unroll
-		for (int c = 0; c < NCH; c++) {
-			valid[c] = 0xffffffffu;
-			if (t >= a.full_tiles) {
-				const uint64_t first_off = word0 * 64 + 32u * c;
-				valid[c] = first_off >= a.search_bits ? 0u
-					: (a.search_bits - first_off >= 32 ? 0xffffffffu : ((1u << (uint32_t)(a.search_bits - first_off)) - 1u));
-			}
-		}
+		const bool ragged = t >= a.full_tiles;          // wave-uniform: offsets beyond the search length are cut out BEHIND the filter
 		const uint32_t this_stream = stream;
 		t += gridDim.x;
 		while (t >= tiles_per_stream && stream < a.n_streams) {
@@ -1854,7 +1847,16 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			for (int c = 0; c < NCH; c++) {
 				pair_planes<0>(D[c + 1], D[c + 2], P[(c + 1) & 1]);
 				m[c] = (wide ? top16_filter<CLS>(P[c & 1], P[(c + 1) & 1], flip, limit)
-					     : top12_filter<CLS>(P[c & 1], P[(c + 1) & 1], flip, limit)) & valid[c];
+					     : top12_filter<CLS>(P[c & 1], P[(c + 1) & 1], flip, limit));
+			}
+		}
+		if (ragged) {                                   // (as four validity masks in front of the filter: a register copy and an AND per chain of every tile)
+			asm volatile("" ::: "memory");              // (keeps the compiler from flattening the branch into selects)
+#pragma unroll
+			for (int c = 0; c < NCH; c++) {
+				const uint64_t first_off = word0 * 64 + 32u * c;
+				m[c] &= first_off >= a.search_bits ? 0u
+					: (a.search_bits - first_off >= 32 ? 0xffffffffu : ((1u << (uint32_t)(a.search_bits - first_off)) - 1u));
 			}
 		}
 #ifdef SCAN_PROFILE
