@@ -767,16 +767,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lap_any_kernel(ScanArgs a)
 // Candidates ranked beyond the ring's free entries are checked in place, never dropped (a stream made of sync
 // words: tests/test_gpu_scan.py adversarial cases).
 // Geometry and tuning (every A/B behind these values is in profiles/: r03_ab, r05_scan).
-#ifndef SLIDE_TILES
 #define SLIDE_TILES 2                      // tiles a wave works on per trip (2 * SLIDE_TILES chains per lane); 1: +15 %, 3 (80 VGPRs): +1 %
-#endif
 #define SLIDE4_TILES 3                     // ... of the two-level form (tables for three and four errors; 2: +2.5 %, 4: +20 %)
 #define SLIDE_WGS 2                        // workgroups per CU the kernel is cut for
 #define SLIDE_THREADS 768                  // workgroup size = words per tile (a multiple of 256: whole waves per SIMD); 2 x 1024: +2.5 % (round 5, spills); round 6,
                                            // the ordered form at 64 registers without a spill: 3.24 against 3.01 ms -- eight waves per SIMD are SLOWER (profiles/r06_order)
-#ifndef SLIDE_FIXED
 #define SLIDE_FIXED 6                      // passes run before the first "anything left?" test of a trip (5: +2 %, 7: +1 %)
-#endif
 #define SLIDE_DRAIN_AT 60u                 // 64-entry ring: entries at which a trip end drains it (32 / 48 / 56 / 60: 3.56 / 3.48 / 3.46 / 3.455 ms; round 6 on
                                            // the 63-word kernel: 32 +1.5 %, 40 and 48 nothing -- profiles/r06_scan/ab_b3_drain_threshold.txt)
 #define SLIDE_DRAIN_AT_ORD 40u             // ... of the ordered form (see its drain)
