@@ -1260,7 +1260,7 @@ void scan_slide_kernel(ScanArgs a)
 		// looked at in the NEXT pass, behind that pass's own steps (level2_take): the L2's answer has a pass to arrive in.
 		// (No "this chain has no member in any lane" shortcut: a branch per chain makes the compiler wait for the loads at
 		// every merge -- 1.9 against 1.43 ms per GiB with tables for three errors, where a third of the chain-passes could skip.)
-		uint32_t v2[TILES][2], w2[TILES][2];
+		uint32_t v2[TILES][2], w2[TILES][2] = {};            // (w2: a lane without a look-up in flight keeps a stale word; `sent` masks its answer)
 		uint64_t sent[TILES][2], any_sent = 0;               // lanes with a look-up in flight, per chain
 		auto level2_send = [&](const uint64_t (&cms)[TILES][2]) {
 			any_sent = 0;
@@ -1272,7 +1272,6 @@ void scan_slide_kernel(ScanArgs a)
 					any_sent |= cms[u][h];
 					asm("v_ffbh_u32 %0, %1" : "=v"(pos2[u][h]) : "v"((uint32_t)(C[u][h] >> 32)));
 					v2[u][h] = alignbit(c2[u][h + 1], c2[u][h], pos2[u][h]);
-					w2[u][h] = 0;
 					if (__builtin_amdgcn_inverse_ballot_w64(cms[u][h]))
 						w2[u][h] = a.t.slide4b_bitmap[(v2[u][h] >> 5) & ((1u << (SLIDE4B_BITS - 5)) - 1)];
 				}
@@ -1312,7 +1311,15 @@ void scan_slide_kernel(ScanArgs a)
 				}
 			if constexpr (CFG::LEVEL2) {
 				level2_take();                           // the previous pass's look-ups, then this pass's are sent
-				if (any)
+				// ("any member in the wave" formed HERE and on the scalar unit by name: carried across level2_take's branches the
+				// compiler re-formed it from the six lane masks with twelve VECTOR instructions per pass)
+				uint64_t any2 = 0;
+#pragma unroll
+				for (int u = 0; u < TILES; u++)
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						asm("s_or_b64 %0, %1, %2" : "=s"(any2) : "s"(any2), "s"(cms[u][h]) : "scc");
+				if (any2)
 					level2_send(cms);
 			} else if (any) {                            // some lane of the wave holds a candidate (half of the passes)
 				events(cms);
