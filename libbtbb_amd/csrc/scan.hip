@@ -263,10 +263,11 @@ __device__ __forceinline__ void barker32(uint32_t dm, uint32_t dh, uint32_t vali
 	const uint32_t b = BITOP3(s3, s4, s5, 0x69);       // m3 ^ m4 ^ m5
 	const uint32_t cb = BITOP3(s3, s4, s5, 0xd4);      // maj(s3, s4, ~s5)
 	const uint32_t cc = BITOP3(a, b, s6, 0xe8);        // carry of the ones column
-	const uint32_t twos = BITOP3(ca, cb, cc, 0x96);
-	const uint32_t fours = BITOP3(ca, cb, cc, 0xe8);
-	pass = BITOP3(twos, fours, valid, 0x82);           // valid & ~(twos ^ fours)
-	cls = ~(twos | fours);
+	// count = ones + 2 (ca + cb + cc): it is 0 or 1 iff the three carries are all clear, 6 or 7 iff they are all set -- one
+	// "all three equal" instead of the twos and fours planes and their comparison (third session of round 6: seven instead of
+	// eight three-input instructions per 32 offsets)
+	pass = BITOP3(ca, cb, cc, 0x81) & valid;
+	cls = BITOP3(ca, cb, cc, 0x01);                    // all clear: count in {0, 1}
 }
 
 // (scan_lap_any_kernel, tables for five errors)  One survivor costs about 17 VALU + 2 DS instructions:
@@ -1313,12 +1314,10 @@ void scan_slide_kernel(ScanArgs a)
 				level2_take();                           // the previous pass's look-ups, then this pass's are sent
 				// ("any member in the wave" formed HERE and on the scalar unit by name: carried across level2_take's branches the
 				// compiler re-formed it from the six lane masks with twelve VECTOR instructions per pass)
-				uint64_t any2 = 0;
-#pragma unroll
-				for (int u = 0; u < TILES; u++)
-#pragma unroll
-					for (int h = 0; h < 2; h++)
-						asm("s_or_b64 %0, %1, %2" : "=s"(any2) : "s"(any2), "s"(cms[u][h]) : "scc");
+				static_assert(!CFG::LEVEL2 || TILES == 3, "the scalar OR below is written for six chains");
+				uint64_t any2;
+				asm("s_or_b64 %0, %1, %2\n\ts_or_b64 %0, %0, %3\n\ts_or_b64 %0, %0, %4\n\ts_or_b64 %0, %0, %5\n\ts_or_b64 %0, %0, %6"
+				    : "=&s"(any2) : "s"(cms[0][0]), "s"(cms[0][1]), "s"(cms[1][0]), "s"(cms[1][1]), "s"(cms[TILES - 1][0]), "s"(cms[TILES - 1][1]) : "scc");
 				if (any2)
 					level2_send(cms);
 			} else if (any) {                            // some lane of the wave holds a candidate (half of the passes)
