@@ -1201,7 +1201,7 @@ void scan_slide_kernel(ScanArgs a)
 						// the marker planted above the chain's check bits has moved down by exactly the offsets passed
 						uint32_t pos;
 						if constexpr (ABS)
-							pos = pos2[u][h] & 31u;
+							pos = pos2[u][h];                   // (a candidate's chain was not empty: 0 .. 31)
 						else if constexpr (CFG::LEVEL2)
 							pos = pos2[u][h];
 						else
@@ -1545,6 +1545,21 @@ __device__ __forceinline__ uint32_t top16_filter(const uint32_t *lowp, const uin
 	const uint32_t o1 = FA_SUM(s0, s1, s2), k0 = FA_CARRY(s0, s1, s2);
 	const uint32_t o2 = bitop3_tt<tt3(0x96, false, false, INV(15))>(s3, s4, m[15]), k1 = bitop3_tt<tt3(0xe8, false, false, INV(15))>(s3, s4, m[15]);
 #undef INV
+	// limit 2 or 3 (third session of round 6): count = o1 + o2 + 2 x (bits set among W = c0 .. c4, k0, k1), so
+	//   count <= 2  <=>  no bit of W, or exactly one and neither o1 nor o2     = at_most_one(W) & ~(any(W) & (o1 | o2))
+	//   count <= 3  <=>  no bit of W, or exactly one and not both o1 and o2    = at_most_one(W) & ~(any(W) & o1 & o2)
+	// at_most_one over the groups (c0 c1 c2) (c3 c4 k0) (k1): no group holds two, no two groups hold one -- nine instructions
+	// where the twos / fours columns, their carries and the compare took thirteen (27 -> 23 per 32 offsets)
+	if (limit == 2 || limit == 3) {
+		const uint32_t a0 = BITOP3(c0, c1, c2, 0xfe), t0 = BITOP3(c0, c1, c2, 0xe8);     // any / at least two of a group
+		const uint32_t a1 = BITOP3(c3, c4, k0, 0xfe), t1 = BITOP3(c3, c4, k0, 0xe8);
+		const uint32_t two_groups = BITOP3(a0, a1, k1, 0xe8);
+		const uint32_t any = BITOP3(a0, a1, k1, 0xfe);
+		const uint32_t odd = limit == 2 ? BITOP3(any, o1, o2, 0xe0)                       // any & (o1 | o2)
+						: BITOP3(any, o1, o2, 0x80);                      // any & o1 & o2
+		const uint32_t bad = BITOP3(t0, t1, two_groups, 0xfe);
+		return ~(bad | odd);
+	}
 	const uint32_t ones = o1 ^ o2, k2 = o1 & o2;
 	// weight 2: c0..c4, k0, k1, k2
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);

@@ -94,3 +94,27 @@ def test_filter_model_is_a_necessary_condition_and_equals_its_definition():
             assert hits <= want and len(hits) >= 10
             if limit >= 2:
                 assert len(want) < n // 50                                # sixteen planes: a sparse survivor set
+
+
+def test_limit_2_and_3_network_of_the_sixteen_plane_filter_equals_the_count():
+    """top16_filter's shortcut for limits 2 and 3 (third session of round 6), over all 2^16 values of the sixteen mismatch bits:
+    five full adders over m0 .. m14, two over their sums and m15, then
+        count <= 2  <=>  at_most_one(W) & ~(any(W) & (o1 | o2)),   count <= 3  <=>  at_most_one(W) & ~(any(W) & o1 & o2)
+    with W = c0 .. c4, k0, k1 in the groups (c0 c1 c2) (c3 c4 k0) (k1)."""
+    v = np.arange(1 << 16, dtype=np.uint32)
+    m = [((v >> k) & 1).astype(bool) for k in range(16)]
+    fa = lambda a, b, c: (a ^ b ^ c, (a & b) | (a & c) | (b & c))             # noqa: E731
+    s0, c0 = fa(m[0], m[1], m[2])
+    s1, c1 = fa(m[3], m[4], m[5])
+    s2, c2 = fa(m[6], m[7], m[8])
+    s3, c3 = fa(m[9], m[10], m[11])
+    s4, c4 = fa(m[12], m[13], m[14])
+    o1, k0 = fa(s0, s1, s2)
+    o2, k1 = fa(s3, s4, m[15])
+    a0, t0 = c0 | c1 | c2, fa(c0, c1, c2)[1]
+    a1, t1 = c3 | c4 | k0, fa(c3, c4, k0)[1]
+    two_groups, any_w = fa(a0, a1, k1)[1], a0 | a1 | k1
+    bad = t0 | t1 | two_groups
+    count = sum(x.astype(np.int32) for x in m)
+    assert np.array_equal(~(bad | (any_w & (o1 | o2))), count <= 2)
+    assert np.array_equal(~(bad | (any_w & o1 & o2)), count <= 3)
