@@ -1487,12 +1487,24 @@ __device__ __forceinline__ uint32_t top12_filter(const uint32_t *lowp, const uin
 #define INV(k) (K && barker_bit(CLS, (k) - 5))
 #define FA_SUM(a, b, c) BITOP3((a), (b), (c), 0x96)
 #define FA_CARRY(a, b, c) BITOP3((a), (b), (c), 0xe8)
+	if (limit == 0) {                                   // no mismatch at all: the OR of the twelve planes (six instructions; third session of round 6)
+		const uint32_t r0 = BITOP3(m[0], m[1], m[2], 0xfe);
+		const uint32_t r1 = bitop3_tt<tt3(0xfe, false, false, INV(5))>(m[3], m[4], m[5]);
+		const uint32_t r2 = bitop3_tt<tt3(0xfe, INV(6), INV(7), INV(8))>(m[6], m[7], m[8]);
+		const uint32_t r3 = bitop3_tt<tt3(0xfe, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]);
+		return ~(BITOP3(r0, r1, r2, 0xfe) | r3);
+	}
 	const uint32_t s0 = FA_SUM(m[0], m[1], m[2]), c0 = FA_CARRY(m[0], m[1], m[2]);
 	const uint32_t s1 = bitop3_tt<tt3(0x96, false, false, INV(5))>(m[3], m[4], m[5]), c1 = bitop3_tt<tt3(0xe8, false, false, INV(5))>(m[3], m[4], m[5]);
 	const uint32_t s2 = bitop3_tt<tt3(0x96, INV(6), INV(7), INV(8))>(m[6], m[7], m[8]), c2 = bitop3_tt<tt3(0xe8, INV(6), INV(7), INV(8))>(m[6], m[7], m[8]);
 	const uint32_t s3 = bitop3_tt<tt3(0x96, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]), c3 = bitop3_tt<tt3(0xe8, INV(9), INV(10), INV(11))>(m[9], m[10], m[11]);
 #undef INV
 	const uint32_t o1 = FA_SUM(s0, s1, s2), k0 = FA_CARRY(s0, s1, s2);
+	if (limit == 1) {                                   // count = o1 + s3 + 2 x (c0 .. c3, k0): <= 1 <=> none of those five and not both of o1, s3
+		const uint32_t w = BITOP3(c0, c1, c2, 0xfe);
+		const uint32_t x = BITOP3(c3, k0, w, 0xfe);
+		return ~BITOP3(x, o1, s3, 0xf8);                // ~(x | (o1 & s3))
+	}
 	const uint32_t ones = o1 ^ s3, k1 = o1 & s3;
 	const uint32_t t0 = FA_SUM(c0, c1, c2), f0 = FA_CARRY(c0, c1, c2);
 	const uint32_t t1 = FA_SUM(c3, k0, k1), f1 = FA_CARRY(c3, k0, k1);

@@ -118,3 +118,19 @@ def test_limit_2_and_3_network_of_the_sixteen_plane_filter_equals_the_count():
     count = sum(x.astype(np.int32) for x in m)
     assert np.array_equal(~(bad | (any_w & (o1 | o2))), count <= 2)
     assert np.array_equal(~(bad | (any_w & o1 & o2)), count <= 3)
+
+
+def test_limit_0_and_1_networks_of_the_twelve_plane_filter_equal_the_count():
+    """top12_filter's shortcuts (third session of round 6), over all 2^12 values of the twelve mismatch bits: limit 0 = none of them;
+    limit 1: four full adders over m0 .. m11, one over their sums s0 s1 s2 -> (o1, k0); count = o1 + s3 + 2 x (c0 .. c3, k0)."""
+    v = np.arange(1 << 12, dtype=np.uint32)
+    m = [((v >> k) & 1).astype(bool) for k in range(12)]
+    fa = lambda a, b, c: (a ^ b ^ c, (a & b) | (a & c) | (b & c))             # noqa: E731
+    (s0, c0), (s1, c1), (s2, c2), (s3, c3) = fa(m[0], m[1], m[2]), fa(m[3], m[4], m[5]), fa(m[6], m[7], m[8]), fa(m[9], m[10], m[11])
+    o1, k0 = fa(s0, s1, s2)
+    count = sum(x.astype(np.int32) for x in m)
+    assert np.array_equal(~((c0 | c1 | c2) | c3 | k0 | (o1 & s3)), count <= 1)
+    any_m = m[0]
+    for x in m[1:]:
+        any_m = any_m | x
+    assert np.array_equal(~any_m, count == 0)
