@@ -1917,7 +1917,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 			}
 			if (!__ballot(mm != 0))
 				break;
-			const uint32_t p1 = __builtin_ctz(mm | 0x80000000u);
+			const uint32_t p1 = lowest_bit(mm);             // (-1 for no survivor: see check() below)
 			const int e1 = __popc(alignbit(db, da, p1) ^ ac_lo) + __popc(alignbit(dc, db, p1) ^ ac_hi);          // :433
 			const bool hit1 = mm != 0 && e1 <= limit;
 			const uint32_t rest = mm & (mm - 1);
@@ -1935,7 +1935,7 @@ __global__ __launch_bounds__(256) void scan_known_lap_kernel(ScanArgs a)
 		int e[NCH];
 		bool hit[NCH];
 		auto check = [&](int c) {
-			p[c] = __builtin_ctz(m[c] | 0x80000000u);
+			p[c] = lowest_bit(m[c]);                        // (-1 for an empty chain: the funnel shifts below take its low five bits, and `hit` is masked)
 			e[c] = __popc(alignbit(D[c + 1], D[c], p[c]) ^ ac_lo)
 				+ __popc(alignbit(D[c + 2], D[c + 1], p[c]) ^ ac_hi);          // :433
 			hit[c] = m[c] != 0 && e[c] <= limit;
